@@ -1,0 +1,92 @@
+"""Synthetic slide backend (``.synth`` descriptor files), SURVEY.md section 8d.
+
+A ``.synth`` file is a small JSON object ``{"width", "height", "seed", "n_ellipses",
+"mag", "mpp", "downsamples"}``.  Pixels are a pure function of those numbers
+(``synth_pixels.render_region``), so a 100 000 x 100 000 slide costs nothing to
+store and any tile can be produced on the host (this class) or directly in HBM
+(csrc/synth.hip, bit-identical).  Registered with ``WSIFactory`` under backend
+name ``synth``, the same seam the reference offers (wsi_factory.py:41-53).
+"""
+from __future__ import annotations
+
+import json
+from typing import Literal, Optional, Tuple, Union
+
+import numpy as np
+from PIL import Image
+
+from .iwsi import IWSI
+from .synth_pixels import SynthSpec, analytic_mask, render_region
+
+
+def load_spec(path: str) -> SynthSpec:
+    with open(path, "r", encoding="utf-8") as handle:
+        raw = json.load(handle)
+    return SynthSpec(
+        width=int(raw["width"]), height=int(raw["height"]), seed=int(raw.get("seed", 1234)),
+        n_ellipses=int(raw.get("n_ellipses", 12)), mag=int(raw.get("mag", 20)),
+        mpp=float(raw.get("mpp", 0.5)),
+        downsamples=tuple(float(d) for d in raw.get("downsamples", (1.0, 4.0, 16.0))))
+
+
+def write_spec(path: str, spec: SynthSpec) -> None:
+    with open(path, "w", encoding="utf-8") as handle:
+        json.dump({"width": spec.width, "height": spec.height, "seed": spec.seed,
+                   "n_ellipses": spec.n_ellipses, "mag": spec.mag, "mpp": spec.mpp,
+                   "downsamples": list(spec.downsamples)}, handle)
+
+
+class SynthWSI(IWSI):
+    def __init__(self, path: str, mpp: Optional[float] = None, **_: object) -> None:
+        super().__init__(path=path, mpp=mpp)
+        self.spec: Optional[SynthSpec] = None
+
+    def _setup(self) -> None:
+        spec = load_spec(self.path)
+        self.spec = spec
+        self.w, self.h = spec.width, spec.height
+        self.ds = [float(d) for d in spec.downsamples]
+        self.nlvl = len(self.ds)
+        self.dims = [(int(round(spec.width / d)), int(round(spec.height / d))) for d in self.ds]
+        self.meta = {"openslide.vendor": "synthetic", "synth.seed": str(spec.seed)}
+        self.mpp = self._extract_mpp()
+        self.mag = self._extract_mag()
+
+    def _extract_mpp(self) -> Optional[float]:
+        if self._mpp_manual is not None:
+            return self.validate_mpp(float(self._mpp_manual), source="user-provided mpp")
+        return self.spec.mpp if self.spec else None
+
+    def _extract_mag(self) -> Optional[int]:
+        return int(self.spec.mag) if self.spec else None
+
+    def extract(self, xy: Tuple[int, int], lv: int, wh: Tuple[int, int], *,
+                mode: Literal["array", "image"] = "array") -> Union[np.ndarray, Image.Image]:
+        self._ensure_loaded()
+        if not 0 <= lv < (self.nlvl or 0):
+            raise ValueError(f"Invalid level {lv}")
+        region = render_region(self.spec, int(xy[0]), int(xy[1]), int(wh[0]), int(wh[1]), int(lv))
+        if mode == "array":
+            return region
+        if mode == "image":
+            return Image.fromarray(region)
+        raise ValueError(f"Invalid mode: {mode}")
+
+    def get_size(self, lv: int = 0) -> Tuple[int, int]:
+        self._ensure_loaded()
+        return self.dims[lv]
+
+    def get_thumb(self, max_hw: Tuple[int, int]) -> Image.Image:
+        self._ensure_loaded()
+        level = (self.nlvl or 1) - 1
+        image = Image.fromarray(self.extract((0, 0), level, self.dims[level]))
+        image.thumbnail(max_hw)
+        return image
+
+    def tissue_mask(self, thumb_max: int = 1024) -> np.ndarray:
+        """Analytic tissue mask on the thumbnail grid (stands in for SAM2 on synthetic slides)."""
+        self._ensure_loaded()
+        return analytic_mask(self.spec, thumb_max)
+
+    def cleanup(self) -> None:
+        self._loaded = False

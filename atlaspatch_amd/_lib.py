@@ -1,0 +1,119 @@
+"""ctypes binding of libatlaspatch_hip.so (the C ABI declared in include/atlaspatch_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C atlaspatch_amd/csrc``.
+There is NO fallback: if the library is missing or a call fails, the product raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+AP_F32, AP_F16, AP_BF16 = 0, 1, 2
+AP_OK = 0
+AP_ERR_CAPACITY = -6
+
+_LIB_NAME = "libatlaspatch_hip.so"
+_lock = threading.Lock()
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+class VitConfig(C.Structure):
+    _fields_ = [("image_size", C.c_int), ("patch_size", C.c_int), ("dim", C.c_int),
+                ("depth", C.c_int), ("heads", C.c_int), ("mlp_dim", C.c_int),
+                ("ln_eps", C.c_float), ("layer_scale", C.c_int), ("compute_dtype", C.c_int)]
+
+
+# name -> (restype, argtypes); every symbol include/atlaspatch_hip.h declares
+SIGNATURES = {
+    "ap_abi_version": (C.c_int, []),
+    "ap_last_error": (C.c_char_p, []),
+    "ap_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
+    "ap_preproc_u8hwc_to_chw": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p,
+                                          C.c_int, C.c_void_p]),
+    "ap_preproc_u8hwc_to_patchrows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
+                                                C.POINTER(C.c_float), C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "ap_vit_create": (C.c_int, [C.POINTER(VitConfig), C.POINTER(C.c_void_p)]),
+    "ap_vit_destroy": (None, [C.c_void_p]),
+    "ap_vit_set_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),
+    "ap_vit_finalize": (C.c_int, [C.c_void_p]),
+    "ap_vit_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
+    "ap_vit_embed_dim": (C.c_int, [C.c_void_p]),
+    "ap_vit_forward_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
+                                    C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ap_vit_forward_chw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                     C.c_size_t, C.c_void_p]),
+    "ap_contours_from_mask": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_double,
+                                        C.c_double, C.POINTER(C.c_void_p), C.c_void_p]),
+    "ap_contours_destroy": (None, [C.c_void_p]),
+    "ap_contours_count": (C.c_int, [C.c_void_p]),
+    "ap_contours_num_holes": (C.c_int, [C.c_void_p, C.c_int]),
+    "ap_contours_points": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
+    "ap_grid_coords": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                 C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]),
+    "ap_synth_tiles": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
+                                 C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+}
+
+
+def library_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises HipLibraryError when the .so is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = library_path()
+        if not os.path.exists(path):
+            raise HipLibraryError(
+                f"{path} not found: the HIP extension has not been built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C atlaspatch_amd/csrc`. "
+                "There is no CPU fallback.")
+        try:
+            # torch bundles its own libamdhip64.so.7; import it first so both share ONE HIP runtime
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch is optional for symbol checks
+            pass
+        lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return _lib
+
+
+def check(code: int, what: str = "") -> None:
+    if code != AP_OK:
+        msg = load().ap_last_error()
+        raise HipLibraryError(f"{what or 'libatlaspatch_hip'} failed with code {code}: "
+                              f"{msg.decode(errors='replace') if msg else ''}")
+
+
+def f3(values):
+    arr = (C.c_float * 3)(*[float(v) for v in values])
+    return arr
+
+
+def torch_dtype_code(dtype) -> int:
+    import torch
+    table = {torch.float32: AP_F32, torch.float16: AP_F16, torch.bfloat16: AP_BF16}
+    if dtype not in table:
+        raise ValueError(f"unsupported compute dtype {dtype}")
+    return table[dtype]
+
+
+def current_stream_ptr(device=None) -> int:
+    import torch
+    return int(torch.cuda.current_stream(device).cuda_stream)

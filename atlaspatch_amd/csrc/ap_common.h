@@ -1,0 +1,105 @@
+// Internal helpers shared by the gfx950 kernels (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include "../../include/atlaspatch_hip.h"
+
+namespace ap {
+
+void set_error(const char* fmt, ...);
+
+#define AP_HIP_CHECK(expr)                                                              \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            ap::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),        \
+                          __FILE__, __LINE__);                                          \
+            return AP_ERR_HIP;                                                          \
+        }                                                                               \
+    } while (0)
+
+#define AP_REQUIRE(cond, ...)                                                           \
+    do {                                                                                \
+        if (!(cond)) {                                                                  \
+            ap::set_error(__VA_ARGS__);                                                 \
+            return AP_ERR_INVALID;                                                      \
+        }                                                                               \
+    } while (0)
+
+using f16 = _Float16;
+using bf16 = __bf16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
+
+inline size_t dtype_size(int dt) { return dt == AP_F32 ? 4 : 2; }
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+template <typename T> struct DType;
+template <> struct DType<float> { static constexpr int id = AP_F32; };
+template <> struct DType<f16> { static constexpr int id = AP_F16; };
+template <> struct DType<bf16> { static constexpr int id = AP_BF16; };
+
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ f16 from_f32<f16>(float v) { return (f16)v; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }
+
+// ---- GEMM ------------------------------------------------------------------------------
+// C[m][n] = sum_k A[m][k] * W[n][k]  (+ epilogue); A: activations [M, lda], W: weights [N, ldw],
+// both K-contiguous in the compute dtype.
+enum GemmEpilogue {
+    EPI_BIAS_STORE = 0,    // out[m][n] = T(acc + bias[n])
+    EPI_BIAS_GELU = 1,     // out[m][n] = T(gelu_erf(acc + bias[n]))
+    EPI_BIAS_RESID = 2,    // resid[m][n] += (acc + bias[n]) * (gamma ? gamma[n] : 1)   (f32, in place)
+    EPI_PATCH_EMBED = 3,   // tok[(m / P) * (P + 1) + 1 + m % P][n] = acc + bias[n] + pos[1 + m % P][n]
+};
+
+struct GemmArgs {
+    const void* A; int lda;
+    const void* W; int ldw;
+    int M, N, K;
+    const float* bias;
+    const float* gamma;      // EPI_BIAS_RESID only (may be null)
+    const float* pos;        // EPI_PATCH_EMBED: [P + 1, N]
+    void* out; int ldo;      // T (STORE / GELU) or f32 (RESID / PATCH_EMBED)
+    int P;                   // EPI_PATCH_EMBED: patches per image
+};
+
+int launch_gemm(int dtype, int epilogue, const GemmArgs& a, hipStream_t stream);
+
+// ---- LayerNorm / attention / misc ---------------------------------------------------------
+// rows of f32 [rows, dim] (row stride `stride` elements) -> T [rows, dim] (dense)
+int launch_layernorm(int dtype, const float* x, long stride, int rows, int dim,
+                     const float* gamma, const float* beta, float eps, void* out,
+                     hipStream_t stream);
+// f32 out variant used for the final norm on CLS rows
+int launch_layernorm_f32out(const float* x, long stride, int rows, int dim, const float* gamma,
+                            const float* beta, float eps, float* out, hipStream_t stream);
+// qkv: T [n*tokens, 3*dim] (q | k | v), out: T [n*tokens, dim]
+int launch_attention(int dtype, const void* qkv, void* out, int n, int tokens, int heads,
+                     int head_dim, hipStream_t stream);
+int launch_cls_init(float* tok, const float* cls, const float* pos, int n, int tokens, int dim,
+                    hipStream_t stream);
+int launch_convert(int dtype, const float* src, void* dst, size_t count, hipStream_t stream);
+// [n,3,S,S] (f32 or T) -> patch rows T [n*g*g, ld]
+int launch_chw_to_patchrows(int x_dtype, int dtype, const void* x, int n, int S, int ps, void* dst,
+                            int ld, hipStream_t stream);
+
+// K1 (preproc.hip)
+int get_norm_lut(const float mean[3], const float stdv[3], int dtype, hipStream_t stream,
+                 const void** out);
+int preproc_chw(const uint8_t* src, int n, int h, int w, int top, int left, int oh, int ow,
+                const float mean[3], const float stdv[3], void* dst, int dtype, hipStream_t stream);
+int preproc_patchrows(const uint8_t* src, int n, int h, int w, int top, int left, int oh, int ow,
+                      int ps, const float mean[3], const float stdv[3], void* dst, int ld, int dtype,
+                      hipStream_t stream);
+
+}  // namespace ap

@@ -1,0 +1,335 @@
+// Tissue mask -> patch coordinates on the device.
+//
+//   threshold_kernel   C1: (mask > 0.5) -> u8, one 16-byte load per lane (HBM-bound, 5 B/px)
+//   grid_flags_kernel  C5: one lane per grid cell.  The cell's tissue polygon and its holes are
+//                      streamed through LDS in chunks (every lane reads the same edge -> LDS
+//                      broadcast, no bank conflicts); each lane runs OpenCV's integer
+//                      point-in-polygon test for the cell centre against every hole (strictly
+//                      inside -> reject) and for the four diagonal probes against the tissue
+//                      polygon (inside or on the edge -> keep), all four probes in one pass.
+//   block counts + scan + compact: kept cells are ranked with wave ballots / popcounts so the
+//                      rows come out in the reference's order (contour-major, row-major grid).
+//
+// Integer work, bit-exact by construction: int32 coordinates, int64 cross products
+// (extraction.py:67-103, contours.py:22-38; cv::pointPolygonTest integer branch [3P]).
+// Algorithmic bytes: 8 B per polygon vertex per 256-cell block (LDS-served after the first
+// touch) + 20 B per emitted row; latency/ALU-bound, reported as cells/s.
+#include <vector>
+#include "ap_common.h"
+#include "coords_internal.h"
+
+struct ap_contours {
+    ap::ContourSet set;
+};
+
+namespace ap {
+namespace {
+
+__global__ void threshold_kernel(const float* __restrict__ mask, uint8_t* __restrict__ out, size_t count) {
+    const size_t i4 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 + 3 < count) {
+        const f32x4 v = *(const f32x4*)(mask + i4);
+        uint32_t packed = (v[0] > 0.5f ? 255u : 0u) | (v[1] > 0.5f ? 255u << 8 : 0u) |
+                          (v[2] > 0.5f ? 255u << 16 : 0u) | (v[3] > 0.5f ? 255u << 24 : 0u);
+        *(uint32_t*)(out + i4) = packed;
+    } else {
+        for (size_t i = i4; i < count; ++i) out[i] = mask[i] > 0.5f ? 255 : 0;
+    }
+}
+
+struct TissueDesc {          // one per tissue contour
+    int poly_off, poly_cnt;  // vertex range in the packed vertex array
+    int hole_first, hole_cnt;   // range in the hole table
+    int x0, y0, nx, ny;      // grid origin and size
+    long cell_off;           // first cell index (global)
+};
+struct HoleDesc { int poly_off, poly_cnt; };
+struct BlockDesc { int tissue; int cell0; };   // 256 cells of one tissue contour
+
+constexpr int kChunk = 1024;   // vertices per LDS chunk
+
+struct PipState {
+    int cnt; int on;
+};
+
+__device__ __forceinline__ void pip_edge(int px, int py, int v0x, int v0y, int vx, int vy, PipState& s) {
+    const bool skip = (v0y <= py && vy <= py) || (v0y > py && vy > py) || (v0x < px && vx < px);
+    if (skip) {
+        if (py == vy && (px == vx || (py == v0y && ((v0x <= px && px <= vx) || (vx <= px && px <= v0x)))))
+            s.on = 1;
+        return;
+    }
+    long long dist = (long long)(py - v0y) * (vx - v0x) - (long long)(px - v0x) * (vy - v0y);
+    if (dist == 0) { s.on = 1; return; }
+    if (vy < v0y) dist = -dist;
+    s.cnt += dist > 0;
+}
+
+// result of cv::pointPolygonTest(measureDist=false): +1 inside, 0 on edge, -1 outside
+__device__ __forceinline__ int pip_result(const PipState& s) { return s.on ? 0 : ((s.cnt & 1) ? 1 : -1); }
+
+__global__ __launch_bounds__(256) void grid_flags_kernel(const int2* __restrict__ verts,
+                                                         const TissueDesc* __restrict__ tissues,
+                                                         const HoleDesc* __restrict__ holes,
+                                                         const BlockDesc* __restrict__ blocks,
+                                                         int patch, int step, uint8_t* __restrict__ flags) {
+    __shared__ int2 sv[kChunk + 1];
+    const BlockDesc bd = blocks[blockIdx.x];
+    const TissueDesc td = tissues[bd.tissue];
+    const int ncell = td.nx * td.ny;
+    const int cell = bd.cell0 + threadIdx.x;
+    const bool live = cell < ncell;
+    const int iy = live ? cell / td.nx : 0, ix = live ? cell - iy * td.nx : 0;
+    const int x = td.x0 + ix * step, y = td.y0 + iy * step;
+    const int half = patch / 2;
+    const int cx = x + half, cy = y + half;
+    const int shift = half / 2;                       // int(patch // 2 * 0.5)
+
+    auto scan = [&](int off, int cnt, auto&& per_edge) {
+        // edges (v[i-1] -> v[i]) for i in [0, cnt), v[-1] = v[cnt-1]
+        for (int base = 0; base < cnt; base += kChunk) {
+            const int m = min(kChunk, cnt - base);
+            __syncthreads();
+            for (int i = threadIdx.x; i <= m; i += 256) {
+                int src = base + i - 1;               // sv[0] = vertex before the chunk
+                if (src < 0) src = cnt - 1;
+                sv[i] = verts[off + src];
+            }
+            __syncthreads();
+            for (int i = 0; i < m; ++i) per_edge(sv[i], sv[i + 1]);
+        }
+    };
+
+    bool in_hole = false;
+    for (int hI = 0; hI < td.hole_cnt; ++hI) {
+        const HoleDesc hd = holes[td.hole_first + hI];
+        PipState s{0, 0};
+        scan(hd.poly_off, hd.poly_cnt, [&](int2 a, int2 b) { pip_edge(cx, cy, a.x, a.y, b.x, b.y, s); });
+        if (pip_result(s) > 0) in_hole = true;
+    }
+    PipState p0{0, 0}, p1{0, 0}, p2{0, 0}, p3{0, 0};
+    scan(td.poly_off, td.poly_cnt, [&](int2 a, int2 b) {
+        pip_edge(cx - shift, cy - shift, a.x, a.y, b.x, b.y, p0);
+        if (shift > 0) {
+            pip_edge(cx + shift, cy + shift, a.x, a.y, b.x, b.y, p1);
+            pip_edge(cx + shift, cy - shift, a.x, a.y, b.x, b.y, p2);
+            pip_edge(cx - shift, cy + shift, a.x, a.y, b.x, b.y, p3);
+        }
+    });
+    bool keep = pip_result(p0) >= 0;
+    if (shift > 0) keep = keep || pip_result(p1) >= 0 || pip_result(p2) >= 0 || pip_result(p3) >= 0;
+    if (live) flags[td.cell_off + cell] = (keep && !in_hole) ? 1 : 0;
+}
+
+// per-block kept counts (wave ballot + popcount)
+__global__ __launch_bounds__(256) void block_count_kernel(const uint8_t* __restrict__ flags,
+                                                          const TissueDesc* __restrict__ tissues,
+                                                          const BlockDesc* __restrict__ blocks,
+                                                          unsigned* __restrict__ counts) {
+    __shared__ unsigned wsum[4];
+    const BlockDesc bd = blocks[blockIdx.x];
+    const TissueDesc td = tissues[bd.tissue];
+    const int cell = bd.cell0 + threadIdx.x;
+    const bool f = cell < td.nx * td.ny && flags[td.cell_off + cell];
+    const unsigned long long b = __ballot(f);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = (unsigned)__popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// single-workgroup exclusive scan of the block counts (<= a few thousand entries)
+__global__ __launch_bounds__(1024) void scan_kernel(const unsigned* __restrict__ counts,
+                                                    unsigned long long* __restrict__ offsets, int n,
+                                                    unsigned long long* __restrict__ total) {
+    __shared__ unsigned long long part[1024];
+    const int per = (n + 1023) / 1024;
+    const int b = threadIdx.x * per, e = min(n, b + per);
+    unsigned long long s = 0;
+    for (int i = b; i < e; ++i) s += counts[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        unsigned long long v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    unsigned long long run = threadIdx.x ? part[threadIdx.x - 1] : 0;
+    for (int i = b; i < e; ++i) { offsets[i] = run; run += counts[i]; }
+    if (threadIdx.x == 1023) *total = part[1023];
+}
+
+__global__ __launch_bounds__(256) void compact_kernel(const uint8_t* __restrict__ flags,
+                                                      const TissueDesc* __restrict__ tissues,
+                                                      const BlockDesc* __restrict__ blocks,
+                                                      const unsigned long long* __restrict__ offsets,
+                                                      int step, int rw, int rh, int level,
+                                                      int32_t* __restrict__ rows, unsigned long long cap) {
+    __shared__ unsigned wsum[4];
+    const BlockDesc bd = blocks[blockIdx.x];
+    const TissueDesc td = tissues[bd.tissue];
+    const int cell = bd.cell0 + threadIdx.x;
+    const bool f = cell < td.nx * td.ny && flags[td.cell_off + cell];
+    const unsigned long long b = __ballot(f);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wsum[wave] = (unsigned)__popcll(b);
+    __syncthreads();
+    unsigned before = 0;
+    for (int wv = 0; wv < wave; ++wv) before += wsum[wv];
+    const unsigned rank = before + (unsigned)__popcll(b & ((1ull << lane) - 1ull));
+    if (f) {
+        const unsigned long long r = offsets[blockIdx.x] + rank;
+        if (r < cap) {
+            const int iy = cell / td.nx, ix = cell - iy * td.nx;
+            int32_t* o = rows + r * 5;
+            o[0] = td.x0 + ix * step; o[1] = td.y0 + iy * step; o[2] = rw; o[3] = rh; o[4] = level;
+        }
+    }
+}
+
+template <typename T> struct DevBuf {
+    T* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t n) { AP_HIP_CHECK(hipMalloc((void**)&p, (n ? n : 1) * sizeof(T))); return AP_OK; }
+};
+
+}  // namespace
+}  // namespace ap
+
+extern "C" {
+
+int ap_contours_from_mask(const float* mask, int h, int w, double tissue_area_thresh,
+                          int min_hole_area, int max_n_holes, double sx, double sy,
+                          ap_contours** out, ap_stream_t stream) {
+    AP_REQUIRE(mask && out, "contours_from_mask: null argument");
+    AP_REQUIRE(h > 0 && w > 0 && (long)h * w <= (1l << 28), "contours_from_mask: bad mask shape %dx%d", h, w);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t count = (size_t)h * w;
+    ap::DevBuf<float> dmask; ap::DevBuf<uint8_t> dbin;
+    int rc;
+    if ((rc = dmask.alloc(count)) != AP_OK || (rc = dbin.alloc(count)) != AP_OK) return rc;
+    AP_HIP_CHECK(hipMemcpyAsync(dmask.p, mask, count * sizeof(float), hipMemcpyHostToDevice, s));
+    ap::threshold_kernel<<<(unsigned)((count / 4 + 256) / 256), 256, 0, s>>>(dmask.p, dbin.p, count);
+    AP_HIP_CHECK(hipGetLastError());
+    std::vector<uint8_t> bin(count);
+    AP_HIP_CHECK(hipMemcpyAsync(bin.data(), dbin.p, count, hipMemcpyDeviceToHost, s));
+    AP_HIP_CHECK(hipStreamSynchronize(s));
+    ap_contours* c = new ap_contours();
+    ap::contours_from_binary(bin.data(), h, w, tissue_area_thresh, min_hole_area, max_n_holes, sx, sy, c->set);
+    *out = c;
+    return AP_OK;
+}
+
+void ap_contours_destroy(ap_contours* c) { delete c; }
+
+int ap_contours_count(const ap_contours* c) { return c ? (int)c->set.tissue.size() : 0; }
+
+int ap_contours_num_holes(const ap_contours* c, int i) {
+    if (!c || i < 0 || i >= (int)c->set.tissue.size()) return 0;
+    return (int)c->set.tissue[i].holes.size();
+}
+
+int ap_contours_points(const ap_contours* c, int i, int hole, int scaled, int32_t* xy, int cap) {
+    AP_REQUIRE(c && i >= 0 && i < (int)c->set.tissue.size(), "contours_points: bad contour index %d", i);
+    const ap::Tissue& t = c->set.tissue[i];
+    int poly = t.poly;
+    if (hole >= 0) {
+        AP_REQUIRE(hole < (int)t.holes.size(), "contours_points: bad hole index %d", hole);
+        poly = t.holes[hole];
+    }
+    const std::vector<int32_t>& v = scaled ? c->set.polys[poly].scaled : c->set.polys[poly].raw;
+    const int n = (int)(v.size() / 2);
+    if (xy && cap > 0) {
+        const int m = n < cap ? n : cap;
+        for (int k = 0; k < 2 * m; ++k) xy[k] = v[k];
+    }
+    return n;
+}
+
+int ap_grid_coords(const ap_contours* c, int patch_size_src, int step_src, int read_w, int read_h,
+                   int level, int32_t* coords, size_t cap, size_t* n_rows, ap_stream_t stream) {
+    AP_REQUIRE(c && n_rows, "grid_coords: null argument");
+    AP_REQUIRE(patch_size_src > 0 && step_src > 0, "grid_coords: patch %d / step %d", patch_size_src, step_src);
+    AP_REQUIRE(coords || cap == 0, "grid_coords: null output with non-zero capacity");
+    hipStream_t s = (hipStream_t)stream;
+    *n_rows = 0;
+    const ap::ContourSet& set = c->set;
+    if (set.tissue.empty()) return AP_OK;
+
+    // ---- pack polygons and describe the grids (bounding rect of the scaled contour)
+    std::vector<int2> verts;
+    std::vector<ap::TissueDesc> tds;
+    std::vector<ap::HoleDesc> hds;
+    std::vector<ap::BlockDesc> bds;
+    long cells = 0;
+    auto pack = [&](int poly, int& off, int& cnt) {
+        const std::vector<int32_t>& v = set.polys[poly].scaled;
+        off = (int)verts.size(); cnt = (int)(v.size() / 2);
+        for (int k = 0; k < cnt; ++k) verts.push_back(make_int2(v[2 * k], v[2 * k + 1]));
+    };
+    for (size_t ti = 0; ti < set.tissue.size(); ++ti) {
+        const ap::Tissue& t = set.tissue[ti];
+        ap::TissueDesc td{};
+        pack(t.poly, td.poly_off, td.poly_cnt);
+        if (td.poly_cnt == 0) continue;
+        int xmin = verts[td.poly_off].x, xmax = xmin, ymin = verts[td.poly_off].y, ymax = ymin;
+        for (int k = 1; k < td.poly_cnt; ++k) {
+            const int2 p = verts[td.poly_off + k];
+            xmin = p.x < xmin ? p.x : xmin; xmax = p.x > xmax ? p.x : xmax;
+            ymin = p.y < ymin ? p.y : ymin; ymax = p.y > ymax ? p.y : ymax;
+        }
+        // boundingRect: w = xmax - xmin + 1; range(x0, x0 + w, step)
+        td.x0 = xmin; td.y0 = ymin;
+        td.nx = (xmax - xmin + 1 + step_src - 1) / step_src;
+        td.ny = (ymax - ymin + 1 + step_src - 1) / step_src;
+        td.hole_first = (int)hds.size(); td.hole_cnt = (int)t.holes.size();
+        for (int hp : t.holes) { ap::HoleDesc hd{}; pack(hp, hd.poly_off, hd.poly_cnt); hds.push_back(hd); }
+        td.cell_off = cells;
+        const long nc = (long)td.nx * td.ny;
+        AP_REQUIRE(nc < (1l << 31), "grid_coords: grid too large");
+        for (long c0 = 0; c0 < nc; c0 += 256) bds.push_back({(int)tds.size(), (int)c0});
+        cells += nc;
+        tds.push_back(td);
+    }
+    if (bds.empty()) return AP_OK;
+
+    ap::DevBuf<int2> dverts; ap::DevBuf<ap::TissueDesc> dtd; ap::DevBuf<ap::HoleDesc> dhd;
+    ap::DevBuf<ap::BlockDesc> dbd; ap::DevBuf<uint8_t> dflags; ap::DevBuf<unsigned> dcounts;
+    ap::DevBuf<unsigned long long> doffs; ap::DevBuf<unsigned long long> dtotal; ap::DevBuf<int32_t> drows;
+    int rc;
+    if ((rc = dverts.alloc(verts.size())) || (rc = dtd.alloc(tds.size())) || (rc = dhd.alloc(hds.size())) ||
+        (rc = dbd.alloc(bds.size())) || (rc = dflags.alloc((size_t)cells)) || (rc = dcounts.alloc(bds.size())) ||
+        (rc = doffs.alloc(bds.size())) || (rc = dtotal.alloc(1)))
+        return rc;
+    AP_HIP_CHECK(hipMemcpyAsync(dverts.p, verts.data(), verts.size() * sizeof(int2), hipMemcpyHostToDevice, s));
+    AP_HIP_CHECK(hipMemcpyAsync(dtd.p, tds.data(), tds.size() * sizeof(ap::TissueDesc), hipMemcpyHostToDevice, s));
+    if (!hds.empty())
+        AP_HIP_CHECK(hipMemcpyAsync(dhd.p, hds.data(), hds.size() * sizeof(ap::HoleDesc), hipMemcpyHostToDevice, s));
+    AP_HIP_CHECK(hipMemcpyAsync(dbd.p, bds.data(), bds.size() * sizeof(ap::BlockDesc), hipMemcpyHostToDevice, s));
+
+    const unsigned nb = (unsigned)bds.size();
+    ap::grid_flags_kernel<<<nb, 256, 0, s>>>(dverts.p, dtd.p, dhd.p, dbd.p, patch_size_src, step_src, dflags.p);
+    AP_HIP_CHECK(hipGetLastError());
+    ap::block_count_kernel<<<nb, 256, 0, s>>>(dflags.p, dtd.p, dbd.p, dcounts.p);
+    AP_HIP_CHECK(hipGetLastError());
+    ap::scan_kernel<<<1, 1024, 0, s>>>(dcounts.p, doffs.p, (int)nb, dtotal.p);
+    AP_HIP_CHECK(hipGetLastError());
+    unsigned long long total = 0;
+    AP_HIP_CHECK(hipMemcpyAsync(&total, dtotal.p, sizeof(total), hipMemcpyDeviceToHost, s));
+    AP_HIP_CHECK(hipStreamSynchronize(s));
+    *n_rows = (size_t)total;
+    if (total == 0) return AP_OK;
+    if (total > cap) {
+        ap::set_error("grid_coords: %llu rows exceed the output capacity %zu", total, cap);
+        return AP_ERR_CAPACITY;
+    }
+    if ((rc = drows.alloc((size_t)total * 5))) return rc;
+    ap::compact_kernel<<<nb, 256, 0, s>>>(dflags.p, dtd.p, dbd.p, doffs.p, step_src, read_w, read_h, level,
+                                          drows.p, total);
+    AP_HIP_CHECK(hipGetLastError());
+    AP_HIP_CHECK(hipMemcpyAsync(coords, drows.p, (size_t)total * 5 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    AP_HIP_CHECK(hipStreamSynchronize(s));
+    return AP_OK;
+}
+
+}  // extern "C"

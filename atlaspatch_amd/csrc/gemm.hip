@@ -1,0 +1,246 @@
+// MFMA GEMM for the ViT encoder on gfx950:  C[m][n] = sum_k A[m][k] * W[n][k]  (+ fused epilogue).
+//
+// Both operands are K-contiguous ("B^T" form), so every MFMA fragment is one 16-byte
+// load.  Block tile 128(m) x 128(n), K-tile = 128 BYTES of K (64 f16/bf16, 32 f32),
+// 256 threads = 4 waves in a 2x2 grid, each wave owns 64x64 = 2x2 MFMA tiles of 32x32.
+//
+//  * staging: global -> LDS by LDS-DMA (global_load_lds, 16 B/lane), double buffered.
+//    The DMA writes lane-linear, so the bank swizzle is applied to the per-lane SOURCE
+//    address and again on the fragment read:  chunk ^= (row >> 1) & 7  over the eight
+//    16-byte chunks of a 128-byte tile row (conflict-free for ds_read_b128's 16-lane
+//    groups: rows r, r+1 sit on different bank halves, (row>>1)&7 spreads 8 row pairs).
+//  * operand roles are swapped (MFMA A-operand = weight rows, B-operand = activation
+//    rows) so that each lane ends up with 4 CONSECUTIVE n for one m: the epilogue reads
+//    bias/gamma/pos and the f32 residual as float4 and stores 8/16 bytes per lane.
+//  * f32 mode uses v_mfma_f32_32x32x2_f32 (exact f32 fma chain); the k index is
+//    permuted (lanes 0-31 take k 0..15 of the tile, lanes 32-63 take k 16..31) so a lane
+//    reads its 16 floats as four 16-byte loads.  Any permutation of k is exact as long
+//    as both operands use the same one.
+//  * XCD-aware tile order: block b runs on XCD b % 8; logical tile ids are remapped so
+//    each XCD owns a contiguous run of tiles (all n-tiles of an m-panel share one L2).
+//
+// Roofline: MFMA (2*M*N*K flop); HBM traffic ~ A once + output once (weights L2-resident).
+#include "ap_common.h"
+
+namespace ap {
+namespace {
+
+constexpr int kTile = 128;            // BM = BN
+constexpr int kRowBytes = 128;        // bytes of K per tile row
+constexpr int kTileBytes = kTile * kRowBytes;   // 16 KiB per operand tile
+constexpr int kBufBytes = 2 * kTileBytes;       // W tile + A tile
+
+template <typename T> struct Mma;
+template <> struct Mma<f16> {
+    using Frag = f16x8;
+    static __device__ __forceinline__ f32x16 run(Frag a, Frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mma<bf16> {
+    using Frag = bf16x8;
+    static __device__ __forceinline__ f32x16 run(Frag a, Frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ float gelu_erf(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+template <typename T> __device__ __forceinline__ void store4(T* p, f32x4 v);
+template <> __device__ __forceinline__ void store4<float>(float* p, f32x4 v) { *(f32x4*)p = v; }
+template <> __device__ __forceinline__ void store4<f16>(f16* p, f32x4 v) {
+    f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+    *(f16x4*)p = h;
+}
+template <> __device__ __forceinline__ void store4<bf16>(bf16* p, f32x4 v) {
+    bf16x4 h = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+    *(bf16x4*)p = h;
+}
+
+__device__ __forceinline__ void dma16(const char* gsrc, char* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * kBufBytes];   // 64 KiB
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave_n = wave >> 1, wave_m = wave & 1;
+    const int hi = lane >> 5, l31 = lane & 31;
+
+    // ---- XCD-aware logical tile id (bijective for any grid size)
+    const int nblk = gridDim.x, b = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = b & 7, idx = b >> 3;
+    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    const int tiles_n = g.N / kTile;
+    const int m0 = (lid / tiles_n) * kTile, n0 = (lid % tiles_n) * kTile;
+
+    // ---- staging plan: wave-instruction s of this wave fills tile rows [8*(4*wave+s), +8)
+    const char* srcW[4];
+    const char* srcA[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int row = (wave * 4 + s) * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        int am = m0 + row;
+        am = am < g.M ? am : g.M - 1;
+        srcW[s] = (const char*)g.W + ((size_t)(n0 + row) * g.ldw) * sizeof(T) + chunk * 16;
+        srcA[s] = (const char*)g.A + ((size_t)am * g.lda) * sizeof(T) + chunk * 16;
+    }
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * kBufBytes + wave * 4096;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) dma16(srcW[s] + (size_t)kt * kRowBytes, base + s * 1024);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            dma16(srcA[s] + (size_t)kt * kRowBytes, base + kTileBytes + s * 1024);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int xr = (l31 >> 1) & 7;                                  // row-dependent chunk xor
+    const int rowW = (wave_n * 64 + l31) * kRowBytes;               // + nt * 32 rows
+    const int rowA = kTileBytes + (wave_m * 64 + l31) * kRowBytes;  // + mt * 32 rows
+
+    const int nk = g.K / (int)(kRowBytes / sizeof(T));
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char* buf = smem + cur * kBufBytes;
+        if constexpr (sizeof(T) == 2) {
+            using Frag = typename Mma<T>::Frag;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int co = ((kk * 2 + hi) ^ xr) << 4;
+                Frag w0 = *(const Frag*)(buf + rowW + co);
+                Frag w1 = *(const Frag*)(buf + rowW + 32 * kRowBytes + co);
+                Frag a0 = *(const Frag*)(buf + rowA + co);
+                Frag a1 = *(const Frag*)(buf + rowA + 32 * kRowBytes + co);
+                acc[0][0] = Mma<T>::run(w0, a0, acc[0][0]);
+                acc[0][1] = Mma<T>::run(w0, a1, acc[0][1]);
+                acc[1][0] = Mma<T>::run(w1, a0, acc[1][0]);
+                acc[1][1] = Mma<T>::run(w1, a1, acc[1][1]);
+            }
+        } else {
+            // f32: lane's 16 k-values = chunks 4*hi .. 4*hi+3 of its row (permuted k, see header)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int co = ((hi * 4 + c) ^ xr) << 4;
+                f32x4 w0 = *(const f32x4*)(buf + rowW + co);
+                f32x4 w1 = *(const f32x4*)(buf + rowW + 32 * kRowBytes + co);
+                f32x4 a0 = *(const f32x4*)(buf + rowA + co);
+                f32x4 a1 = *(const f32x4*)(buf + rowA + 32 * kRowBytes + co);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[e], a0[e], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[e], a1[e], acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[e], a0[e], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1[e], a1[e], acc[1][1], 0, 0, 0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane owns m = .. + l31 and, per (nt, g4), n = .. + 8*g4 + 4*hi + {0..3}
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int m = m0 + wave_m * 64 + mt * 32 + l31;
+        if (m >= g.M) continue;
+        size_t orow;
+        const float* posrow = nullptr;
+        if constexpr (EPI == EPI_PATCH_EMBED) {
+            const int img = m / g.P, p = m - img * g.P;
+            orow = ((size_t)img * (g.P + 1) + 1 + p) * (size_t)g.ldo;
+            posrow = g.pos + (size_t)(1 + p) * g.N;
+        } else {
+            orow = (size_t)m * (size_t)g.ldo;
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int n = n0 + wave_n * 64 + nt * 32 + g4 * 8 + hi * 4;
+                const f32x4 bias = *(const f32x4*)(g.bias + n);
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[nt][mt][g4 * 4 + e] + bias[e];
+                if constexpr (EPI == EPI_BIAS_STORE) {
+                    store4<T>((T*)g.out + orow + n, v);
+                } else if constexpr (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                    store4<T>((T*)g.out + orow + n, v);
+                } else if constexpr (EPI == EPI_BIAS_RESID) {
+                    float* dst = (float*)g.out + orow + n;
+                    f32x4 r = *(const f32x4*)dst;
+                    if (g.gamma) {
+                        const f32x4 ga = *(const f32x4*)(g.gamma + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= ga[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) r[e] += v[e];
+                    *(f32x4*)dst = r;
+                } else {
+                    const f32x4 pe = *(const f32x4*)(posrow + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += pe[e];
+                    *(f32x4*)((float*)g.out + orow + n) = v;
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+int launch_typed(int epilogue, const GemmArgs& a, hipStream_t stream) {
+    const int tiles = ((a.M + kTile - 1) / kTile) * (a.N / kTile);
+    dim3 grid(tiles), block(256);
+    switch (epilogue) {
+        case EPI_BIAS_STORE: gemm_kernel<T, EPI_BIAS_STORE><<<grid, block, 0, stream>>>(a); break;
+        case EPI_BIAS_GELU: gemm_kernel<T, EPI_BIAS_GELU><<<grid, block, 0, stream>>>(a); break;
+        case EPI_BIAS_RESID: gemm_kernel<T, EPI_BIAS_RESID><<<grid, block, 0, stream>>>(a); break;
+        case EPI_PATCH_EMBED: gemm_kernel<T, EPI_PATCH_EMBED><<<grid, block, 0, stream>>>(a); break;
+        default: set_error("gemm: unknown epilogue %d", epilogue); return AP_ERR_INVALID;
+    }
+    AP_HIP_CHECK(hipGetLastError());
+    return AP_OK;
+}
+
+}  // namespace
+
+int launch_gemm(int dtype, int epilogue, const GemmArgs& a, hipStream_t stream) {
+    const int kt = kRowBytes / (int)dtype_size(dtype);
+    AP_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem %d x %d x %d", a.M, a.N, a.K);
+    AP_REQUIRE(a.N % kTile == 0, "gemm: N=%d must be a multiple of %d", a.N, kTile);
+    AP_REQUIRE(a.K % kt == 0, "gemm: K=%d must be a multiple of %d for this dtype", a.K, kt);
+    AP_REQUIRE(a.lda >= a.K && a.ldw >= a.K, "gemm: leading dimensions smaller than K");
+    AP_REQUIRE(((size_t)a.lda * dtype_size(dtype)) % 16 == 0 && ((size_t)a.ldw * dtype_size(dtype)) % 16 == 0,
+               "gemm: row strides must be 16-byte multiples");
+    switch (dtype) {
+        case AP_F16: return launch_typed<f16>(epilogue, a, stream);
+        case AP_BF16: return launch_typed<bf16>(epilogue, a, stream);
+        case AP_F32: return launch_typed<float>(epilogue, a, stream);
+    }
+    set_error("gemm: unknown dtype %d", dtype);
+    return AP_ERR_INVALID;
+}
+
+}  // namespace ap

@@ -1,0 +1,244 @@
+// K1: uint8 HWC tiles -> normalised float tensors, HBM-bound.
+//
+//   y = ((float(x) / 255) - mean[c]) / std[c]      (two true f32 divisions, as torchvision)
+//
+// x only takes 256 values per channel, so the 3 x 256 possible results are computed ONCE on the
+// host with exactly that op order (IEEE f32, no contraction possible: div, sub, div), converted
+// to the output dtype on the device (round-to-nearest-even, same as torch's .to(dtype)) and
+// kept in LDS as a lookup table: the kernel is bit-exact by construction and does no division.
+//
+// Work decomposition: one workgroup per (image, band of `band` output rows).  The band's
+// cropped window is copied HBM -> LDS with 16-byte loads (each source row of a 256-px tile
+// is 768 contiguous bytes; the 224-px crop window starts 48 bytes in, still 16-byte aligned),
+// then every lane converts 8 consecutive pixels x 3 channels (24 contiguous LDS bytes) and
+// writes three 16-byte (f16/bf16) or 32-byte (f32) runs, arranged so that consecutive lanes
+// write consecutive addresses of one channel plane.
+//
+// Algorithmic bytes / patch (256 -> 224 crop): 150 528 read (window only) + 301 056 written
+// (f16) = 451 584; counting the whole 196 608-byte tile as read: 497 664.
+#include <mutex>
+#include <vector>
+#include "ap_common.h"
+
+namespace ap {
+namespace {
+
+constexpr int kMaxBand = 16;
+
+enum Layout { LAYOUT_CHW = 0, LAYOUT_PATCHROWS = 1 };
+
+struct PreArgs {
+    const uint8_t* src; int n, h, w, top, left, oh, ow;
+    const void* lut;          // [3][256] T
+    void* dst;
+    int ps, ld;               // patch rows layout
+    int band;                 // rows per block (= ps for patch rows)
+};
+
+template <typename T> struct Out8;     // 8 consecutive outputs
+template <> struct Out8<f16> { using vec = f16x8; };
+template <> struct Out8<bf16> { using vec = bf16x8; };
+
+template <typename T>
+__device__ __forceinline__ void store8(T* p, const T* v) {
+    if constexpr (sizeof(T) == 2) {
+        typename Out8<T>::vec o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = v[e];
+        *(typename Out8<T>::vec*)p = o;
+    } else {
+        f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+        ((f32x4*)p)[0] = a;
+        ((f32x4*)p)[1] = b;
+    }
+}
+
+template <typename T, int LAYOUT>
+__global__ __launch_bounds__(256) void preproc_kernel(PreArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* lut = (T*)smem;                                   // 768 entries
+    uint8_t* rows = (uint8_t*)smem + 768 * sizeof(T);    // band x rowStride
+    const int rowBytes = a.ow * 3;
+    const int rowStride = (rowBytes + 15) / 16 * 16 + 8;
+    const int tid = threadIdx.x;
+    const int bands = (a.oh + a.band - 1) / a.band;
+    const int img = blockIdx.x / bands, bnd = blockIdx.x - img * bands;
+    const int y0 = bnd * a.band;
+    const int nrows = min(a.band, a.oh - y0);
+
+    for (int i = tid; i < 768; i += 256) lut[i] = ((const T*)a.lut)[i];
+
+    const uint8_t* win = a.src + ((size_t)img * a.h + (a.top + y0)) * (size_t)a.w * 3 + (size_t)a.left * 3;
+    const size_t srcStride = (size_t)a.w * 3;
+    const bool aligned = ((srcStride & 15) == 0) && ((((size_t)a.left * 3) & 15) == 0) &&
+                         ((rowBytes & 15) == 0) && ((((uintptr_t)a.src) & 15) == 0) &&
+                         (((size_t)a.h * srcStride) % 16 == 0);
+    if (aligned) {
+        const int chunks = rowBytes >> 4;
+        for (int i = tid; i < nrows * chunks; i += 256) {
+            const int r = i / chunks, c = i - r * chunks;
+            const u32x4 v = *(const u32x4*)(win + r * srcStride + c * 16);
+            // rowStride is 8 mod 16: store as two 8-byte halves
+            u32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
+            *(u32x2*)(rows + r * rowStride + c * 16) = lo;
+            *(u32x2*)(rows + r * rowStride + c * 16 + 8) = hi;
+        }
+    } else {
+        for (int i = tid; i < nrows * rowBytes; i += 256) {
+            const int r = i / rowBytes, c = i - r * rowBytes;
+            rows[r * rowStride + c] = win[r * srcStride + c];
+        }
+    }
+    __syncthreads();
+
+    const int groups = a.ow >> 3;                        // 8-pixel groups per row (ow % 8 == 0)
+    if constexpr (LAYOUT == LAYOUT_PATCHROWS) {
+        // task order: (px, ky, half) with half fastest -> 2*ps consecutive lanes write ps*ps
+        // consecutive elements of one (patch, channel) plane
+        const int gw = a.ow / a.ps, gh = a.oh / a.ps, halves = a.ps >> 3;
+        const int per_px = a.ps * halves;
+        const int py = bnd;
+        for (int t = tid; t < gw * per_px; t += 256) {
+            const int px = t / per_px, rem = t - px * per_px;
+            const int ky = rem / halves, hf = rem - ky * halves;
+            if (ky >= nrows) continue;
+            const uint8_t* p = rows + ky * rowStride + (px * a.ps + hf * 8) * 3;
+            uint8_t b[24];
+#pragma unroll
+            for (int e = 0; e < 3; ++e) *(u32x2*)(b + e * 8) = *(const u32x2*)(p + e * 8);
+            T* drow = (T*)a.dst + ((size_t)(img * gh + py) * gw + px) * (size_t)a.ld;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                T v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = lut[c * 256 + b[e * 3 + c]];
+                store8<T>(drow + (c * a.ps + ky) * a.ps + hf * 8, v);
+            }
+        }
+    } else {
+        for (int t = tid; t < nrows * groups; t += 256) {
+            const int r = t / groups, gx = t - r * groups;
+            const uint8_t* p = rows + r * rowStride + gx * 24;
+            uint8_t b[24];
+#pragma unroll
+            for (int e = 0; e < 3; ++e) *(u32x2*)(b + e * 8) = *(const u32x2*)(p + e * 8);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                T v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = lut[c * 256 + b[e * 3 + c]];
+                store8<T>((T*)a.dst + (((size_t)img * 3 + c) * a.oh + (y0 + r)) * (size_t)a.ow + gx * 8, v);
+            }
+        }
+    }
+}
+
+// ---- LUT cache: device-resident [3][256] tables keyed by (mean, std, dtype, device)
+struct LutEntry {
+    float mean[3], stdv[3];
+    int dtype, device;
+    void* dev;
+};
+std::mutex g_lut_mu;
+std::vector<LutEntry> g_luts;
+
+}  // namespace
+
+int get_norm_lut(const float mean[3], const float stdv[3], int dtype, hipStream_t stream,
+                 const void** out) {
+    int device = 0;
+    AP_HIP_CHECK(hipGetDevice(&device));
+    std::lock_guard<std::mutex> lock(g_lut_mu);
+    for (const LutEntry& e : g_luts) {
+        bool same = e.dtype == dtype && e.device == device;
+        for (int c = 0; c < 3 && same; ++c) same = e.mean[c] == mean[c] && e.stdv[c] == stdv[c];
+        if (same) { *out = e.dev; return AP_OK; }
+    }
+    float host[768];
+    for (int c = 0; c < 3; ++c)
+        for (int x = 0; x < 256; ++x) {
+            volatile float t = (float)x / 255.0f;      // volatile: keep each step a rounded f32 op
+            volatile float u = t - mean[c];
+            host[c * 256 + x] = u / stdv[c];
+        }
+    float* tmp = nullptr;
+    void* dev = nullptr;
+    AP_HIP_CHECK(hipMalloc((void**)&tmp, sizeof(host)));
+    AP_HIP_CHECK(hipMalloc(&dev, 768 * dtype_size(dtype)));
+    AP_HIP_CHECK(hipMemcpy(tmp, host, sizeof(host), hipMemcpyHostToDevice));
+    int rc = launch_convert(dtype, tmp, dev, 768, stream);
+    if (rc != AP_OK) return rc;
+    AP_HIP_CHECK(hipStreamSynchronize(stream));
+    AP_HIP_CHECK(hipFree(tmp));
+    LutEntry e;
+    for (int c = 0; c < 3; ++c) { e.mean[c] = mean[c]; e.stdv[c] = stdv[c]; }
+    e.dtype = dtype; e.device = device; e.dev = dev;
+    g_luts.push_back(e);
+    *out = dev;
+    return AP_OK;
+}
+
+namespace {
+
+template <typename T>
+int launch_pre(int layout, const PreArgs& a, hipStream_t stream) {
+    const int rowBytes = a.ow * 3;
+    const int rowStride = (rowBytes + 15) / 16 * 16 + 8;
+    const size_t smem = 768 * sizeof(T) + (size_t)a.band * rowStride;
+    const int bands = (a.oh + a.band - 1) / a.band;
+    dim3 grid((unsigned)(a.n * bands)), block(256);
+    if (layout == LAYOUT_PATCHROWS)
+        preproc_kernel<T, LAYOUT_PATCHROWS><<<grid, block, smem, stream>>>(a);
+    else
+        preproc_kernel<T, LAYOUT_CHW><<<grid, block, smem, stream>>>(a);
+    AP_HIP_CHECK(hipGetLastError());
+    return AP_OK;
+}
+
+int preproc_common(int layout, const uint8_t* src, int n, int h, int w, int top, int left, int oh,
+                   int ow, int ps, int ld, const float mean[3], const float stdv[3], void* dst,
+                   int dtype, hipStream_t stream) {
+    AP_REQUIRE(src && dst && mean && stdv, "preproc: null pointer");
+    AP_REQUIRE(n >= 0 && h > 0 && w > 0 && oh > 0 && ow > 0, "preproc: bad shape");
+    AP_REQUIRE(top >= 0 && left >= 0 && top + oh <= h && left + ow <= w,
+               "preproc: crop window %d,%d+%dx%d outside %dx%d", top, left, oh, ow, h, w);
+    AP_REQUIRE(ow % 8 == 0, "preproc: output width %d must be a multiple of 8", ow);
+    AP_REQUIRE(ow * 3 <= 16384, "preproc: output width %d too large", ow);
+    if (n == 0) return AP_OK;
+    PreArgs a;
+    a.src = src; a.n = n; a.h = h; a.w = w; a.top = top; a.left = left; a.oh = oh; a.ow = ow;
+    a.dst = dst; a.ps = ps; a.ld = ld;
+    if (layout == LAYOUT_PATCHROWS) {
+        AP_REQUIRE(ps > 0 && ps % 8 == 0 && ps <= kMaxBand && oh % ps == 0 && ow % ps == 0,
+                   "preproc: patch size %d unsupported for %dx%d", ps, oh, ow);
+        AP_REQUIRE(ld >= 3 * ps * ps && (ld * dtype_size(dtype)) % 16 == 0, "preproc: bad row length %d", ld);
+        a.band = ps;
+    } else {
+        a.band = 8;
+    }
+    int rc = get_norm_lut(mean, stdv, dtype, stream, &a.lut);
+    if (rc != AP_OK) return rc;
+    switch (dtype) {
+        case AP_F16: return launch_pre<f16>(layout, a, stream);
+        case AP_BF16: return launch_pre<bf16>(layout, a, stream);
+        case AP_F32: return launch_pre<float>(layout, a, stream);
+    }
+    set_error("preproc: unknown dtype %d", dtype);
+    return AP_ERR_INVALID;
+}
+
+}  // namespace
+
+int preproc_chw(const uint8_t* src, int n, int h, int w, int top, int left, int oh, int ow,
+                const float mean[3], const float stdv[3], void* dst, int dtype, hipStream_t stream) {
+    return preproc_common(LAYOUT_CHW, src, n, h, w, top, left, oh, ow, 0, 0, mean, stdv, dst, dtype, stream);
+}
+
+int preproc_patchrows(const uint8_t* src, int n, int h, int w, int top, int left, int oh, int ow,
+                      int ps, const float mean[3], const float stdv[3], void* dst, int ld, int dtype,
+                      hipStream_t stream) {
+    return preproc_common(LAYOUT_PATCHROWS, src, n, h, w, top, left, oh, ow, ps, ld, mean, stdv, dst,
+                          dtype, stream);
+}
+
+}  // namespace ap

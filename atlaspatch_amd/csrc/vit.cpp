@@ -1,0 +1,295 @@
+// ViT encoder object behind the C ABI: parameter storage in HBM, workspace carving and the
+// launch sequence of one forward pass.  Host C++ only; every kernel
+// it launches lives in gemm.hip / attention.hip / elementwise.hip / preproc.hip.
+//
+// HBM layout for a batch of n images (T = compute dtype, Tk = 1 + (S/ps)^2 tokens, M = n*Tk):
+//   tok   f32 [M, D]      residual stream (always f32)
+//   xn    T   [M, D]      LayerNorm output (GEMM A operand)
+//   qkv   T   [M, 3D]     packed q | k | v
+//   att   T   [M, D]      attention output
+//   hid   T   [M, mlp]    GELU(fc1) ; the patch-row matrix [n*P, Kpe] aliases it
+// Weights are converted once to T, K-contiguous ([out, in], exactly the checkpoint layout).
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+#include "ap_common.h"
+
+namespace ap {
+
+struct Param {
+    size_t count = 0;      // f32 elements expected
+    int rows = 0, cols = 0, ld = 0;   // matrices converted to T: [rows, ld] (cols <= ld, zero padded)
+    bool matrix = false;
+    void* dev = nullptr;   // f32 vector or T matrix
+    bool set = false;
+};
+
+}  // namespace ap
+
+struct ap_vit {
+    ap_vit_config cfg;
+    int grid = 0, patches = 0, tokens = 0, kpe = 0;
+    std::map<std::string, ap::Param> params;
+    bool finalized = false;
+    int device = 0;
+};
+
+namespace {
+
+using ap::Param;
+
+int alloc_param(ap_vit* m, const std::string& name, int rows, int cols, bool matrix) {
+    Param p;
+    p.rows = rows; p.cols = cols; p.matrix = matrix;
+    p.count = (size_t)rows * cols;
+    const int kq = 64;    // K padded to 64 elements: whole 128-byte K tiles for every dtype
+    p.ld = matrix ? (int)ap::align_up(cols, kq) : cols;
+    const size_t bytes = matrix ? (size_t)rows * p.ld * ap::dtype_size(m->cfg.compute_dtype)
+                                : p.count * sizeof(float);
+    AP_HIP_CHECK(hipMalloc(&p.dev, bytes));
+    AP_HIP_CHECK(hipMemset(p.dev, 0, bytes));
+    m->params[name] = p;
+    return AP_OK;
+}
+
+const Param* find(const ap_vit* m, const std::string& name) {
+    auto it = m->params.find(name);
+    return it == m->params.end() ? nullptr : &it->second;
+}
+
+struct Workspace {
+    float* tok; void* xn; void* qkv; void* att; void* hid;
+    size_t total;
+};
+
+Workspace carve(const ap_vit* m, int n, char* base) {
+    const size_t es = ap::dtype_size(m->cfg.compute_dtype);
+    const size_t M = (size_t)n * m->tokens, D = m->cfg.dim;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += ap::align_up(bytes, 256); return o; };
+    Workspace w;
+    const size_t o_tok = take(M * D * 4);
+    const size_t o_xn = take(M * D * es);
+    const size_t o_qkv = take(M * 3 * D * es);
+    const size_t o_att = take(M * D * es);
+    size_t hid_bytes = M * (size_t)m->cfg.mlp_dim * es;
+    const size_t pe_bytes = (size_t)n * m->patches * m->kpe * es;
+    if (pe_bytes > hid_bytes) hid_bytes = pe_bytes;
+    const size_t o_hid = take(hid_bytes);
+    w.tok = (float*)(base + o_tok); w.xn = base + o_xn; w.qkv = base + o_qkv;
+    w.att = base + o_att; w.hid = base + o_hid; w.total = off;
+    return w;
+}
+
+int run_blocks(ap_vit* m, int n, const Workspace& w, float* out, hipStream_t stream) {
+    const ap_vit_config& c = m->cfg;
+    const int dt = c.compute_dtype, D = c.dim, M = n * m->tokens;
+    int rc;
+    // patch embedding: tok[img][1 + p] = pe_row @ W^T + b + pos[1 + p]
+    {
+        const Param* wpe = find(m, "patch_embed.weight");
+        ap::GemmArgs g{};
+        g.A = w.hid; g.lda = m->kpe; g.W = wpe->dev; g.ldw = wpe->ld;
+        g.M = n * m->patches; g.N = D; g.K = m->kpe;
+        g.bias = (const float*)find(m, "patch_embed.bias")->dev;
+        g.pos = (const float*)find(m, "pos_embed")->dev;
+        g.out = w.tok; g.ldo = D; g.P = m->patches;
+        if ((rc = ap::launch_gemm(dt, ap::EPI_PATCH_EMBED, g, stream)) != AP_OK) return rc;
+        if ((rc = ap::launch_cls_init(w.tok, (const float*)find(m, "cls_token")->dev,
+                                      (const float*)find(m, "pos_embed")->dev, n, m->tokens, D,
+                                      stream)) != AP_OK) return rc;
+    }
+    for (int i = 0; i < c.depth; ++i) {
+        const std::string b = "blocks." + std::to_string(i) + ".";
+        auto vec = [&](const char* s) { return (const float*)find(m, b + s)->dev; };
+        auto mat = [&](const char* s) { return find(m, b + s); };
+        if ((rc = ap::launch_layernorm(dt, w.tok, D, M, D, vec("ln1.weight"), vec("ln1.bias"),
+                                       c.ln_eps, w.xn, stream)) != AP_OK) return rc;
+        {
+            ap::GemmArgs g{};
+            g.A = w.xn; g.lda = D; g.W = mat("qkv.weight")->dev; g.ldw = mat("qkv.weight")->ld;
+            g.M = M; g.N = 3 * D; g.K = D; g.bias = vec("qkv.bias"); g.out = w.qkv; g.ldo = 3 * D;
+            if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_STORE, g, stream)) != AP_OK) return rc;
+        }
+        if ((rc = ap::launch_attention(dt, w.qkv, w.att, n, m->tokens, c.heads, D / c.heads,
+                                       stream)) != AP_OK) return rc;
+        {
+            ap::GemmArgs g{};
+            g.A = w.att; g.lda = D; g.W = mat("proj.weight")->dev; g.ldw = mat("proj.weight")->ld;
+            g.M = M; g.N = D; g.K = D; g.bias = vec("proj.bias");
+            g.gamma = c.layer_scale ? vec("ls1") : nullptr; g.out = w.tok; g.ldo = D;
+            if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_RESID, g, stream)) != AP_OK) return rc;
+        }
+        if ((rc = ap::launch_layernorm(dt, w.tok, D, M, D, vec("ln2.weight"), vec("ln2.bias"),
+                                       c.ln_eps, w.xn, stream)) != AP_OK) return rc;
+        {
+            ap::GemmArgs g{};
+            g.A = w.xn; g.lda = D; g.W = mat("fc1.weight")->dev; g.ldw = mat("fc1.weight")->ld;
+            g.M = M; g.N = c.mlp_dim; g.K = D; g.bias = vec("fc1.bias"); g.out = w.hid; g.ldo = c.mlp_dim;
+            if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_GELU, g, stream)) != AP_OK) return rc;
+        }
+        {
+            ap::GemmArgs g{};
+            g.A = w.hid; g.lda = c.mlp_dim; g.W = mat("fc2.weight")->dev; g.ldw = mat("fc2.weight")->ld;
+            g.M = M; g.N = D; g.K = c.mlp_dim; g.bias = vec("fc2.bias");
+            g.gamma = c.layer_scale ? vec("ls2") : nullptr; g.out = w.tok; g.ldo = D;
+            if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_RESID, g, stream)) != AP_OK) return rc;
+        }
+    }
+    // final LayerNorm on the CLS row of every image -> out f32 [n, D]
+    return ap::launch_layernorm(AP_F32, w.tok, (long)m->tokens * D, n, D,
+                                (const float*)find(m, "norm.weight")->dev,
+                                (const float*)find(m, "norm.bias")->dev, c.ln_eps, out, stream);
+}
+
+int check_forward_args(const ap_vit* m, int n, const void* in, const float* out, const void* ws,
+                       size_t ws_bytes) {
+    AP_REQUIRE(m != nullptr, "vit: null handle");
+    if (!m->finalized) { ap::set_error("vit: ap_vit_finalize has not been called"); return AP_ERR_STATE; }
+    AP_REQUIRE(n >= 0, "vit: negative batch");
+    if (n == 0) return AP_OK;
+    AP_REQUIRE(in && out && ws, "vit: null buffer");
+    AP_REQUIRE(((uintptr_t)ws & 255) == 0, "vit: workspace must be 256-byte aligned");
+    if (ws_bytes < ap_vit_workspace_bytes(m, n)) {
+        ap::set_error("vit: workspace %zu bytes < required %zu", ws_bytes, ap_vit_workspace_bytes(m, n));
+        return AP_ERR_WORKSPACE;
+    }
+    return AP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ap_vit_create(const ap_vit_config* cfg, ap_vit** out) {
+    AP_REQUIRE(cfg && out, "vit_create: null argument");
+    const ap_vit_config& c = *cfg;
+    AP_REQUIRE(c.image_size > 0 && c.patch_size > 0 && c.image_size % c.patch_size == 0,
+               "vit_create: image %d / patch %d", c.image_size, c.patch_size);
+    AP_REQUIRE(c.patch_size % 8 == 0 && c.patch_size <= 16,
+               "vit_create: patch size %d unsupported by this build (8 or 16)", c.patch_size);
+    AP_REQUIRE(c.dim > 0 && c.heads > 0 && c.dim % c.heads == 0 && c.dim / c.heads == 64,
+               "vit_create: dim %d / heads %d: head_dim must be 64", c.dim, c.heads);
+    AP_REQUIRE(c.dim % 128 == 0 && c.mlp_dim % 128 == 0, "vit_create: dim and mlp_dim must be multiples of 128");
+    AP_REQUIRE(c.depth > 0, "vit_create: depth %d", c.depth);
+    AP_REQUIRE(c.compute_dtype == AP_F16 || c.compute_dtype == AP_BF16 || c.compute_dtype == AP_F32,
+               "vit_create: compute dtype %d", c.compute_dtype);
+    const int g = c.image_size / c.patch_size;
+    AP_REQUIRE(1 + g * g <= 288, "vit_create: %d tokens exceed this build's attention limit (288)", 1 + g * g);
+    ap_vit* m = new ap_vit();
+    m->cfg = c;
+    m->grid = g; m->patches = g * g; m->tokens = 1 + g * g;
+    m->kpe = (int)ap::align_up(3 * c.patch_size * c.patch_size, 64);
+    AP_HIP_CHECK(hipGetDevice(&m->device));
+    int rc = AP_OK;
+    auto add = [&](const std::string& name, int rows, int cols, bool matrix) {
+        if (rc == AP_OK) rc = alloc_param(m, name, rows, cols, matrix);
+    };
+    const int D = c.dim;
+    add("patch_embed.weight", D, 3 * c.patch_size * c.patch_size, true);
+    add("patch_embed.bias", 1, D, false);
+    add("cls_token", 1, D, false);
+    add("pos_embed", m->tokens, D, false);
+    add("norm.weight", 1, D, false);
+    add("norm.bias", 1, D, false);
+    for (int i = 0; i < c.depth; ++i) {
+        const std::string b = "blocks." + std::to_string(i) + ".";
+        add(b + "ln1.weight", 1, D, false); add(b + "ln1.bias", 1, D, false);
+        add(b + "qkv.weight", 3 * D, D, true); add(b + "qkv.bias", 1, 3 * D, false);
+        add(b + "proj.weight", D, D, true); add(b + "proj.bias", 1, D, false);
+        add(b + "ln2.weight", 1, D, false); add(b + "ln2.bias", 1, D, false);
+        add(b + "fc1.weight", c.mlp_dim, D, true); add(b + "fc1.bias", 1, c.mlp_dim, false);
+        add(b + "fc2.weight", D, c.mlp_dim, true); add(b + "fc2.bias", 1, D, false);
+        if (c.layer_scale) { add(b + "ls1", 1, D, false); add(b + "ls2", 1, D, false); }
+    }
+    if (rc != AP_OK) { ap_vit_destroy(m); return rc; }
+    *out = m;
+    return AP_OK;
+}
+
+void ap_vit_destroy(ap_vit* m) {
+    if (!m) return;
+    for (auto& kv : m->params)
+        if (kv.second.dev) (void)hipFree(kv.second.dev);
+    delete m;
+}
+
+int ap_vit_set_param(ap_vit* m, const char* name, const float* host, size_t count) {
+    AP_REQUIRE(m && name && host, "vit_set_param: null argument");
+    auto it = m->params.find(name);
+    AP_REQUIRE(it != m->params.end(), "vit_set_param: unknown parameter '%s'", name);
+    Param& p = it->second;
+    AP_REQUIRE(count == p.count, "vit_set_param: '%s' expects %zu values, got %zu", name, p.count, count);
+    if (!p.matrix) {
+        AP_HIP_CHECK(hipMemcpy(p.dev, host, count * sizeof(float), hipMemcpyHostToDevice));
+    } else {
+        float* tmp = nullptr;
+        AP_HIP_CHECK(hipMalloc((void**)&tmp, (size_t)p.rows * p.ld * sizeof(float)));
+        AP_HIP_CHECK(hipMemset(tmp, 0, (size_t)p.rows * p.ld * sizeof(float)));
+        AP_HIP_CHECK(hipMemcpy2D(tmp, (size_t)p.ld * sizeof(float), host, (size_t)p.cols * sizeof(float),
+                                 (size_t)p.cols * sizeof(float), p.rows, hipMemcpyHostToDevice));
+        int rc = ap::launch_convert(m->cfg.compute_dtype, tmp, p.dev, (size_t)p.rows * p.ld, nullptr);
+        if (rc != AP_OK) { (void)hipFree(tmp); return rc; }
+        AP_HIP_CHECK(hipDeviceSynchronize());
+        AP_HIP_CHECK(hipFree(tmp));
+    }
+    p.set = true;
+    return AP_OK;
+}
+
+int ap_vit_finalize(ap_vit* m) {
+    AP_REQUIRE(m, "vit_finalize: null handle");
+    for (auto& kv : m->params)
+        if (!kv.second.set) {
+            ap::set_error("vit_finalize: parameter '%s' was never set", kv.first.c_str());
+            return AP_ERR_STATE;
+        }
+    m->finalized = true;
+    return AP_OK;
+}
+
+size_t ap_vit_workspace_bytes(const ap_vit* m, int n) {
+    if (!m || n <= 0) return 0;
+    return carve(m, n, nullptr).total;
+}
+
+int ap_vit_embed_dim(const ap_vit* m) { return m ? m->cfg.dim : 0; }
+
+int ap_vit_forward_u8(ap_vit* m, const uint8_t* patches, int n, int h, int w, const float mean[3],
+                      const float stdv[3], float* out, void* workspace, size_t workspace_bytes,
+                      ap_stream_t stream) {
+    int rc = check_forward_args(m, n, patches, out, workspace, workspace_bytes);
+    if (rc != AP_OK || n == 0) return rc;
+    const int S = m->cfg.image_size;
+    AP_REQUIRE(h >= S && w >= S, "vit_forward_u8: %dx%d tiles smaller than the %d model input "
+               "(resampling preprocess not in this build)", h, w, S);
+    // torchvision CenterCrop: top = int(round((h - S) / 2.0)) (banker's rounding)
+    auto crop_off = [](int full, int size) { int d = full - size; return (d / 2) + ((d & 1) && ((d / 2) & 1) ? 1 : 0); };
+    const Workspace ws = carve(m, n, (char*)workspace);
+    hipStream_t s = (hipStream_t)stream;
+    if (m->kpe != 3 * m->cfg.patch_size * m->cfg.patch_size)
+        AP_HIP_CHECK(hipMemsetAsync(ws.hid, 0, (size_t)n * m->patches * m->kpe * ap::dtype_size(m->cfg.compute_dtype), s));
+    rc = ap::preproc_patchrows(patches, n, h, w, crop_off(h, S), crop_off(w, S), S, S, m->cfg.patch_size,
+                               mean, stdv, ws.hid, m->kpe, m->cfg.compute_dtype, s);
+    if (rc != AP_OK) return rc;
+    return run_blocks(m, n, ws, out, s);
+}
+
+int ap_vit_forward_chw(ap_vit* m, const void* x, int x_dtype, int n, float* out, void* workspace,
+                       size_t workspace_bytes, ap_stream_t stream) {
+    int rc = check_forward_args(m, n, x, out, workspace, workspace_bytes);
+    if (rc != AP_OK || n == 0) return rc;
+    AP_REQUIRE(x_dtype == AP_F32 || x_dtype == m->cfg.compute_dtype,
+               "vit_forward_chw: input dtype %d must be f32 or the compute dtype", x_dtype);
+    const Workspace ws = carve(m, n, (char*)workspace);
+    hipStream_t s = (hipStream_t)stream;
+    if (m->kpe != 3 * m->cfg.patch_size * m->cfg.patch_size)
+        AP_HIP_CHECK(hipMemsetAsync(ws.hid, 0, (size_t)n * m->patches * m->kpe * ap::dtype_size(m->cfg.compute_dtype), s));
+    rc = ap::launch_chw_to_patchrows(x_dtype, m->cfg.compute_dtype, x, n, m->cfg.image_size,
+                                     m->cfg.patch_size, ws.hid, m->kpe, s);
+    if (rc != AP_OK) return rc;
+    return run_blocks(m, n, ws, out, s);
+}
+
+}  // extern "C"

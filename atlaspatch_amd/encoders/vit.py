@@ -1,0 +1,303 @@
+"""ViT-family encoders on the native HIP path.
+
+* ``ARCHS``: the shapes the reference registers as ``vit_b_16`` / ``vit_l_16``
+  (/root/reference/atlas_patch/models/patch/vit.py:9-15, torchvision) and ``uni_v1``
+  (models/patch/uni.py:13-60, timm ViT-L/16 with LayerScale).
+* ``canonical_state_dict``: adapters from torchvision / timm / HF ``ViTModel`` key names to the
+  parameter names of ``ap_vit_set_param``.  QKV is packed ``[q; k; v]`` rows.
+* ``HipViT``: owns the ``ap_vit`` handle and its HBM workspace; ``forward_u8`` / ``forward_chw``
+  launch on torch's current stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+import os
+from pathlib import Path
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .base import HipViTFeatureExtractor
+
+logger = logging.getLogger("atlaspatch_amd.encoders.vit")
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+ARCHS = {
+    # name: image, patch, dim, depth, heads, mlp, eps, layer_scale
+    "vit_b_16": dict(image_size=224, patch_size=16, dim=768, depth=12, heads=12, mlp_dim=3072,
+                     ln_eps=1e-6, layer_scale=False),
+    "vit_l_16": dict(image_size=224, patch_size=16, dim=1024, depth=24, heads=16, mlp_dim=4096,
+                     ln_eps=1e-6, layer_scale=False),
+    "uni_v1": dict(image_size=224, patch_size=16, dim=1024, depth=24, heads=16, mlp_dim=4096,
+                   ln_eps=1e-6, layer_scale=True),
+}
+
+
+# ----------------------------------------------------------------------------- adapters
+def _detect_source(sd: dict) -> str:
+    keys = sd.keys()
+    if "conv_proj.weight" in keys:
+        return "torchvision"
+    if "patch_embed.proj.weight" in keys:
+        return "timm"
+    if any(k.startswith("embeddings.patch_embeddings") for k in keys):
+        return "hf"
+    if "patch_embed.weight" in keys:
+        return "canonical"
+    raise ValueError("unrecognised ViT state dict (expected torchvision, timm, HF ViTModel or canonical keys)")
+
+
+def canonical_state_dict(sd: dict, *, depth: int, layer_scale: bool, source: str = "auto") -> dict:
+    """Return ``{canonical name: float32 CPU tensor}`` for ``ap_vit_set_param``."""
+    sd = {k: v for k, v in sd.items()}
+    if source == "auto":
+        source = _detect_source(sd)
+    out: dict[str, torch.Tensor] = {}
+
+    def put(name, tensor):
+        out[name] = tensor.detach().to(dtype=torch.float32, device="cpu").contiguous()
+
+    if source == "canonical":
+        for k, v in sd.items():
+            put(k, v)
+    elif source == "torchvision":
+        put("patch_embed.weight", sd["conv_proj.weight"]); put("patch_embed.bias", sd["conv_proj.bias"])
+        put("cls_token", sd["class_token"].reshape(-1)); put("pos_embed", sd["encoder.pos_embedding"][0])
+        put("norm.weight", sd["encoder.ln.weight"]); put("norm.bias", sd["encoder.ln.bias"])
+        for i in range(depth):
+            p, b = f"encoder.layers.encoder_layer_{i}.", f"blocks.{i}."
+            put(b + "ln1.weight", sd[p + "ln_1.weight"]); put(b + "ln1.bias", sd[p + "ln_1.bias"])
+            put(b + "qkv.weight", sd[p + "self_attention.in_proj_weight"])
+            put(b + "qkv.bias", sd[p + "self_attention.in_proj_bias"])
+            put(b + "proj.weight", sd[p + "self_attention.out_proj.weight"])
+            put(b + "proj.bias", sd[p + "self_attention.out_proj.bias"])
+            put(b + "ln2.weight", sd[p + "ln_2.weight"]); put(b + "ln2.bias", sd[p + "ln_2.bias"])
+            f1 = "mlp.0" if p + "mlp.0.weight" in sd else "mlp.linear_1"
+            f2 = "mlp.3" if p + "mlp.3.weight" in sd else "mlp.linear_2"
+            put(b + "fc1.weight", sd[p + f1 + ".weight"]); put(b + "fc1.bias", sd[p + f1 + ".bias"])
+            put(b + "fc2.weight", sd[p + f2 + ".weight"]); put(b + "fc2.bias", sd[p + f2 + ".bias"])
+    elif source == "timm":
+        put("patch_embed.weight", sd["patch_embed.proj.weight"]); put("patch_embed.bias", sd["patch_embed.proj.bias"])
+        put("cls_token", sd["cls_token"].reshape(-1)); put("pos_embed", sd["pos_embed"][0])
+        put("norm.weight", sd["norm.weight"]); put("norm.bias", sd["norm.bias"])
+        for i in range(depth):
+            p, b = f"blocks.{i}.", f"blocks.{i}."
+            put(b + "ln1.weight", sd[p + "norm1.weight"]); put(b + "ln1.bias", sd[p + "norm1.bias"])
+            put(b + "qkv.weight", sd[p + "attn.qkv.weight"]); put(b + "qkv.bias", sd[p + "attn.qkv.bias"])
+            put(b + "proj.weight", sd[p + "attn.proj.weight"]); put(b + "proj.bias", sd[p + "attn.proj.bias"])
+            put(b + "ln2.weight", sd[p + "norm2.weight"]); put(b + "ln2.bias", sd[p + "norm2.bias"])
+            put(b + "fc1.weight", sd[p + "mlp.fc1.weight"]); put(b + "fc1.bias", sd[p + "mlp.fc1.bias"])
+            put(b + "fc2.weight", sd[p + "mlp.fc2.weight"]); put(b + "fc2.bias", sd[p + "mlp.fc2.bias"])
+            if layer_scale:
+                put(b + "ls1", sd[p + "ls1.gamma"]); put(b + "ls2", sd[p + "ls2.gamma"])
+    elif source == "hf":
+        put("patch_embed.weight", sd["embeddings.patch_embeddings.projection.weight"])
+        put("patch_embed.bias", sd["embeddings.patch_embeddings.projection.bias"])
+        put("cls_token", sd["embeddings.cls_token"].reshape(-1))
+        put("pos_embed", sd["embeddings.position_embeddings"][0])
+        put("norm.weight", sd["layernorm.weight"]); put("norm.bias", sd["layernorm.bias"])
+        for i in range(depth):
+            b = f"blocks.{i}."
+            if f"layers.{i}.layernorm_before.weight" in sd:          # transformers >= 5
+                p = f"layers.{i}."
+                q, k, v, o = (p + "attention." + n for n in ("q_proj", "k_proj", "v_proj", "o_proj"))
+                f1, f2 = p + "mlp.fc1", p + "mlp.fc2"
+            else:                                                    # transformers 4.x
+                p = f"encoder.layer.{i}."
+                q, k, v = (p + "attention.attention." + n for n in ("query", "key", "value"))
+                o, f1, f2 = p + "attention.output.dense", p + "intermediate.dense", p + "output.dense"
+            put(b + "ln1.weight", sd[p + "layernorm_before.weight"]); put(b + "ln1.bias", sd[p + "layernorm_before.bias"])
+            put(b + "qkv.weight", torch.cat([sd[q + ".weight"], sd[k + ".weight"], sd[v + ".weight"]], 0))
+            put(b + "qkv.bias", torch.cat([sd[q + ".bias"], sd[k + ".bias"], sd[v + ".bias"]], 0))
+            put(b + "proj.weight", sd[o + ".weight"]); put(b + "proj.bias", sd[o + ".bias"])
+            put(b + "ln2.weight", sd[p + "layernorm_after.weight"]); put(b + "ln2.bias", sd[p + "layernorm_after.bias"])
+            put(b + "fc1.weight", sd[f1 + ".weight"]); put(b + "fc1.bias", sd[f1 + ".bias"])
+            put(b + "fc2.weight", sd[f2 + ".weight"]); put(b + "fc2.bias", sd[f2 + ".bias"])
+    else:
+        raise ValueError(f"unknown state-dict source '{source}'")
+    return out
+
+
+def random_canonical_state_dict(arch: dict, seed: int = 0) -> dict:
+    """Seeded random-init weights (trunc-normal-ish sigma 0.02, LN gamma ~ 1): there are no
+    pretrained checkpoints offline."""
+    g = torch.Generator().manual_seed(seed)
+    d, mlp, ps = arch["dim"], arch["mlp_dim"], arch["patch_size"]
+    tokens = 1 + (arch["image_size"] // ps) ** 2
+
+    def w(*shape, s=0.02):
+        return torch.randn(*shape, generator=g) * s
+
+    sd = {"patch_embed.weight": w(d, 3, ps, ps), "patch_embed.bias": w(d), "cls_token": w(d),
+          "pos_embed": w(tokens, d), "norm.weight": 1.0 + w(d, s=0.1), "norm.bias": w(d)}
+    for i in range(arch["depth"]):
+        b = f"blocks.{i}."
+        sd[b + "ln1.weight"] = 1.0 + w(d, s=0.1); sd[b + "ln1.bias"] = w(d)
+        sd[b + "qkv.weight"] = w(3 * d, d); sd[b + "qkv.bias"] = w(3 * d)
+        sd[b + "proj.weight"] = w(d, d); sd[b + "proj.bias"] = w(d)
+        sd[b + "ln2.weight"] = 1.0 + w(d, s=0.1); sd[b + "ln2.bias"] = w(d)
+        sd[b + "fc1.weight"] = w(mlp, d); sd[b + "fc1.bias"] = w(mlp)
+        sd[b + "fc2.weight"] = w(d, mlp); sd[b + "fc2.bias"] = w(d)
+        if arch.get("layer_scale"):
+            sd[b + "ls1"] = torch.full((d,), 1e-5) + w(d, s=1e-6)
+            sd[b + "ls2"] = torch.full((d,), 1e-5) + w(d, s=1e-6)
+    return sd
+
+
+# ----------------------------------------------------------------------------- device object
+class HipViT:
+    """Device-resident ViT encoder behind ``ap_vit_*``."""
+
+    def __init__(self, arch: dict, state: dict, *, device: torch.device, dtype: torch.dtype) -> None:
+        if device.type != "cuda":
+            raise _lib.HipLibraryError("HipViT needs a HIP device ('cuda' on PyTorch-ROCm); "
+                                       "there is no CPU fallback")
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.dtype = dtype
+        self.arch = dict(arch)
+        self.embed_dim = int(arch["dim"])
+        cfg = _lib.VitConfig(arch["image_size"], arch["patch_size"], arch["dim"], arch["depth"],
+                             arch["heads"], arch["mlp_dim"], float(arch["ln_eps"]),
+                             1 if arch.get("layer_scale") else 0, _lib.torch_dtype_code(dtype))
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ap_vit_create(C.byref(cfg), C.byref(handle)), "ap_vit_create")
+            self._handle = handle
+            for name, tensor in state.items():
+                arr = np.ascontiguousarray(tensor.detach().to(torch.float32).cpu().numpy())
+                _lib.check(self.lib.ap_vit_set_param(self._handle, name.encode(), arr.ctypes.data_as(C.c_void_p),
+                                                     arr.size), f"ap_vit_set_param({name})")
+            _lib.check(self.lib.ap_vit_finalize(self._handle), "ap_vit_finalize")
+        self._workspace: Optional[torch.Tensor] = None
+
+    def _ws(self, n: int) -> torch.Tensor:
+        need = int(self.lib.ap_vit_workspace_bytes(self._handle, n))
+        if self._workspace is None or self._workspace.numel() < need:
+            self._workspace = None
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._workspace
+
+    def forward_u8(self, tiles: torch.Tensor, mean, std, out: torch.Tensor) -> torch.Tensor:
+        """tiles: uint8 [n, H, W, 3] on the device; out: float32 [n, D] on the device (written)."""
+        if self._handle is None:
+            raise _lib.HipLibraryError("HipViT used after release()")
+        assert tiles.dtype == torch.uint8 and tiles.is_contiguous() and tiles.dim() == 4 and tiles.shape[3] == 3
+        assert out.dtype == torch.float32 and out.is_contiguous() and out.shape == (tiles.shape[0], self.embed_dim)
+        n, h, w, _ = tiles.shape
+        if n == 0:
+            return out
+        ws = self._ws(n)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ap_vit_forward_u8(self._handle, tiles.data_ptr(), n, h, w, _lib.f3(mean), _lib.f3(std),
+                                                  out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                  _lib.current_stream_ptr(self.device)), "ap_vit_forward_u8")
+        return out
+
+    def forward_chw(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x: [n, 3, S, S] float32 or compute dtype, already normalised."""
+        if self._handle is None:
+            raise _lib.HipLibraryError("HipViT used after release()")
+        assert x.is_contiguous() and x.dim() == 4
+        n = x.shape[0]
+        if out is None:
+            out = torch.empty((n, self.embed_dim), dtype=torch.float32, device=self.device)
+        if n == 0:
+            return out
+        ws = self._ws(n)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ap_vit_forward_chw(self._handle, x.data_ptr(), _lib.torch_dtype_code(x.dtype), n,
+                                                   out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                   _lib.current_stream_ptr(self.device)), "ap_vit_forward_chw")
+        return out
+
+    def release(self) -> None:
+        if getattr(self, "_handle", None) is not None:
+            torch.cuda.synchronize(self.device)
+            self.lib.ap_vit_destroy(self._handle)
+            self._handle = None
+            self._workspace = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+# ----------------------------------------------------------------------------- builders
+def weights_path(name: str) -> Optional[Path]:
+    """``$ATLASPATCH_WEIGHTS_DIR/<name>.{safetensors,pt,pth}`` if present."""
+    root = os.environ.get("ATLASPATCH_WEIGHTS_DIR")
+    if not root:
+        return None
+    for ext in (".safetensors", ".pt", ".pth"):
+        candidate = Path(root) / f"{name}{ext}"
+        if candidate.exists():
+            return candidate
+    return None
+
+
+def load_checkpoint(path: Path) -> dict:
+    if path.suffix == ".safetensors":
+        from safetensors.torch import load_file
+        return load_file(str(path))
+    obj = torch.load(str(path), map_location="cpu", weights_only=True)
+    for key in ("model", "state_dict"):
+        if isinstance(obj, dict) and key in obj and isinstance(obj[key], dict):
+            obj = obj[key]
+    return obj
+
+
+def build_hip_vit_extractor(*, name: str, arch, device, dtype, state_dict: Optional[dict] = None,
+                            mean=None, std=None, source: str = "auto", max_batch: int = 1024,
+                            random_init_seed: Optional[int] = None, host_resize=None,
+                            expect_size: Optional[int] = 256, **arch_overrides) -> HipViTFeatureExtractor:
+    spec = dict(ARCHS[arch]) if isinstance(arch, str) else dict(arch)
+    spec.update(arch_overrides)
+    if state_dict is None:
+        path = weights_path(name)
+        if path is not None:
+            state_dict = load_checkpoint(path)
+        elif random_init_seed is not None:
+            logger.warning("%s: using seeded RANDOM weights (seed %d); features are not meaningful",
+                           name, random_init_seed)
+            state_dict = random_canonical_state_dict(spec, random_init_seed)
+            source = "canonical"
+        else:
+            raise FileNotFoundError(
+                f"No weights for '{name}': set ATLASPATCH_WEIGHTS_DIR to a directory holding "
+                f"{name}.safetensors/.pt (torchvision, timm or HF ViT key names), or set "
+                "ATLASPATCH_RANDOM_INIT=<seed> for seeded random weights (benchmarks/tests).")
+    state = canonical_state_dict(state_dict, depth=spec["depth"], layer_scale=bool(spec.get("layer_scale")),
+                                 source=source)
+    vit = HipViT(spec, state, device=torch.device(device), dtype=dtype)
+    return HipViTFeatureExtractor(name=name, vit=vit, mean=mean or IMAGENET_MEAN, std=std or IMAGENET_STD,
+                                  max_batch=max_batch, host_resize=host_resize, expect_size=expect_size)
+
+
+def _env_seed() -> Optional[int]:
+    raw = os.environ.get("ATLASPATCH_RANDOM_INIT")
+    return int(raw) if raw not in (None, "") else None
+
+
+def register_vits(registry, *, device, dtype=torch.float32, num_workers: int = 0) -> None:
+    """vit_b_16 / vit_l_16 with torchvision's transform semantics: ImageClassification(crop 224,
+    resize 256) -- for the 256-px tiles this pipeline produces that is a centre crop."""
+    for name in ("vit_b_16", "vit_l_16"):
+        registry.register(name, lambda n=name: build_hip_vit_extractor(
+            name=n, arch=n, device=device, dtype=dtype, random_init_seed=_env_seed(), expect_size=256))
+
+
+def register_uni(registry, *, device, dtype=torch.float32, num_workers: int = 0) -> None:
+    """uni_v1: timm ViT-L/16 + LayerScale; timm transform Resize(224, bicubic) + CenterCrop(224):
+    the resize runs on the host with Pillow (the reference's own resampler), the rest on device."""
+    from PIL import Image
+    registry.register("uni_v1", lambda: build_hip_vit_extractor(
+        name="uni_v1", arch="uni_v1", device=device, dtype=dtype, random_init_seed=_env_seed(),
+        host_resize=(224, Image.Resampling.BICUBIC), expect_size=224))

@@ -1,0 +1,151 @@
+/*
+ * atlaspatch_hip.h -- C ABI of the MI355X (gfx950) hot path of the AtlasPatch drop-in.
+ *
+ * One shared library (libatlaspatch_hip.so), plain pointers and sizes, no torch or
+ * C++ types in any signature.  Every entry point returns 0 on success or a
+ * negative AP_ERR_* code; nothing throws, nothing synchronises the device unless
+ * its comment says so, and the caller owns every buffer.  Device pointers are
+ * HIP device pointers (what torch.Tensor.data_ptr() returns on ROCm); a stream is
+ * a hipStream_t passed as void* (NULL = the default stream).
+ *
+ * Each block cites the reference interface it replaces (paths under
+ * /root/reference/atlas_patch).  INTEGRATION.md shows the ctypes stubs a
+ * maintainer of the reference would add.
+ */
+#ifndef ATLASPATCH_HIP_H
+#define ATLASPATCH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AP_OK 0
+#define AP_ERR_INVALID (-1)      /* bad argument (null pointer, size, unsupported shape) */
+#define AP_ERR_HIP (-2)          /* a HIP runtime call failed; see ap_last_error() */
+#define AP_ERR_WORKSPACE (-3)    /* workspace too small */
+#define AP_ERR_UNSUPPORTED (-4)  /* valid request this build has no kernel for */
+#define AP_ERR_STATE (-5)        /* object not finalised / already finalised */
+#define AP_ERR_CAPACITY (-6)     /* output buffer too small; needed count is reported */
+
+/* element types of device tensors */
+#define AP_F32 0
+#define AP_F16 1
+#define AP_BF16 2
+
+typedef void* ap_stream_t;
+
+/* ---- library ---------------------------------------------------------------------- */
+int ap_abi_version(void);                 /* bumps when a signature changes */
+const char* ap_last_error(void);          /* thread-local text of the last failure */
+int ap_device_info(int device, char* name, int name_cap, int* cu_count, size_t* hbm_bytes);
+
+/* ---- K1: patch preprocess ----------------------------------------------------------
+ * Replaces the per-item CPU transform + collate + H2D + cast of
+ * models/patch/base.py:42-45,84-99 (PatchDataset.__getitem__ + DataLoader + .to()).
+ * y = ((float(x) / 255) - mean[c]) / std[c] with two true divisions and no FMA
+ * contraction, i.e. bit-identical in f32 to torchvision's ToTensor + Normalize;
+ * the cast to f16/bf16 happens after normalisation (base.py:95-99).
+ *
+ * src: device uint8 [n, h, w, 3] (HWC RGB).  Output window: rows crop_top..crop_top+oh,
+ * cols crop_left..crop_left+ow (centre crop of torchvision ImageClassification; no resample). */
+int ap_preproc_u8hwc_to_chw(const uint8_t* src, int n, int h, int w,
+                            int crop_top, int crop_left, int oh, int ow,
+                            const float mean[3], const float stdv[3],
+                            void* dst /* [n,3,oh,ow] */, int dst_dtype, ap_stream_t stream);
+
+/* Same arithmetic, output laid out for the patch-embed GEMM: dst[(i*gh+py)*gw+px][c*ps*ps+ky*ps+kx]
+ * with gh = oh/ps, gw = ow/ps, row length ld (>= 3*ps*ps, zero padded). */
+int ap_preproc_u8hwc_to_patchrows(const uint8_t* src, int n, int h, int w,
+                                  int crop_top, int crop_left, int oh, int ow, int ps,
+                                  const float mean[3], const float stdv[3],
+                                  void* dst, int ld, int dst_dtype, ap_stream_t stream);
+
+/* ---- ViT encoder -------------------------------------------------------------------
+ * Replaces `forward_fn(batch) or model(batch)` of models/patch/base.py:100 for the
+ * ViT family the reference registers as vit_b_16 / vit_l_16 (models/patch/vit.py:9-38)
+ * and uni_v1 (models/patch/uni.py:13-60): conv patch-embed, CLS + pos-embed, pre-LN
+ * blocks (packed-QKV MHA, erf-GELU MLP, optional LayerScale), final LN, CLS token. */
+typedef struct ap_vit ap_vit;
+
+typedef struct ap_vit_config {
+    int image_size;      /* 224 */
+    int patch_size;      /* 16 */
+    int dim;             /* 768 / 1024 */
+    int depth;           /* 12 / 24 */
+    int heads;           /* 12 / 16 */
+    int mlp_dim;         /* 3072 / 4096 */
+    float ln_eps;        /* 1e-6 (torchvision, timm) or 1e-12 (HF default) */
+    int layer_scale;     /* 1: per-branch gamma (timm init_values, uni.py:35) */
+    int compute_dtype;   /* AP_F16 / AP_BF16 / AP_F32: MFMA operand type; accumulation,
+                            residual stream, LayerNorm and softmax are always f32 */
+} ap_vit_config;
+
+int ap_vit_create(const ap_vit_config* cfg, ap_vit** out);
+void ap_vit_destroy(ap_vit* m);
+
+/* Upload one parameter (host float32, `count` elements).  Names:
+ *   patch_embed.weight [dim,3,ps,ps]  patch_embed.bias [dim]  cls_token [dim]
+ *   pos_embed [1+gh*gw, dim]          norm.weight / norm.bias [dim]
+ *   blocks.<i>.ln1.weight|bias  blocks.<i>.qkv.weight [3dim,dim] (rows q;k;v)  blocks.<i>.qkv.bias
+ *   blocks.<i>.proj.weight [dim,dim] | .bias   blocks.<i>.ls1 [dim]
+ *   blocks.<i>.ln2.weight|bias  blocks.<i>.fc1.weight [mlp,dim] | .bias
+ *   blocks.<i>.fc2.weight [dim,mlp] | .bias    blocks.<i>.ls2 [dim]
+ * Synchronous (copies before returning). */
+int ap_vit_set_param(ap_vit* m, const char* name, const float* host, size_t count);
+int ap_vit_finalize(ap_vit* m);   /* checks every parameter was set */
+
+size_t ap_vit_workspace_bytes(const ap_vit* m, int n);
+int ap_vit_embed_dim(const ap_vit* m);
+
+/* patches: device uint8 [n, h, w, 3]; centre-cropped to image_size, normalised with
+ * mean/std, embedded.  out: device float32 [n, dim].  Asynchronous on `stream`. */
+int ap_vit_forward_u8(ap_vit* m, const uint8_t* patches, int n, int h, int w,
+                      const float mean[3], const float stdv[3],
+                      float* out, void* workspace, size_t workspace_bytes, ap_stream_t stream);
+
+/* x: device [n, 3, image_size, image_size] already normalised, dtype x_dtype (AP_F32 or the
+ * compute dtype): the boundary a plugin `preprocess` feeds (models/patch/custom.py:31-43). */
+int ap_vit_forward_chw(ap_vit* m, const void* x, int x_dtype, int n,
+                       float* out, void* workspace, size_t workspace_bytes, ap_stream_t stream);
+
+/* ---- tissue mask -> patch coordinates ----------------------------------------------
+ * Replaces utils/contours.py:41-131 (mask_to_contours, scale_contours) and the grid scan of
+ * services/extraction.py:67-128 (_in_tissue, _iter_patch_entries, FourPointContainment). */
+typedef struct ap_contours ap_contours;
+
+/* mask: HOST float32 [h, w].  Thresholds (> 0.5) on the device, follows borders
+ * (Suzuki-Abe, RETR_CCOMP / CHAIN_APPROX_NONE semantics), applies the area / hole filters
+ * of mask_to_contours and scales to level 0 with scale_contours' float32 truncation.
+ * Synchronous. */
+int ap_contours_from_mask(const float* mask, int h, int w, double tissue_area_thresh,
+                          int min_hole_area, int max_n_holes, double sx, double sy,
+                          ap_contours** out, ap_stream_t stream);
+void ap_contours_destroy(ap_contours* c);
+int ap_contours_count(const ap_contours* c);                 /* tissue contours */
+int ap_contours_num_holes(const ap_contours* c, int i);
+/* points of tissue contour i (hole < 0) or of its hole `hole`; scaled=0 -> mask space.
+ * Returns the point count; copies min(count, cap) int32 (x, y) pairs into xy. */
+int ap_contours_points(const ap_contours* c, int i, int hole, int scaled, int32_t* xy, int cap);
+
+/* Grid scan on the device.  coords: HOST int32 [cap, 5] rows (x, y, read_w, read_h, level) in
+ * the reference's order.  *n_rows receives the total (also when it exceeds cap ->
+ * AP_ERR_CAPACITY).  Synchronous. */
+int ap_grid_coords(const ap_contours* c, int patch_size_src, int step_src,
+                   int read_w, int read_h, int level,
+                   int32_t* coords, size_t cap, size_t* n_rows, ap_stream_t stream);
+
+/* ---- synthetic slide tiles ------------------------------------------
+ * Renders tiles of a synthetic slide straight into HBM: dst uint8 [n, ps, ps, 3] for the n
+ * level-0 top-left corners xy (device int32 [n, 2]).  Bit-identical to
+ * atlaspatch_amd/core/wsi/synth_pixels.py.  ellipses: device int64 [k, 4]. */
+int ap_synth_tiles(const int32_t* xy, int n, int ps, int level_ds, int level,
+                   int64_t width, int64_t height, uint32_t seed,
+                   const int64_t* ellipses, int k, uint8_t* dst, ap_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ATLASPATCH_HIP_H */

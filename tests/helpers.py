@@ -1,0 +1,47 @@
+"""Shared test helpers (inputs that reproduce the golden generator's seeds)."""
+import json
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_coords_cases():
+    arrays = np.load(os.path.join(GOLDEN, "coords_cases.npz"))
+    with open(os.path.join(GOLDEN, "coords_cases.json")) as fh:
+        meta = json.load(fh)
+    cases = {}
+    for name, info in meta.items():
+        shape = tuple(int(v) for v in arrays[f"{name}__mask_shape"])
+        bits = np.unpackbits(arrays[f"{name}__mask_bits"])[: shape[0] * shape[1]]
+        mask = bits.reshape(shape).astype(np.float32)
+        cases[name] = dict(mask=mask, coords=arrays[f"{name}__coords"], info=info)
+    return cases
+
+
+def load_contour_case(name):
+    arrays = np.load(os.path.join(GOLDEN, "contours_cases.npz"))
+    lens = arrays[f"{name}__lens"]
+    pts = arrays[f"{name}__pts"]
+    nholes = arrays[f"{name}__nholes"]
+    polys, off = [], 0
+    for n in lens:
+        polys.append(pts[off:off + n])
+        off += n
+    n_t = len(nholes)
+    tissue = polys[:n_t]
+    holes, k = [], n_t
+    for nh in nholes:
+        holes.append(polys[k:k + nh])
+        k += nh
+    return tissue, holes
+
+
+def golden_patches(tag_ns):
+    """Patches exactly as tests/golden/gen_golden.py drew them: ONE rng per tag, sequential ns."""
+    rng = np.random.default_rng(0)
+    out = {}
+    for n in tag_ns:
+        out[n] = [rng.integers(0, 256, (256, 256, 3), dtype=np.uint8) for _ in range(n)]
+    return out

@@ -11,6 +11,8 @@ import threading
 
 AP_F32, AP_F16, AP_BF16 = 0, 1, 2
 AP_OK = 0
+PROF_KINDS = ("preproc", "gemm_patch_embed", "gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2",
+              "attention", "layernorm")
 AP_ERR_CAPACITY = -6
 
 _LIB_NAME = "libatlaspatch_hip.so"
@@ -45,6 +47,8 @@ SIGNATURES = {
     "ap_vit_finalize": (C.c_int, [C.c_void_p]),
     "ap_vit_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
     "ap_vit_embed_dim": (C.c_int, [C.c_void_p]),
+    "ap_vit_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "ap_vit_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]),
     "ap_vit_forward_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
                                     C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ap_vit_forward_chw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,

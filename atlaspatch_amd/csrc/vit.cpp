@@ -33,7 +33,32 @@ struct ap_vit {
     std::map<std::string, ap::Param> params;
     bool finalized = false;
     int device = 0;
+    // optional per-launch HIP-event timing (ap_vit_profile_*): kind -> events of the last forwards
+    bool profile = false;
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> ev_used;
+    size_t ev_next = 0;
 };
+
+namespace {
+hipEvent_t next_event(ap_vit* m) {
+    if (m->ev_next == m->ev_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        m->ev_pool.push_back(e);
+    }
+    return m->ev_pool[m->ev_next++];
+}
+struct ScopedTimer {      // records start/stop events around one launch when profiling is on
+    ap_vit* m; int kind; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
+    ScopedTimer(ap_vit* m_, int kind_, hipStream_t s_) : m(m_), kind(kind_), s(s_) {
+        if (m->profile) { a = next_event(m); b = next_event(m); if (a) (void)hipEventRecord(a, s); }
+    }
+    ~ScopedTimer() {
+        if (m->profile && a && b) { (void)hipEventRecord(b, s); m->ev_used.push_back({kind, {a, b}}); }
+    }
+};
+}  // namespace
 
 namespace {
 
@@ -95,7 +120,8 @@ int run_blocks(ap_vit* m, int n, const Workspace& w, float* out, hipStream_t str
         g.bias = (const float*)find(m, "patch_embed.bias")->dev;
         g.pos = (const float*)find(m, "pos_embed")->dev;
         g.out = w.tok; g.ldo = D; g.P = m->patches;
-        if ((rc = ap::launch_gemm(dt, ap::EPI_PATCH_EMBED, g, stream)) != AP_OK) return rc;
+        { ScopedTimer t(m, AP_PROF_GEMM_PATCH_EMBED, stream);
+          if ((rc = ap::launch_gemm(dt, ap::EPI_PATCH_EMBED, g, stream)) != AP_OK) return rc; }
         if ((rc = ap::launch_cls_init(w.tok, (const float*)find(m, "cls_token")->dev,
                                       (const float*)find(m, "pos_embed")->dev, n, m->tokens, D,
                                       stream)) != AP_OK) return rc;
@@ -104,29 +130,35 @@ int run_blocks(ap_vit* m, int n, const Workspace& w, float* out, hipStream_t str
         const std::string b = "blocks." + std::to_string(i) + ".";
         auto vec = [&](const char* s) { return (const float*)find(m, b + s)->dev; };
         auto mat = [&](const char* s) { return find(m, b + s); };
-        if ((rc = ap::launch_layernorm(dt, w.tok, D, M, D, vec("ln1.weight"), vec("ln1.bias"),
-                                       c.ln_eps, w.xn, stream)) != AP_OK) return rc;
+        { ScopedTimer t(m, AP_PROF_LAYERNORM, stream);
+          if ((rc = ap::launch_layernorm(dt, w.tok, D, M, D, vec("ln1.weight"), vec("ln1.bias"),
+                                         c.ln_eps, w.xn, stream)) != AP_OK) return rc; }
         {
             ap::GemmArgs g{};
             g.A = w.xn; g.lda = D; g.W = mat("qkv.weight")->dev; g.ldw = mat("qkv.weight")->ld;
             g.M = M; g.N = 3 * D; g.K = D; g.bias = vec("qkv.bias"); g.out = w.qkv; g.ldo = 3 * D;
+            ScopedTimer t(m, AP_PROF_GEMM_QKV, stream);
             if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_STORE, g, stream)) != AP_OK) return rc;
         }
-        if ((rc = ap::launch_attention(dt, w.qkv, w.att, n, m->tokens, c.heads, D / c.heads,
-                                       stream)) != AP_OK) return rc;
+        { ScopedTimer t(m, AP_PROF_ATTENTION, stream);
+          if ((rc = ap::launch_attention(dt, w.qkv, w.att, n, m->tokens, c.heads, D / c.heads,
+                                         stream)) != AP_OK) return rc; }
         {
             ap::GemmArgs g{};
             g.A = w.att; g.lda = D; g.W = mat("proj.weight")->dev; g.ldw = mat("proj.weight")->ld;
             g.M = M; g.N = D; g.K = D; g.bias = vec("proj.bias");
             g.gamma = c.layer_scale ? vec("ls1") : nullptr; g.out = w.tok; g.ldo = D;
+            ScopedTimer t(m, AP_PROF_GEMM_PROJ, stream);
             if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_RESID, g, stream)) != AP_OK) return rc;
         }
-        if ((rc = ap::launch_layernorm(dt, w.tok, D, M, D, vec("ln2.weight"), vec("ln2.bias"),
-                                       c.ln_eps, w.xn, stream)) != AP_OK) return rc;
+        { ScopedTimer t(m, AP_PROF_LAYERNORM, stream);
+          if ((rc = ap::launch_layernorm(dt, w.tok, D, M, D, vec("ln2.weight"), vec("ln2.bias"),
+                                         c.ln_eps, w.xn, stream)) != AP_OK) return rc; }
         {
             ap::GemmArgs g{};
             g.A = w.xn; g.lda = D; g.W = mat("fc1.weight")->dev; g.ldw = mat("fc1.weight")->ld;
             g.M = M; g.N = c.mlp_dim; g.K = D; g.bias = vec("fc1.bias"); g.out = w.hid; g.ldo = c.mlp_dim;
+            ScopedTimer t(m, AP_PROF_GEMM_FC1, stream);
             if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_GELU, g, stream)) != AP_OK) return rc;
         }
         {
@@ -134,6 +166,7 @@ int run_blocks(ap_vit* m, int n, const Workspace& w, float* out, hipStream_t str
             g.A = w.hid; g.lda = c.mlp_dim; g.W = mat("fc2.weight")->dev; g.ldw = mat("fc2.weight")->ld;
             g.M = M; g.N = D; g.K = c.mlp_dim; g.bias = vec("fc2.bias");
             g.gamma = c.layer_scale ? vec("ls2") : nullptr; g.out = w.tok; g.ldo = D;
+            ScopedTimer t(m, AP_PROF_GEMM_FC2, stream);
             if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_RESID, g, stream)) != AP_OK) return rc;
         }
     }
@@ -212,6 +245,7 @@ void ap_vit_destroy(ap_vit* m) {
     if (!m) return;
     for (auto& kv : m->params)
         if (kv.second.dev) (void)hipFree(kv.second.dev);
+    for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
     delete m;
 }
 
@@ -256,6 +290,29 @@ size_t ap_vit_workspace_bytes(const ap_vit* m, int n) {
 
 int ap_vit_embed_dim(const ap_vit* m) { return m ? m->cfg.dim : 0; }
 
+int ap_vit_profile_enable(ap_vit* m, int on) {
+    AP_REQUIRE(m, "vit_profile_enable: null handle");
+    m->profile = on != 0;
+    m->ev_used.clear();
+    m->ev_next = 0;
+    return AP_OK;
+}
+
+int ap_vit_profile_read(ap_vit* m, double* ms_by_kind, long long* launches_by_kind, int kinds) {
+    AP_REQUIRE(m && ms_by_kind && launches_by_kind && kinds >= AP_PROF_KINDS, "vit_profile_read: bad arguments");
+    for (int k = 0; k < kinds; ++k) { ms_by_kind[k] = 0.0; launches_by_kind[k] = 0; }
+    for (auto& u : m->ev_used) {
+        AP_HIP_CHECK(hipEventSynchronize(u.second.second));
+        float ms = 0.f;
+        AP_HIP_CHECK(hipEventElapsedTime(&ms, u.second.first, u.second.second));
+        ms_by_kind[u.first] += ms;
+        launches_by_kind[u.first] += 1;
+    }
+    m->ev_used.clear();
+    m->ev_next = 0;
+    return AP_OK;
+}
+
 int ap_vit_forward_u8(ap_vit* m, const uint8_t* patches, int n, int h, int w, const float mean[3],
                       const float stdv[3], float* out, void* workspace, size_t workspace_bytes,
                       ap_stream_t stream) {
@@ -270,8 +327,9 @@ int ap_vit_forward_u8(ap_vit* m, const uint8_t* patches, int n, int h, int w, co
     hipStream_t s = (hipStream_t)stream;
     if (m->kpe != 3 * m->cfg.patch_size * m->cfg.patch_size)
         AP_HIP_CHECK(hipMemsetAsync(ws.hid, 0, (size_t)n * m->patches * m->kpe * ap::dtype_size(m->cfg.compute_dtype), s));
-    rc = ap::preproc_patchrows(patches, n, h, w, crop_off(h, S), crop_off(w, S), S, S, m->cfg.patch_size,
-                               mean, stdv, ws.hid, m->kpe, m->cfg.compute_dtype, s);
+    { ScopedTimer t(m, AP_PROF_PREPROC, s);
+      rc = ap::preproc_patchrows(patches, n, h, w, crop_off(h, S), crop_off(w, S), S, S, m->cfg.patch_size,
+                                 mean, stdv, ws.hid, m->kpe, m->cfg.compute_dtype, s); }
     if (rc != AP_OK) return rc;
     return run_blocks(m, n, ws, out, s);
 }

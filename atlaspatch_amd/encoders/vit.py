@@ -216,6 +216,17 @@ class HipViT:
                                                    _lib.current_stream_ptr(self.device)), "ap_vit_forward_chw")
         return out
 
+    def profile(self, on: bool) -> None:
+        _lib.check(self.lib.ap_vit_profile_enable(self._handle, 1 if on else 0), "ap_vit_profile_enable")
+
+    def profile_read(self) -> dict:
+        """{kind: (milliseconds, launches)} accumulated since the last read (HIP events)."""
+        k = len(_lib.PROF_KINDS)
+        ms = (C.c_double * k)()
+        cnt = (C.c_longlong * k)()
+        _lib.check(self.lib.ap_vit_profile_read(self._handle, ms, cnt, k), "ap_vit_profile_read")
+        return {name: (float(ms[i]), int(cnt[i])) for i, name in enumerate(_lib.PROF_KINDS)}
+
     def release(self) -> None:
         if getattr(self, "_handle", None) is not None:
             torch.cuda.synchronize(self.device)

@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py -- patches/sec embedded (256x256 tiles, ViT-B/16) on N MI355X.
+
+Workload (BASELINE.json configs[1]): `process` on one synthetic 40 000 x 40 000 slide, ViT-B/16,
+one slide per rank.  Tiles are the slide's own tissue tiles (coords from the device coordinate
+path, pixels rendered into HBM by ap_synth_tiles) -- resident in HBM before the timed region.
+A "step" = one pass of the hot path over one device batch of tiles:
+    uint8 HWC tiles -> K1 normalise/crop/patch-rows -> ViT-B/16 (12 blocks) -> float32 [B, 768].
+Weights: seeded random init of the ViT-B/16 architecture (no checkpoints offline).
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched by
+torch.distributed.run, one rank per GPU (RCCL).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+FLOP_PER_PATCH_VIT_B16 = 35.126e9      # 33.695 GEMM (incl. 0.231 patch-embed) + 1.431 attention
+MFMA_PEAK = {"f16": 2.5e15, "bf16": 2.5e15, "f32": 157.3e12}   # dense, MI355X_MICROARCH.md
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=1024, help="tiles per step (device batch)")
+    ap.add_argument("--precision", default="float16", choices=["float16", "bfloat16", "float32"])
+    ap.add_argument("--slide", type=int, default=40000, help="synthetic slide side in pixels")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=192, help="patches timed on the CPU oracle")
+    return ap.parse_args()
+
+
+def slide_tiles(device, side, seed, count):
+    """Device coords path + on-device tile synthesis -> uint8 [count, 256, 256, 3] in HBM."""
+    import ctypes as C
+    from atlaspatch_amd import _lib
+    from atlaspatch_amd.core.wsi.synth_pixels import SynthSpec, analytic_mask
+    from atlaspatch_amd.services.extraction import coords_from_mask
+
+    spec = SynthSpec(width=side, height=side, seed=seed)
+    mask = analytic_mask(spec)
+    t0 = time.perf_counter()
+    coords, geom = coords_from_mask(mask, level0_wh=(side, side), downsamples=list(spec.downsamples),
+                                    src_mag=spec.mag, tgt_mag=spec.mag, patch_size=256, step_size=None,
+                                    tissue_thresh=0.0)
+    coords_s = time.perf_counter() - t0
+    cells = int(math.ceil(side / 256) ** 2)
+    n_slide = coords.shape[0]
+    reps = int(math.ceil(count / max(1, n_slide)))
+    xy = np.tile(coords[:, :2], (reps, 1))[:count].astype(np.int32)
+    lib = _lib.load()
+    d_xy = torch.from_numpy(np.ascontiguousarray(xy)).to(device)
+    d_ell = torch.from_numpy(spec.ellipses()).to(device)
+    tiles = torch.empty((count, 256, 256, 3), dtype=torch.uint8, device=device)
+    _lib.check(lib.ap_synth_tiles(d_xy.data_ptr(), count, 256, 1, 0, side, side, spec.seed, d_ell.data_ptr(),
+                                  d_ell.shape[0], tiles.data_ptr(), _lib.current_stream_ptr(device)))
+    torch.cuda.synchronize(device)
+    return tiles, n_slide, cells, coords_s
+
+
+def cpu_baseline(sample, seed):
+    """CPU oracle (torch fp32 restatement of the reference path) on a bounded sample."""
+    from atlaspatch_amd.encoders.vit import ARCHS, random_canonical_state_dict
+    from oracle import vit_oracle
+
+    arch = ARCHS["vit_b_16"]
+    sd = random_canonical_state_dict(arch, seed=seed)
+    hf = {"embeddings.patch_embeddings.projection.weight": sd["patch_embed.weight"],
+          "embeddings.patch_embeddings.projection.bias": sd["patch_embed.bias"],
+          "embeddings.cls_token": sd["cls_token"].view(1, 1, -1),
+          "embeddings.position_embeddings": sd["pos_embed"][None],
+          "layernorm.weight": sd["norm.weight"], "layernorm.bias": sd["norm.bias"]}
+    for i in range(arch["depth"]):
+        p, b = f"layers.{i}.", f"blocks.{i}."
+        q, k, v = sd[b + "qkv.weight"].chunk(3, 0)
+        qb, kb, vb = sd[b + "qkv.bias"].chunk(3, 0)
+        hf.update({p + "layernorm_before.weight": sd[b + "ln1.weight"], p + "layernorm_before.bias": sd[b + "ln1.bias"],
+                   p + "attention.q_proj.weight": q, p + "attention.q_proj.bias": qb,
+                   p + "attention.k_proj.weight": k, p + "attention.k_proj.bias": kb,
+                   p + "attention.v_proj.weight": v, p + "attention.v_proj.bias": vb,
+                   p + "attention.o_proj.weight": sd[b + "proj.weight"], p + "attention.o_proj.bias": sd[b + "proj.bias"],
+                   p + "layernorm_after.weight": sd[b + "ln2.weight"], p + "layernorm_after.bias": sd[b + "ln2.bias"],
+                   p + "mlp.fc1.weight": sd[b + "fc1.weight"], p + "mlp.fc1.bias": sd[b + "fc1.bias"],
+                   p + "mlp.fc2.weight": sd[b + "fc2.weight"], p + "mlp.fc2.bias": sd[b + "fc2.bias"]})
+    rng = np.random.default_rng(0)
+    patches = [rng.integers(0, 256, (256, 256, 3), dtype=np.uint8) for _ in range(sample)]
+    vit_oracle.extract_batch(hf, patches[:32], heads=arch["heads"], batch_size=32)        # warm-up
+    t0 = time.perf_counter()
+    out = vit_oracle.extract_batch(hf, patches, heads=arch["heads"], batch_size=32)
+    dt = time.perf_counter() - t0
+    return out, hf, patches, sample / dt
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the product has no CPU fallback")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    from atlaspatch_amd.encoders.vit import build_hip_vit_extractor
+
+    dtype = {"float16": torch.float16, "bfloat16": torch.bfloat16, "float32": torch.float32}[args.precision]
+    short = {"float16": "f16", "bfloat16": "bf16", "float32": "f32"}[args.precision]
+    ex = build_hip_vit_extractor(name="vit_b_16", arch="vit_b_16", device=device, dtype=dtype,
+                                 random_init_seed=0, max_batch=args.batch)
+    B, K, W = args.batch, args.steps, args.warmup
+    pool_steps = min(K, 12)                       # distinct tile batches cycled through the timed steps
+    tiles, n_slide, cells, coords_s = slide_tiles(device, args.slide, 1234 + rank, pool_steps * B)
+    feats = torch.empty((K * B, ex.embedding_dim), dtype=torch.float32, device=device)
+
+    def step(i, dst):
+        s = (i % pool_steps) * B
+        ex.vit.forward_u8(tiles[s:s + B], ex.mean, ex.std, dst)
+
+    for i in range(W):
+        step(i, feats[:B])
+    torch.cuda.synchronize(device)
+    ex.vit.profile(True)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for i in range(K):
+        step(i, feats[i * B:(i + 1) * B])
+    gathered = None
+    if dist is not None:        # reassemble the feature matrix on every rank (north star): one all-gather
+        gathered = torch.empty((world * K * B, ex.embedding_dim), dtype=torch.float32, device=device)
+        dist.all_gather_into_tensor(gathered, feats)
+    torch.cuda.synchronize(device)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    prof = ex.vit.profile_read()
+    ex.vit.profile(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    value = world * K * B / elapsed
+    # ---- roofline of the dominant kernel: the fc1 GEMM (gemm_kernel<T, EPI_BIAS_GELU>), one shape per launch
+    M = B * 197
+    fc1_ms, fc1_n = prof["gemm_fc1"]
+    flop_launch = 2.0 * M * 3072 * 768
+    fc1_avg_s = (fc1_ms / max(1, fc1_n)) * 1e-3
+    achieved = flop_launch / fc1_avg_s / 1e12 if fc1_n else 0.0
+    peak = MFMA_PEAK[short] / 1e12
+    gemm_ms = sum(prof[k][0] for k in ("gemm_patch_embed", "gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2"))
+    kernel_ms = {k: round(v[0] / K, 4) for k, v in prof.items()}
+    line = {
+        "metric": "patches/sec embedded (256x256, ViT-B/16)", "value": round(value, 1), "unit": "patches/s",
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": short, "data": "synthetic",
+        "config": {"workload": f"process: one synthetic {args.slide}x{args.slide} slide per rank, 256x256 tiles "
+                               f"resident in HBM, ViT-B/16 (random-init), device batch {B}",
+                   "tiles_per_step": B, "slide_tissue_tiles": int(n_slide), "grid_cells": cells,
+                   "parallelism": f"slide-per-rank x{world}" + (" + RCCL all-gather of features" if world > 1 else "")},
+        "roofline": {"bound": "mfma", "kernel": "gemm_kernel<T,EPI_BIAS_GELU> (fc1: [B*197,768]x[768,3072])",
+                     "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "TFLOP/s",
+                     "frac": round(achieved / peak, 4), "traffic": None,
+                     "avg_launch_ms": round(fc1_avg_s * 1e3, 4), "launches": fc1_n,
+                     "algorithmic_flop_per_launch": flop_launch},
+        "end_to_end_model_tflops": round(value * FLOP_PER_PATCH_VIT_B16 / 1e12 / world, 1),
+        "kernel_ms_per_step": kernel_ms,
+        "coords": {"cells": cells, "rows": int(n_slide), "seconds": round(coords_s, 4),
+                   "cells_per_s": round(cells / coords_s, 1)},
+    }
+    if not args.no_cpu_baseline:
+        out_cpu, hf, patches, cpu_rate = cpu_baseline(args.cpu_sample, seed=0)
+        # parity of the measured path against the CPU oracle on the same sample (reported, not timed)
+        got = ex.extract_batch(patches, batch_size=32)
+        rel = float(np.linalg.norm(got.astype(np.float64) - out_cpu) / np.linalg.norm(out_cpu))
+        line["cpu_baseline"] = {"value": round(cpu_rate, 2), "unit": "patches/s",
+                                "cores": int(torch.get_num_threads()), "kind": "port",
+                                "sample": f"{args.cpu_sample} random 256x256 tiles, ViT-B/16 fp32, torch CPU oracle "
+                                          f"(oracle/vit_oracle.py), batch 32",
+                                "rel_err_gpu_vs_cpu": rel}
+    print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

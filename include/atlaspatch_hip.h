@@ -100,6 +100,22 @@ int ap_vit_finalize(ap_vit* m);   /* checks every parameter was set */
 size_t ap_vit_workspace_bytes(const ap_vit* m, int n);
 int ap_vit_embed_dim(const ap_vit* m);
 
+/* Optional per-launch timing with HIP events recorded on the forward's own stream (what
+ * bench.py's roofline block reads).  Off by default; when on, every kernel launch of a forward
+ * is bracketed by two events.  ap_vit_profile_read synchronises on them, returns summed
+ * milliseconds and launch counts per kind since the last read, and resets. */
+#define AP_PROF_PREPROC 0
+#define AP_PROF_GEMM_PATCH_EMBED 1
+#define AP_PROF_GEMM_QKV 2
+#define AP_PROF_GEMM_PROJ 3
+#define AP_PROF_GEMM_FC1 4
+#define AP_PROF_GEMM_FC2 5
+#define AP_PROF_ATTENTION 6
+#define AP_PROF_LAYERNORM 7
+#define AP_PROF_KINDS 8
+int ap_vit_profile_enable(ap_vit* m, int on);
+int ap_vit_profile_read(ap_vit* m, double* ms_by_kind, long long* launches_by_kind, int kinds);
+
 /* patches: device uint8 [n, h, w, 3]; centre-cropped to image_size, normalised with
  * mean/std, embedded.  out: device float32 [n, dim].  Asynchronous on `stream`. */
 int ap_vit_forward_u8(ap_vit* m, const uint8_t* patches, int n, int h, int w,

@@ -182,7 +182,7 @@ class PatchFeatureExtractor(FeatureExtractor):
                 feats = torch.flatten(feats, start_dim=1)
             results.append(feats.detach())
         merged = results[0] if len(results) == 1 else torch.cat(results, dim=0)
-        return merged.cpu().to(dtype=torch.float32).numpy()
+        return merged.cpu().to(dtype=torch.float32).contiguous().numpy()
 
     def cleanup(self) -> None:
         try:

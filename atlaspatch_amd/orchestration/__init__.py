@@ -1,0 +1,3 @@
+from .runner import ProcessingRunner
+
+__all__ = ["ProcessingRunner"]

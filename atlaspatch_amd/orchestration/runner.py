@@ -1,0 +1,193 @@
+"""Phase-1 orchestration: discover -> (skip | reuse | lock) -> segment -> coords (reference:
+orchestration/runner.py:39-306, orchestration/parallel.py).
+
+The reference hides the slow Python grid scan behind a thread pool with an in-flight tracker;
+here coordinate extraction is a few milliseconds of GPU work per slide, so slides are processed
+in order within each segmentation batch (results therefore come back in slide order, which the
+reference only guarantees per batch).  Everything observable is kept: per-slide lock files
+(``O_CREAT | O_EXCL``), ``--skip-existing`` reuse of an H5 whose feature sets are incomplete,
+per-slide failure isolation, ``(results, failures)`` return value.
+
+MI355X addition: ``rank`` / ``world_size`` shard the slide list one-slide-per-rank
+(``slides[rank::world_size]``) -- the device/rank dispatch of the north star.
+"""
+from __future__ import annotations
+
+import logging
+import os
+import time
+from pathlib import Path
+from typing import Any, Iterable, Sequence
+
+from tqdm import tqdm
+
+from ..core.config import AppConfig
+from ..core.models import ExtractionResult, Slide
+from ..core.paths import find_existing_patch, patch_lock_path
+from ..services.interfaces import (ExtractionService, MPPResolver, SegmentationService,
+                                   VisualizationService, WSILoader)
+from ..utils.features import missing_features
+from ..utils.h5 import h5
+from ..utils.params import get_wsi_files
+
+logger = logging.getLogger("atlaspatch_amd.runner")
+
+
+def _batches(items: Sequence[Slide], size: int) -> Iterable[Sequence[Slide]]:
+    for start in range(0, len(items), size):
+        yield items[start:start + size]
+
+
+class ProcessingRunner:
+    def __init__(self, config: AppConfig, segmentation: SegmentationService, extractor: ExtractionService,
+                 visualizer: VisualizationService | None, mpp_resolver: MPPResolver, wsi_loader: WSILoader, *,
+                 show_progress: bool = False, rank: int = 0, world_size: int = 1) -> None:
+        self.config = config.validated()
+        self.segmentation = segmentation
+        self.extractor = extractor
+        self.visualizer = visualizer
+        self.mpp_resolver = mpp_resolver
+        self.wsi_loader = wsi_loader
+        self.show_progress = show_progress
+        self.rank, self.world_size = int(rank), max(1, int(world_size))
+
+    # ------------------------------------------------------------------ discovery
+    def discover_slides(self) -> list[Slide]:
+        files = get_wsi_files(str(self.config.processing.input_path), recursive=self.config.processing.recursive)
+        slides = [Slide(path=Path(f)) for f in files]
+        return slides[self.rank::self.world_size]
+
+    def _with_mpp(self, slides: list[Slide]) -> list[Slide]:
+        return [Slide(path=s.path, mpp=self.mpp_resolver.resolve(s), backend=s.backend) for s in slides]
+
+    # ------------------------------------------------------------------ skip / reuse
+    def _existing_result(self, slide: Slide, h5_path: Path) -> ExtractionResult | None:
+        try:
+            with h5.File(h5_path, "r") as f:
+                total = f.attrs.get("num_patches")
+                if total is None and "coords" in f:
+                    total = f["coords"].shape[0]
+                ps0 = f.attrs.get("patch_size_level0")
+        except Exception as exc:  # noqa: BLE001
+            logger.warning("Failed to read existing output for %s; will reprocess. Error: %s", slide.path.name, exc)
+            return None
+        if total is None or int(total) <= 0:
+            return None
+        meta: dict[str, Any] = {}
+        return ExtractionResult(slide=slide, h5_path=h5_path, num_patches=int(total),
+                                patch_size_level0=int(ps0) if ps0 is not None else None, metadata=meta)
+
+    def _handled_as_existing(self, slide: Slide, results: list[ExtractionResult], tick) -> bool:
+        if not self.config.output.skip_existing:
+            return False
+        path = find_existing_patch(slide, self.config.output, self.config.extraction)
+        if path is None:
+            return False
+        feats = self.config.features
+        if feats is None or not feats.extractors:
+            logger.info("Skipping %s (already processed).", slide.path.name)
+            tick()
+            return True
+        prior = self._existing_result(slide, path)
+        if prior is None:
+            logger.info("Existing output invalid for %s; reprocessing.", slide.path.name)
+            return False
+        gaps = missing_features(path, feats.extractors, expected_total=prior.num_patches)
+        if gaps:
+            results.append(prior)
+            logger.info("Reusing existing patches for %s; missing features: %s", slide.path.name, ", ".join(gaps))
+        else:
+            logger.info("Skipping %s (features complete).", slide.path.name)
+        tick()
+        return True
+
+    # ------------------------------------------------------------------ locks
+    def _acquire_lock(self, slide: Slide):
+        path = patch_lock_path(slide, self.config.output, self.config.extraction)
+        path.parent.mkdir(parents=True, exist_ok=True)
+        try:
+            fd = os.open(path, os.O_CREAT | os.O_EXCL | os.O_WRONLY)
+        except FileExistsError:
+            return None, path
+        except Exception as exc:  # noqa: BLE001
+            raise RuntimeError(f"Failed to create lock {path}: {exc}") from exc
+        os.write(fd, f"pid={os.getpid()},time={int(time.time())},slide={slide.path}".encode())
+        os.fsync(fd)
+        return fd, path
+
+    @staticmethod
+    def _release_lock(fd, path: Path) -> None:
+        if fd is not None:
+            try:
+                os.close(fd)
+            except OSError:
+                pass
+        try:
+            path.unlink()
+        except OSError:
+            pass
+
+    # ------------------------------------------------------------------ main loop
+    def run(self):
+        slides = self._with_mpp(self.discover_slides())
+        if not slides:
+            logger.warning("No slides found to process.")
+            return [], []
+        results: list[ExtractionResult] = []
+        failures: list[tuple] = []
+        bar = tqdm(total=len(slides), disable=not self.show_progress, desc="Processing slides")
+        tick = (lambda: bar.update(1)) if self.show_progress else (lambda: None)
+
+        for group in _batches(slides, max(1, self.config.segmentation.batch_size)):
+            opened = []
+            for slide in group:
+                if self._handled_as_existing(slide, results, tick):
+                    continue
+                fd, lock_path = self._acquire_lock(slide)
+                if fd is None:
+                    logger.info("Skipping %s (locked by another process).", slide.path.name)
+                    tick()
+                    continue
+                try:
+                    opened.append((slide, self.wsi_loader.open(slide), fd, lock_path))
+                except Exception as exc:  # noqa: BLE001
+                    failures.append((slide, exc))
+                    logger.error("Failed to open %s: %s", slide.path.name, exc)
+                    self._release_lock(fd, lock_path)
+                    tick()
+            if not opened:
+                continue
+            try:
+                wsis = [w for _, w, _, _ in opened]
+                masks = (self.segmentation.segment_batch(wsis) if len(wsis) > 1
+                         else [self.segmentation.segment_thumbnail(wsis[0])])
+            except Exception as exc:  # noqa: BLE001
+                for slide, wsi, fd, lock_path in opened:
+                    failures.append((slide, exc))
+                    logger.error("Segmentation failed for %s: %s", slide.path.name, exc)
+                    self._close(wsi)
+                    self._release_lock(fd, lock_path)
+                    tick()
+                continue
+            for (slide, wsi, fd, lock_path), mask in zip(opened, masks):
+                try:
+                    result = self.extractor.extract(wsi, mask.data, slide=slide)
+                    if self.visualizer is not None:
+                        self.visualizer.visualize(result, wsi=wsi, mask=mask.data)
+                    results.append(result)
+                except Exception as exc:  # noqa: BLE001
+                    failures.append((slide, exc))
+                    logger.error("Extraction failed for %s: %s", slide.path.name, exc)
+                finally:
+                    self._close(wsi)
+                    self._release_lock(fd, lock_path)
+                    tick()
+        bar.close()
+        return results, failures
+
+    @staticmethod
+    def _close(wsi) -> None:
+        try:
+            wsi.cleanup()
+        except Exception:  # noqa: BLE001
+            pass

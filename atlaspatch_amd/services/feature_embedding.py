@@ -1,0 +1,266 @@
+"""Feature embedding service (reference: services/feature_embedding.py:28-316).
+
+Same public surface (``resolve_feature_dtype``, ``PatchFeatureEmbeddingService.embed_features /
+embed_all``), same sequencing (extractor-major, slide-minor; one model resident at a time; lock
+file per slide; skip feature sets that are already complete; failures collected, not raised).
+For extractors on the native HIP path the per-slide work runs through the pinned tile ring
+(``tile_ring.TileRing``) and the feature matrix is written in one bulk append; any other
+extractor goes through the reference's buffered ``append_features`` loop.
+"""
+from __future__ import annotations
+
+import logging
+import os
+import time
+from pathlib import Path
+from typing import Iterable, Optional
+
+import numpy as np
+import torch
+
+from ..core.config import ExtractionConfig, FeatureExtractionConfig, OutputConfig
+from ..core.models import ExtractionResult
+from ..core.paths import patch_lock_path
+from ..core.wsi.iwsi import IWSI
+from ..encoders import build_default_registry
+from ..encoders.base import HipViTFeatureExtractor
+from ..encoders.custom import register_feature_extractors_from_module
+from ..encoders.registry import PatchFeatureExtractorRegistry
+from ..utils.features import get_existing_features
+from .interfaces import FeatureEmbeddingService
+from .storage import H5PatchWriter, read_coords
+
+logger = logging.getLogger("atlaspatch_amd.feature_embedding_service")
+
+_PRECISION = {"float32": torch.float32, "float16": torch.float16, "bfloat16": torch.bfloat16}
+
+
+def resolve_feature_dtype(device: torch.device, precision: str) -> torch.dtype:
+    """float16 on a CPU device falls back to float32 (feature_embedding.py:28-39)."""
+    dtype = _PRECISION.get(precision, torch.float32)
+    if device.type == "cpu" and dtype == torch.float16:
+        logger.warning("float16 on CPU is unsupported in many ops; falling back to float32.")
+        dtype = torch.float32
+    return dtype
+
+
+def _resize_tile(tile: np.ndarray, size: int) -> np.ndarray:
+    """cv2.resize(tile, (size, size)) stand-in (INTER_LINEAR) for level reads that are not already
+    ``patch_size`` (feature_embedding.py:94-95) -- Pillow bilinear, parity unpinned."""
+    from PIL import Image
+    return np.asarray(Image.fromarray(tile).resize((size, size), Image.Resampling.BILINEAR))
+
+
+class PatchFeatureEmbeddingService(FeatureEmbeddingService):
+    def __init__(self, extraction_cfg: ExtractionConfig, output_cfg: OutputConfig,
+                 feature_cfg: FeatureExtractionConfig,
+                 registry: Optional[PatchFeatureExtractorRegistry] = None) -> None:
+        self.cfg = extraction_cfg.validated()
+        self.output_cfg = output_cfg.validated()
+        self.feature_cfg = feature_cfg.validated()
+        wanted = self.feature_cfg.device
+        if wanted.startswith("cuda") and not torch.cuda.is_available():
+            logger.warning("Feature extraction requested on CUDA but unavailable; using CPU instead.")
+            wanted = "cpu"
+        self.device = torch.device(wanted)
+        self.dtype = resolve_feature_dtype(self.device, self.feature_cfg.precision)
+        self.registry = registry or build_default_registry(device=self.device, dtype=self.dtype,
+                                                           num_workers=self.feature_cfg.num_workers)
+        if registry is None:
+            for plugin in self.feature_cfg.plugins:
+                register_feature_extractors_from_module(plugin, registry=self.registry, device=self.device,
+                                                        dtype=self.dtype,
+                                                        num_workers=self.feature_cfg.num_workers)
+        self.extractor_names = [name.lower() for name in self.feature_cfg.extractors]
+        self._seen: dict[Path, tuple[int | None, set[str]]] = {}
+        self._ring = None
+
+    # ------------------------------------------------------------------ bookkeeping
+    def _existing(self, h5_path: Path, expected_total: int | None = None) -> set[str]:
+        key = Path(h5_path).resolve()
+        hit = self._seen.get(key)
+        if hit is not None and (expected_total is None or hit[0] == expected_total):
+            return set(hit[1])
+        found = get_existing_features(key, expected_total=expected_total)
+        self._seen[key] = (expected_total, set(found))
+        return set(found)
+
+    def _remember(self, h5_path: Path, name: str, total: int) -> None:
+        key = Path(h5_path).resolve()
+        _, have = self._seen.get(key, (total, set()))
+        self._seen[key] = (total, set(have) | {name.lower()})
+
+    def _stamp(self, result: ExtractionResult) -> ExtractionResult:
+        have = sorted(self._existing(result.h5_path, expected_total=result.num_patches))
+        if have:
+            result.metadata["feature_sets"] = have
+        return result
+
+    def _lock(self, slide):
+        path = patch_lock_path(slide, self.output_cfg, self.cfg)
+        path.parent.mkdir(parents=True, exist_ok=True)
+        note = f"pid={os.getpid()},time={int(time.time())},slide={slide.path},phase=features"
+        try:
+            fd = os.open(path, os.O_CREAT | os.O_EXCL | os.O_WRONLY)
+        except FileExistsError:
+            return None, path
+        except Exception as exc:  # noqa: BLE001
+            raise RuntimeError(f"Failed to create feature lock {path}: {exc}") from exc
+        os.write(fd, note.encode())
+        os.fsync(fd)
+        return fd, path
+
+    @staticmethod
+    def _unlock(fd, path) -> None:
+        if fd is not None:
+            try:
+                os.close(fd)
+            except OSError:
+                pass
+        if path is not None:
+            try:
+                path.unlink()
+            except OSError:
+                pass
+
+    # ------------------------------------------------------------------ tile access
+    def _read_tile(self, wsi: IWSI):
+        ps = self.cfg.patch_size
+
+        def read(x, y, rw, rh, lv):
+            tile = wsi.extract((x, y), lv=lv, wh=(rw, rh), mode="array")
+            if tile.shape[0] != ps or tile.shape[1] != ps:
+                tile = _resize_tile(tile, ps)
+            return tile
+
+        return read
+
+    def _entries(self, wsi: IWSI, result: ExtractionResult) -> Iterable[tuple]:
+        read = self._read_tile(wsi)
+        for x, y, rw, rh, lv in read_coords(result.h5_path).tolist():
+            yield x, y, rw, rh, lv, read(x, y, rw, rh, lv)
+
+    # ------------------------------------------------------------------ public API
+    def embed_features(self, result: ExtractionResult, *, wsi: IWSI) -> ExtractionResult:
+        if not self.extractor_names:
+            return result
+        extractor = self.registry.create(self.extractor_names[0])
+        try:
+            return self._embed_with_extractor(result=result, wsi=wsi, extractor=extractor)
+        finally:
+            try:
+                extractor.cleanup()
+            except Exception:  # noqa: BLE001
+                pass
+
+    def _writer(self, result: ExtractionResult, wsi: IWSI) -> H5PatchWriter:
+        step = self.cfg.step_size or self.cfg.patch_size
+        return H5PatchWriter(chunk_rows=self.cfg.write_batch, patch_size=self.cfg.patch_size,
+                             patch_size_level0=result.patch_size_level0 or 0,
+                             level0_mag=int(wsi.mag) if wsi.mag is not None else 0,
+                             target_mag=self.cfg.target_magnification, level0_wh=wsi.get_size(lv=0),
+                             overlap=max(0, int(self.cfg.patch_size) - int(step)),
+                             slide_stem=result.slide.stem, wsi_path=str(wsi.path))
+
+    def _embed_with_extractor(self, *, result: ExtractionResult, wsi: IWSI, extractor) -> ExtractionResult:
+        fd, lock_path = self._lock(result.slide)
+        if fd is None:
+            logger.info("Skipping feature embedding for %s (locked by another process).", result.slide.path.name)
+            return self._stamp(result)
+        try:
+            if extractor.name.lower() in self._existing(result.h5_path, expected_total=result.num_patches):
+                logger.info("Skipping feature embedding for %s (feature '%s' already exists).",
+                            result.slide.path.name, extractor.name)
+                return self._stamp(result)
+            attrs = {"name": extractor.name, "embedding_dim": extractor.embedding_dim}
+            writer = self._writer(result, wsi)
+            if isinstance(extractor, HipViTFeatureExtractor) and extractor.host_resize is None:
+                feats = self.embed_matrix(result, wsi, extractor)
+                writer.append_feature_matrix(output_path=result.h5_path, feature_name=extractor.name,
+                                             features=feats, feature_attrs=attrs,
+                                             feature_batch=self.feature_cfg.batch_size,
+                                             expected_total=result.num_patches)
+            else:
+                writer.append_features(output_path=result.h5_path, entries=self._entries(wsi, result),
+                                       feature_name=extractor.name,
+                                       feature_fn=lambda patches, ex=extractor: ex.extract_batch(
+                                           patches, batch_size=self.feature_cfg.batch_size),
+                                       feature_attrs=attrs, feature_batch=self.feature_cfg.batch_size,
+                                       expected_total=result.num_patches)
+            self._remember(result.h5_path, extractor.name, result.num_patches)
+        finally:
+            self._unlock(fd, lock_path)
+        known = result.metadata.get("feature_sets", [])
+        merged = list(dict.fromkeys([*known, extractor.name])) if isinstance(known, list) else [extractor.name]
+        result.metadata["feature_sets"] = merged
+        return self._stamp(result)
+
+    def embed_matrix(self, result: ExtractionResult, wsi: IWSI, extractor: HipViTFeatureExtractor) -> np.ndarray:
+        """float32 [N, D] for one slide through the pinned tile ring (device pipeline)."""
+        from .tile_ring import TileRing
+        coords = read_coords(result.h5_path)
+        batch = max(self.feature_cfg.batch_size, min(1024, max(1, coords.shape[0])))
+        if self._ring is None or self._ring.batch != batch or self._ring.ps != self.cfg.patch_size:
+            if self._ring is not None:
+                self._ring.close()
+            self._ring = TileRing(device=extractor.device, batch=batch, patch_size=self.cfg.patch_size,
+                                  slots=2, workers=max(1, self.feature_cfg.num_workers))
+        with torch.cuda.device(extractor.device):
+            return self._ring.run(coords, self._read_tile(wsi),
+                                  lambda tiles, out: extractor.vit.forward_u8(tiles, extractor.mean, extractor.std, out),
+                                  extractor.embedding_dim)
+
+    def embed_all(self, results: list[ExtractionResult], *, wsi_loader, progress=None) -> list[tuple]:
+        failures: list[tuple] = []
+        todo: dict[Path, set[str]] = {}
+        already = 0
+        for res in results:
+            have = self._existing(res.h5_path, expected_total=res.num_patches)
+            missing = [n for n in self.extractor_names if n not in have]
+            if missing:
+                todo[res.h5_path] = set(missing)
+            else:
+                self._stamp(res)
+            already += len(self.extractor_names) - len(missing)
+        if progress and already:
+            progress.update(already)
+
+        for name in self.extractor_names:
+            try:
+                extractor = self.registry.create(name)
+            except Exception as exc:  # noqa: BLE001
+                for res in results:
+                    if name in todo.get(res.h5_path, ()):
+                        failures.append((res.slide, exc))
+                        if progress:
+                            progress.update(1)
+                continue
+            try:
+                for res in results:
+                    if name not in todo.get(res.h5_path, ()):
+                        continue
+                    wsi = None
+                    try:
+                        if extractor.name.lower() not in self._existing(res.h5_path, expected_total=res.num_patches):
+                            wsi = wsi_loader.open(res.slide)
+                            self._embed_with_extractor(result=res, wsi=wsi, extractor=extractor)
+                        self._stamp(res)
+                    except Exception as exc:  # noqa: BLE001
+                        failures.append((res.slide, exc))
+                    finally:
+                        if wsi is not None:
+                            try:
+                                wsi.cleanup()
+                            except Exception:  # noqa: BLE001
+                                pass
+                    if progress:
+                        progress.update(1)
+            finally:
+                try:
+                    extractor.cleanup()
+                except Exception:  # noqa: BLE001
+                    pass
+        if self._ring is not None:
+            self._ring.close()
+            self._ring = None
+        return failures

@@ -1,0 +1,65 @@
+"""world_size-2 gloo tests of the rank dispatch (slide sharding + feature all-gather-v)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, tmp):
+    import torch.distributed as dist
+    from atlaspatch_amd.orchestration.dispatch import gather_feature_matrix, shard
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        slides = [f"s{i}" for i in range(5)]
+        mine = shard(slides, rank, world)
+        assert mine == slides[rank::world]
+        rows = [3, 7][rank]                                   # ragged: different N per rank
+        local = torch.full((rows, 4), float(rank + 1)) + torch.arange(rows).view(-1, 1)
+        parts = gather_feature_matrix(local)
+        assert [p.shape for p in parts] == [(3, 4), (7, 4)]
+        for r, p in enumerate(parts):
+            want = torch.full(([3, 7][r], 4), float(r + 1)) + torch.arange([3, 7][r]).view(-1, 1)
+            assert torch.equal(p, want)
+        empty = gather_feature_matrix(torch.zeros((0, 4)) if rank == 0 else local)   # one empty shard
+        assert empty[0].shape == (0, 4) and empty[1].shape == (7, 4)
+        np.save(os.path.join(tmp, f"ok{rank}.npy"), np.array([1]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_and_gather_world2(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0.npy").exists() and (tmp_path / "ok1.npy").exists()
+
+
+def test_runner_shards_slides_one_per_rank(tmp_path):
+    import json
+    from pathlib import Path
+    from atlaspatch_amd.core.config import (AppConfig, ExtractionConfig, OutputConfig, ProcessingConfig,
+                                            SegmentationConfig)
+    from atlaspatch_amd.orchestration.runner import ProcessingRunner
+    for i in range(5):
+        json.dump({"width": 4096, "height": 4096}, open(tmp_path / f"slide{i}.synth", "w"))
+    yaml = tmp_path / "seg.yaml"
+    yaml.write_text("model: {}\n")
+    seen = []
+    for rank in range(2):
+        cfg = AppConfig(processing=ProcessingConfig(input_path=tmp_path),
+                        segmentation=SegmentationConfig(checkpoint_path=None, config_path=yaml, device="cpu"),
+                        extraction=ExtractionConfig(patch_size=256, target_magnification=20),
+                        output=OutputConfig(output_root=tmp_path / "out"))
+        runner = ProcessingRunner(cfg, None, None, None, None, None, rank=rank, world_size=2)
+        seen.append([s.path.name for s in runner.discover_slides()])
+    assert seen[0] == ["slide0.synth", "slide2.synth", "slide4.synth"]
+    assert seen[1] == ["slide1.synth", "slide3.synth"]

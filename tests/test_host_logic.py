@@ -1,0 +1,279 @@
+"""CPU tests of the host side: config / registry / plugin API / H5 output / C-ABI symbols."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import textwrap
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ----------------------------------------------------------------------------- config (G7)
+def _cases(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "config_cases.json")))
+
+
+def test_device_strings(golden_dir):
+    from atlaspatch_amd.core.config import normalise_device
+    for raw, want in _cases(golden_dir)["device"]:
+        if isinstance(want, dict):
+            with pytest.raises(ValueError) as err:
+                normalise_device(raw)
+            assert str(err.value) == want["error"]
+        else:
+            assert normalise_device(raw) == want
+
+
+def test_extraction_and_feature_config(golden_dir):
+    from atlaspatch_amd.core.config import ExtractionConfig, FeatureExtractionConfig
+    for kw, want in _cases(golden_dir)["extraction"]:
+        if "error" in want:
+            with pytest.raises(ValueError) as err:
+                ExtractionConfig(**kw).validated()
+            assert str(err.value) == want["error"]
+        else:
+            cfg = ExtractionConfig(**kw).validated()
+            assert {"step_size": cfg.step_size, "max_open_slides": cfg.max_open_slides} == want
+    for kw, want in _cases(golden_dir)["features"]:
+        if "error" in want:
+            with pytest.raises(ValueError) as err:
+                FeatureExtractionConfig(**kw).validated()
+            assert str(err.value) == want["error"]
+        else:
+            cfg = FeatureExtractionConfig(**kw).validated()
+            assert {"precision": cfg.precision, "device": cfg.device} == want
+
+
+def test_resolve_feature_dtype_and_registry(golden_dir):
+    import click
+    from atlaspatch_amd.encoders.registry import PatchFeatureExtractorRegistry
+    from atlaspatch_amd.services.feature_embedding import resolve_feature_dtype
+    from atlaspatch_amd.utils.features import parse_feature_list
+    cases = _cases(golden_dir)
+    for dev, prec, want in cases["dtype"]:
+        assert str(resolve_feature_dtype(torch.device(dev), prec)) == want
+    reg = PatchFeatureExtractorRegistry()
+    reg.register("Foo", lambda: "foo-built")
+    reg.register("bar", lambda: "bar-built")
+    ev = cases["registry"]
+    assert reg.available() == ev["available"] and reg.create("FOO") == ev["create_FOO"]
+    with pytest.raises(ValueError) as e1:
+        reg.register("foo", lambda: 1)
+    assert str(e1.value) == ev["dup"]
+    with pytest.raises(KeyError) as e2:
+        reg.create("nope")
+    assert str(e2.value) == ev["unknown"]
+    for raw, want in cases["parse_feature_list"]:
+        if isinstance(want, dict):
+            with pytest.raises(click.BadParameter) as e3:
+                parse_feature_list(raw, choices=["vit_b_16", "uni_v1"])
+            assert e3.value.message == want["error"]
+        else:
+            assert parse_feature_list(raw, choices=["vit_b_16", "uni_v1"]) == want
+
+
+def test_product_geometry_matches_reference(golden_dir):
+    from atlaspatch_amd.services.extraction import _StaticLevels
+    from atlaspatch_amd.services.geometry import prepare_geometry
+    table = json.load(open(os.path.join(golden_dir, "geometry.json")))
+    for row in table["geometry"]:
+        wsi = _StaticLevels(row["ds"], row["mag"])
+        try:
+            g = prepare_geometry(wsi, patch_size=row["ps"], step_size=row["step"], target_magnification=row["tgt"])
+            got = [g.level, g.read_wh[0], g.read_wh[1], g.patch_size_src, g.step_src, g.patch_size_level0]
+        except ValueError as exc:
+            got = {"error": str(exc)}
+        assert got == row["out"], row
+    for row in table["levels"]:
+        wsi = _StaticLevels(row["ds"], 20)
+        if "error" in row:
+            with pytest.raises(ValueError):
+                wsi.optimal_level(row["target"])
+        else:
+            assert wsi.optimal_level(row["target"]) == (row["level"], row["extra"])
+
+
+# ----------------------------------------------------------------------------- plugin API on CPU
+def test_plugin_hook_and_generic_extractor_match_reference_golden(tmp_path, golden_dir):
+    """A plugin file written for the reference's API runs unchanged (generic torch path, CPU) and
+    reproduces the reference's own extract_batch outputs (golden G1)."""
+    from atlaspatch_amd.encoders import PatchFeatureExtractorRegistry, register_feature_extractors_from_module
+    from tests import helpers
+    plugin = tmp_path / "my_plugin.py"
+    plugin.write_text(textwrap.dedent('''
+        import numpy as np, torch
+        from atlaspatch_amd.encoders import CustomEncoderComponents, register_custom_encoder
+        from oracle import vit_oracle
+        MEAN = torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1)
+        STD = torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
+        def preprocess(pil):
+            arr = np.asarray(pil, dtype=np.uint8)[16:240, 16:240, :]
+            x = torch.from_numpy(arr.copy()).permute(2, 0, 1).to(torch.float32).div(255)
+            return x.sub(MEAN).div(STD)
+        def register_feature_extractors(registry, device, dtype, num_workers):
+            def loader(dev, dt):
+                m = vit_oracle.make_hf_vit(layers=2)
+                return CustomEncoderComponents(model=m, preprocess=preprocess,
+                                               forward_fn=lambda x: m(pixel_values=x).last_hidden_state[:, 0])
+            register_custom_encoder(registry=registry, name="HFvit_L2", embedding_dim=768, loader=loader,
+                                    device=device, dtype=dtype, num_workers=num_workers)
+    '''))
+    reg = PatchFeatureExtractorRegistry()
+    register_feature_extractors_from_module(plugin, reg, device=torch.device("cpu"), dtype=torch.float32, num_workers=0)
+    assert reg.available() == ["hfvit_l2"]
+    ex = reg.create("hfvit_L2")
+    g = np.load(os.path.join(golden_dir, "extract_batch.npz"))
+    ns = (0, 1, 5, 32, 33)
+    patches = helpers.golden_patches(ns)
+    for n in ns:
+        out = ex.extract_batch(patches[n], batch_size=32)
+        assert out.dtype == np.float32 and out.shape == (n, 768) and out.flags.c_contiguous
+        if n:
+            assert np.linalg.norm(out - g[f"L2_n{n}_out"]) / np.linalg.norm(g[f"L2_n{n}_out"]) < 2e-5
+    ex.cleanup()
+    bad = tmp_path / "no_hook.py"
+    bad.write_text("x = 1\n")
+    with pytest.raises(AttributeError):
+        register_feature_extractors_from_module(bad, reg, device=torch.device("cpu"), dtype=torch.float32)
+
+
+def test_state_dict_adapters_agree():
+    """torchvision / timm / HF key layouts map to the same canonical parameters."""
+    from atlaspatch_amd.encoders.vit import ARCHS, canonical_state_dict, random_canonical_state_dict
+    arch = dict(ARCHS["uni_v1"]); arch["depth"] = 2
+    canon = random_canonical_state_dict(arch, seed=3)
+    d = arch["dim"]
+    tv = {"conv_proj.weight": canon["patch_embed.weight"], "conv_proj.bias": canon["patch_embed.bias"],
+          "class_token": canon["cls_token"].view(1, 1, d), "encoder.pos_embedding": canon["pos_embed"][None],
+          "encoder.ln.weight": canon["norm.weight"], "encoder.ln.bias": canon["norm.bias"]}
+    timm = {"patch_embed.proj.weight": canon["patch_embed.weight"], "patch_embed.proj.bias": canon["patch_embed.bias"],
+            "cls_token": canon["cls_token"].view(1, 1, d), "pos_embed": canon["pos_embed"][None],
+            "norm.weight": canon["norm.weight"], "norm.bias": canon["norm.bias"]}
+    for i in range(2):
+        b = f"blocks.{i}."
+        p = f"encoder.layers.encoder_layer_{i}."
+        tv.update({p + "ln_1.weight": canon[b + "ln1.weight"], p + "ln_1.bias": canon[b + "ln1.bias"],
+                   p + "self_attention.in_proj_weight": canon[b + "qkv.weight"],
+                   p + "self_attention.in_proj_bias": canon[b + "qkv.bias"],
+                   p + "self_attention.out_proj.weight": canon[b + "proj.weight"],
+                   p + "self_attention.out_proj.bias": canon[b + "proj.bias"],
+                   p + "ln_2.weight": canon[b + "ln2.weight"], p + "ln_2.bias": canon[b + "ln2.bias"],
+                   p + "mlp.0.weight": canon[b + "fc1.weight"], p + "mlp.0.bias": canon[b + "fc1.bias"],
+                   p + "mlp.3.weight": canon[b + "fc2.weight"], p + "mlp.3.bias": canon[b + "fc2.bias"]})
+        timm.update({b + "norm1.weight": canon[b + "ln1.weight"], b + "norm1.bias": canon[b + "ln1.bias"],
+                     b + "attn.qkv.weight": canon[b + "qkv.weight"], b + "attn.qkv.bias": canon[b + "qkv.bias"],
+                     b + "attn.proj.weight": canon[b + "proj.weight"], b + "attn.proj.bias": canon[b + "proj.bias"],
+                     b + "ls1.gamma": canon[b + "ls1"], b + "ls2.gamma": canon[b + "ls2"],
+                     b + "norm2.weight": canon[b + "ln2.weight"], b + "norm2.bias": canon[b + "ln2.bias"],
+                     b + "mlp.fc1.weight": canon[b + "fc1.weight"], b + "mlp.fc1.bias": canon[b + "fc1.bias"],
+                     b + "mlp.fc2.weight": canon[b + "fc2.weight"], b + "mlp.fc2.bias": canon[b + "fc2.bias"]})
+    a = canonical_state_dict(timm, depth=2, layer_scale=True)
+    for k, v in canon.items():
+        assert torch.equal(a[k], v), k
+    t = canonical_state_dict(tv, depth=2, layer_scale=False)
+    for k, v in canon.items():
+        if ".ls" not in k:
+            assert torch.equal(t[k], v), k
+
+
+# ----------------------------------------------------------------------------- H5 output (G5)
+def test_h5_layout_matches_reference(tmp_path, golden_dir):
+    from atlaspatch_amd.services.storage import H5PatchWriter, read_coords
+    from atlaspatch_amd.utils.features import get_existing_features, missing_features
+    from atlaspatch_amd.utils.h5 import h5
+    want = json.load(open(os.path.join(golden_dir, "features_h5.json")))
+    arrays = np.load(os.path.join(golden_dir, "features_h5.npz"))
+    path = tmp_path / "patches" / "tiny.h5"
+    path.parent.mkdir()
+    writer = H5PatchWriter(chunk_rows=8192, patch_size=256, patch_size_level0=256, level0_mag=20, target_mag=20,
+                           level0_wh=(8192, 8192), overlap=0, slide_stem="tiny", wsi_path="x",
+                           extra_file_attrs={"filename": "tiny.synth", "mpp": 0.5, "magnification": 20,
+                                             "vendor": "synthetic"})
+    n = writer.write_coords_array(path, arrays["coords"])
+    assert n == want["num_patches"] and not list(path.parent.glob(".tiny.h5.tmp.*"))
+    assert missing_features(path, ["tiny12"], expected_total=n) == ["tiny12"]
+    # iterator form with the reference's signature, batch 7 like the golden run
+    feats = arrays["feats"]
+    calls = []
+
+    def fn(buf):
+        calls.append(len(buf))
+        start = sum(calls[:-1])
+        return feats[start:start + len(buf)]
+
+    entries = ((int(r[0]), int(r[1]), 256, 256, 0, np.zeros((2, 2, 3), np.uint8)) for r in arrays["coords"])
+    writer.append_features(output_path=path, entries=entries, feature_name="tiny12", feature_fn=fn,
+                           feature_attrs={"name": "tiny12", "embedding_dim": 12}, feature_batch=7, expected_total=n)
+    assert calls == [7] * (n // 7) + ([n % 7] if n % 7 else [])
+    assert get_existing_features(path, expected_total=n) == {"tiny12"}
+    assert get_existing_features(path, expected_total=n + 1) == set()
+    with h5.File(path, "r") as f:
+        for name, spec in want["layout"]["datasets"].items():
+            ds = f[name.split("/")[0]] if "/" not in name else f[name.split("/")[0]][name.split("/")[1]]
+            assert ds.dtype.str == spec["dtype"] and list(ds.shape) == spec["shape"]
+            assert list(ds.chunks) == spec["chunks"]
+            assert [None if m is None else int(m) for m in ds.maxshape] == spec["maxshape"]
+        mine = {k: f.attrs[k] for k in f.attrs.keys()}
+        for k, v in want["layout"]["file_attr_values"].items():
+            assert mine[k] == v, k
+        assert set(mine) - set(want["layout"]["file_attr_values"]) == {"creation_date", "wsi_path"}
+        assert np.array_equal(f["features"]["tiny12"][:], feats)
+    assert np.array_equal(read_coords(path), arrays["coords"])
+    with pytest.raises(ValueError):        # duplicate dataset guard (storage.py:269-272)
+        writer.append_feature_matrix(output_path=path, feature_name="tiny12", features=feats,
+                                     feature_attrs={"embedding_dim": 12}, feature_batch=7, expected_total=n)
+    with pytest.raises(ValueError):        # row-count check (storage.py:323-326); partial dataset removed
+        writer.append_feature_matrix(output_path=path, feature_name="other", features=feats[:5],
+                                     feature_attrs={"embedding_dim": 12}, feature_batch=7, expected_total=n)
+    assert get_existing_features(path) == {"tiny12"}
+    dump = "/opt/conda/bin/h5dump"
+    if os.path.exists(dump):
+        out = subprocess.run([dump, "-H", str(path)], capture_output=True, text=True)
+        assert out.returncode == 0 and 'DATASET "coords"' in out.stdout and "H5T_STD_I32LE" in out.stdout
+
+
+def test_thumbnail_size_matches_pillow():
+    from PIL import Image
+    from atlaspatch_amd.core.wsi.synth_pixels import thumbnail_size
+    for w, h in [(6250, 6250), (2875, 2057), (1024, 733), (500, 300), (2500, 1875), (1025, 1024), (3000, 1001), (7, 9000)]:
+        im = Image.new("RGB", (w, h))
+        im.thumbnail((1024, 1024))
+        assert im.size == thumbnail_size(w, h, 1024), (w, h)
+
+
+# ----------------------------------------------------------------------------- C ABI
+def test_c_abi_library_loads_and_exports_every_declared_symbol():
+    from atlaspatch_amd import _lib
+    header = open(os.path.join(ROOT, "include", "atlaspatch_hip.h")).read()
+    declared = set(re.findall(r"\b(ap_[a-z0-9_]+)\s*\(", header))
+    declared -= {"ap_vit", "ap_contours"}
+    assert declared, "no prototypes found"
+    lib = ctypes.CDLL(_lib.library_path())
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/atlaspatch_hip.h but not exported"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert _lib.load().ap_abi_version() == 1
+
+
+def test_product_has_no_cpu_fallback():
+    from atlaspatch_amd import _lib
+    from atlaspatch_amd.encoders.vit import ARCHS, HipViT, random_canonical_state_dict
+    arch = dict(ARCHS["vit_b_16"]); arch["depth"] = 1
+    with pytest.raises(_lib.HipLibraryError):
+        HipViT(arch, random_canonical_state_dict(arch), device=torch.device("cpu"), dtype=torch.float32)
+    if not torch.cuda.is_available():
+        from atlaspatch_amd.utils.contours import mask_to_contours
+        with pytest.raises(_lib.HipLibraryError):
+            mask_to_contours(np.ones((8, 8), np.float32))
+
+
+def test_product_never_imports_the_oracle():
+    import glob
+    for path in glob.glob(os.path.join(ROOT, "atlaspatch_amd", "**", "*.py"), recursive=True):
+        text = open(path).read()
+        assert "import oracle" not in text and "from oracle" not in text, path

@@ -45,3 +45,25 @@ def golden_patches(tag_ns):
     for n in tag_ns:
         out[n] = [rng.integers(0, 256, (256, 256, 3), dtype=np.uint8) for _ in range(n)]
     return out
+
+
+def canonical_to_hf(sd, depth):
+    """Canonical (ap_vit_set_param) names -> HF ViTModel names the oracle consumes."""
+    hf = {"embeddings.patch_embeddings.projection.weight": sd["patch_embed.weight"],
+          "embeddings.patch_embeddings.projection.bias": sd["patch_embed.bias"],
+          "embeddings.cls_token": sd["cls_token"].view(1, 1, -1),
+          "embeddings.position_embeddings": sd["pos_embed"][None],
+          "layernorm.weight": sd["norm.weight"], "layernorm.bias": sd["norm.bias"]}
+    for i in range(depth):
+        p, b = f"layers.{i}.", f"blocks.{i}."
+        q, k, v = sd[b + "qkv.weight"].chunk(3, 0)
+        qb, kb, vb = sd[b + "qkv.bias"].chunk(3, 0)
+        hf.update({p + "layernorm_before.weight": sd[b + "ln1.weight"], p + "layernorm_before.bias": sd[b + "ln1.bias"],
+                   p + "attention.q_proj.weight": q, p + "attention.q_proj.bias": qb,
+                   p + "attention.k_proj.weight": k, p + "attention.k_proj.bias": kb,
+                   p + "attention.v_proj.weight": v, p + "attention.v_proj.bias": vb,
+                   p + "attention.o_proj.weight": sd[b + "proj.weight"], p + "attention.o_proj.bias": sd[b + "proj.bias"],
+                   p + "layernorm_after.weight": sd[b + "ln2.weight"], p + "layernorm_after.bias": sd[b + "ln2.bias"],
+                   p + "mlp.fc1.weight": sd[b + "fc1.weight"], p + "mlp.fc1.bias": sd[b + "fc1.bias"],
+                   p + "mlp.fc2.weight": sd[b + "fc2.weight"], p + "mlp.fc2.bias": sd[b + "fc2.bias"]})
+    return hf

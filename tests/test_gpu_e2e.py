@@ -1,0 +1,98 @@
+"""GPU end-to-end: the CLI `process` command on a synthetic slide -> H5, checked against the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def _make_slide(folder, name, **kw):
+    spec = {"width": 12000, "height": 9000, "seed": 7, "mag": 20, "mpp": 0.5, "downsamples": [1, 4, 16]}
+    spec.update(kw)
+    path = os.path.join(folder, name)
+    json.dump(spec, open(path, "w"))
+    return path, spec
+
+
+def test_cli_process_synthetic_slide(tmp_path, monkeypatch):
+    from click.testing import CliRunner
+    from atlaspatch_amd.cli import cli
+    from atlaspatch_amd.core.wsi.synth_pixels import SynthSpec, analytic_mask, render_region
+    from atlaspatch_amd.encoders.vit import ARCHS, random_canonical_state_dict
+    from atlaspatch_amd.utils.h5 import h5
+    from oracle import coords_oracle, vit_oracle
+
+    monkeypatch.setenv("ATLASPATCH_RANDOM_INIT", "0")
+    slide, raw = _make_slide(str(tmp_path), "s1.synth")
+    out = tmp_path / "out"
+    args = ["process", slide, "-o", str(out), "--patch-size", "256", "--target-mag", "20",
+            "--feature-extractors", "vit_b_16", "--feature-precision", "float32", "--feature-num-workers", "4"]
+    res = CliRunner().invoke(cli, args, catch_exceptions=False)
+    assert res.exit_code == 0, res.output
+    assert "failures: 0" in res.output
+    h5_path = out / "patches" / "s1.h5"
+    assert h5_path.exists() and not (out / "patches" / "s1.lock").exists()
+
+    spec = SynthSpec(width=raw["width"], height=raw["height"], seed=raw["seed"])
+    want_coords, _ = coords_oracle.coords_from_mask(
+        analytic_mask(spec), level0_wh=(spec.width, spec.height), downsamples=[1.0, 4.0, 16.0], src_mag=20,
+        tgt_mag=20, patch_size=256, step_size=None, tissue_thresh=0.0)          # CLI default thresh 0.0
+    with h5.File(h5_path, "r") as f:
+        coords = f["coords"][:]
+        feats = f["features"]["vit_b_16"][:]
+        assert f.attrs["num_patches"] == coords.shape[0] and f.attrs["patch_size"] == 256
+        assert f["passports"][0].decode().startswith("s1__x")
+    assert np.array_equal(coords, want_coords)
+    assert feats.shape == (coords.shape[0], 768) and feats.dtype == np.float32
+
+    # features of a sample of rows vs the CPU oracle (same seeded weights, same tiles)
+    rows = np.linspace(0, coords.shape[0] - 1, 12).astype(int)
+    tiles = [render_region(spec, int(coords[r, 0]), int(coords[r, 1]), 256, 256, 0) for r in rows]
+    sd = helpers.canonical_to_hf(random_canonical_state_dict(ARCHS["vit_b_16"], 0), 12)
+    want = vit_oracle.extract_batch(sd, tiles, heads=12)
+    rel = np.linalg.norm(feats[rows] - want) / np.linalg.norm(want)
+    assert rel <= 1e-3, rel
+
+    # second run: --skip-existing is the default -> nothing to do, file untouched
+    before = os.path.getmtime(h5_path)
+    res2 = CliRunner().invoke(cli, args, catch_exceptions=False)
+    assert res2.exit_code == 0 and os.path.getmtime(h5_path) == before
+
+
+def test_segment_and_get_coords_two_slides(tmp_path):
+    from click.testing import CliRunner
+    from atlaspatch_amd.cli import cli
+    from atlaspatch_amd.utils.h5 import h5
+    _make_slide(str(tmp_path), "a.synth", seed=1)
+    _make_slide(str(tmp_path), "b.synth", seed=2, width=20000, height=20000)
+    out = tmp_path / "out"
+    res = CliRunner().invoke(cli, ["segment-and-get-coords", str(tmp_path), "-o", str(out), "--patch-size", "256",
+                                   "--target-mag", "20", "--step-size", "128"], catch_exceptions=False)
+    assert res.exit_code == 0 and "Completed 2 slide(s), failures: 0" in res.output
+    for stem in ("a", "b"):
+        with h5.File(out / "patches" / f"{stem}.h5", "r") as f:
+            assert f.attrs["overlap"] == 128 and f["coords"].shape[1] == 5 and "features" not in f
+
+
+def test_tile_ring_matches_direct_forward():
+    from atlaspatch_amd.encoders.vit import build_hip_vit_extractor
+    from atlaspatch_amd.services.tile_ring import TileRing
+    dev = torch.device("cuda:0")
+    ex = build_hip_vit_extractor(name="ring", arch="vit_b_16", depth=1, device=dev, dtype=torch.float16,
+                                 random_init_seed=3)
+    rng = np.random.default_rng(0)
+    n = 70
+    tiles = rng.integers(0, 256, (n, 256, 256, 3), dtype=np.uint8)
+    coords = np.stack([np.arange(n), np.zeros(n), np.full(n, 256), np.full(n, 256), np.zeros(n)], 1).astype(np.int32)
+    ring = TileRing(device=dev, batch=16, patch_size=256, slots=2, workers=3)
+    got = ring.run(coords, lambda x, y, rw, rh, lv: tiles[x],
+                   lambda t, o: ex.vit.forward_u8(t, ex.mean, ex.std, o), 768)
+    ring.close()
+    want = ex.extract_batch(list(tiles), batch_size=32)
+    assert np.array_equal(got, want)
+    ex.cleanup()

@@ -53,6 +53,12 @@ SIGNATURES = {
                                     C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ap_vit_forward_chw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                      C.c_size_t, C.c_void_p]),
+    "ap_gemm": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ap_gemm_trace": (C.c_int, [C.c_void_p, C.c_int]),
+    "ap_layernorm": (C.c_int, [C.c_int, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                               C.c_float, C.c_void_p, C.c_void_p]),
+    "ap_attention": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ap_contours_from_mask": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_double,
                                         C.c_double, C.POINTER(C.c_void_p), C.c_void_p]),
     "ap_contours_destroy": (None, [C.c_void_p]),

@@ -52,11 +52,25 @@ template <> __device__ __forceinline__ float from_f32<float>(float v) { return v
 template <> __device__ __forceinline__ f16 from_f32<f16>(float v) { return (f16)v; }
 template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }
 
+// GELU(x) = x * Phi(x) for results that are rounded to f16 / bf16 right after (both GEMM kernels):
+//   Phi(x) ~= sigmoid(x * (c0 + c1 t + c2 t^2)),  t = min(x^2, 50)
+// (coefficients: minimax fit against 0.5 x (1 + erf(x / sqrt 2)) on [-9, 9], max |error| 2.6e-5,
+// below f16's half-ulp for |gelu| >= 0.06; the clamp keeps the odd polynomial monotone so the
+// sigmoid saturates correctly for any |x|).  -log2(e) is folded into the coefficients:
+// 7 VALU + v_exp_f32 + v_rcp_f32.  The f32 mode uses libm erff instead.
+__device__ __forceinline__ float gelu_sigmoid_poly(float x) {
+    const float t = fminf(x * x, 50.0f);
+    float p = __builtin_fmaf(t, 1.0148166e-3f, -1.0677913e-1f);      // -log2e * (c2 t + c1)
+    p = __builtin_fmaf(t, p, -2.3011176f);                           // -log2e * c0
+    const float e = __builtin_amdgcn_exp2f(x * p);
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
 // ---- GEMM ------------------------------------------------------------------------------
 // C[m][n] = sum_k A[m][k] * W[n][k]  (+ epilogue); A: activations [M, lda], W: weights [N, ldw],
 // both K-contiguous in the compute dtype.
 enum GemmEpilogue {
-    EPI_BIAS_STORE = 0,    // out[m][n] = T(acc + bias[n])
+    EPI_BIAS_STORE = 0,    // out[m][n] = T((acc + bias[n]) * (gamma ? gamma[n] : 1))
     EPI_BIAS_GELU = 1,     // out[m][n] = T(gelu_erf(acc + bias[n]))
     EPI_BIAS_RESID = 2,    // resid[m][n] += (acc + bias[n]) * (gamma ? gamma[n] : 1)   (f32, in place)
     EPI_PATCH_EMBED = 3,   // tok[(m / P) * (P + 1) + 1 + m % P][n] = acc + bias[n] + pos[1 + m % P][n]
@@ -67,19 +81,34 @@ struct GemmArgs {
     const void* W; int ldw;
     int M, N, K;
     const float* bias;
-    const float* gamma;      // EPI_BIAS_RESID only (may be null)
+    const float* gamma;      // EPI_BIAS_STORE / EPI_BIAS_RESID: LayerScale (may be null)
     const float* pos;        // EPI_PATCH_EMBED: [P + 1, N]
     void* out; int ldo;      // T (STORE / GELU) or f32 (RESID / PATCH_EMBED)
     int P;                   // EPI_PATCH_EMBED: patches per image
+    int skew_ticks;          // gemm256 only: start-time spread across an XCD's workgroups (100 MHz ticks)
+    long long* trace;        // gemm256 diagnostics: per (workgroup, tile) 8 x 100-MHz time stamps, or null
+    int trace_tiles;         //   tiles recorded per workgroup
 };
+void set_gemm_trace(long long* buf, int tiles_per_wg);
 
 int launch_gemm(int dtype, int epilogue, const GemmArgs& a, hipStream_t stream);
+// impl: 0 = pick (256x256 persistent kernel when it supports the problem), 128 / 256 = force;
+// variant: gemm256 tuning knob: bits 4.. = workgroup start skew in percent of the estimated tile time
+int launch_gemm_impl(int dtype, int epilogue, const GemmArgs& a, int impl, int variant, hipStream_t stream);
+bool gemm256_supports(int dtype, int epilogue, const GemmArgs& a);
+int launch_gemm256(int dtype, int epilogue, const GemmArgs& a, int variant, hipStream_t stream);
 
 // ---- LayerNorm / attention / misc ---------------------------------------------------------
 // rows of f32 [rows, dim] (row stride `stride` elements) -> T [rows, dim] (dense)
 int launch_layernorm(int dtype, const float* x, long stride, int rows, int dim,
                      const float* gamma, const float* beta, float eps, void* out,
                      hipStream_t stream);
+// x[row] += delta[row] * ls (delta: delta_dtype rows, stride dstride elements, may be null; ls:
+// f32 [dim] LayerScale, may be null), then out[row] = LayerNorm(x[row]) in out_dtype.
+// Supported pairs: (T, T) and (T, f32).
+int launch_add_layernorm(int delta_dtype, int out_dtype, float* x, long stride, const void* delta,
+                         long dstride, const float* ls, int rows, int dim, const float* gamma, const float* beta,
+                         float eps, void* out, hipStream_t stream);
 // f32 out variant used for the final norm on CLS rows
 int launch_layernorm_f32out(const float* x, long stride, int rows, int dim, const float* gamma,
                             const float* beta, float eps, float* out, hipStream_t stream);

@@ -19,7 +19,7 @@ void set_error(const char* fmt, ...) {
 
 extern "C" {
 
-int ap_abi_version(void) { return 1; }
+int ap_abi_version(void) { return 2; }
 
 const char* ap_last_error(void) { return ap::g_error; }
 
@@ -47,6 +47,36 @@ int ap_preproc_u8hwc_to_patchrows(const uint8_t* src, int n, int h, int w, int c
                                   ap_stream_t stream) {
     return ap::preproc_patchrows(src, n, h, w, crop_top, crop_left, oh, ow, ps, mean, stdv, dst, ld,
                                  dst_dtype, (hipStream_t)stream);
+}
+
+int ap_gemm(int dtype, int epilogue, const void* A, int lda, const void* W, int ldw, int M, int N,
+            int K, const float* bias, const float* gamma, void* out, int ldo, int impl, int variant,
+            ap_stream_t stream) {
+    AP_REQUIRE(A && W && bias && out, "ap_gemm: null pointer");
+    AP_REQUIRE(epilogue == AP_EPI_BIAS || epilogue == AP_EPI_BIAS_GELU || epilogue == AP_EPI_BIAS_RESID,
+               "ap_gemm: unknown epilogue %d", epilogue);
+    AP_REQUIRE(dtype == AP_F16 || dtype == AP_BF16 || dtype == AP_F32, "ap_gemm: unknown dtype %d", dtype);
+    ap::GemmArgs g{};
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K;
+    g.bias = bias; g.gamma = gamma; g.out = out; g.ldo = ldo;
+    return ap::launch_gemm_impl(dtype, epilogue, g, impl, variant, (hipStream_t)stream);
+}
+
+int ap_gemm_trace(long long* device_buf, int tiles_per_workgroup) {
+    ap::set_gemm_trace(device_buf, device_buf ? tiles_per_workgroup : 0);
+    return AP_OK;
+}
+
+int ap_layernorm(int out_dtype, const float* x, long stride, int rows, int dim, const float* gamma,
+                 const float* beta, float eps, void* out, ap_stream_t stream) {
+    AP_REQUIRE(x && gamma && beta && out, "ap_layernorm: null pointer");
+    return ap::launch_layernorm(out_dtype, x, stride, rows, dim, gamma, beta, eps, out, (hipStream_t)stream);
+}
+
+int ap_attention(int dtype, const void* qkv, void* out, int n, int tokens, int heads, int head_dim,
+                 ap_stream_t stream) {
+    AP_REQUIRE(qkv && out, "ap_attention: null pointer");
+    return ap::launch_attention(dtype, qkv, out, n, tokens, heads, head_dim, (hipStream_t)stream);
 }
 
 }  // extern "C"

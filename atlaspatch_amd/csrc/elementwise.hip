@@ -2,7 +2,8 @@
 // CHW -> patch-row gather.  All are streaming kernels: 16-byte loads per lane, one wave
 // per row where a row reduction is needed (no LDS, no block barrier).
 //
-// Algorithmic bytes: LayerNorm reads 4*dim and writes sizeof(T)*dim per row.
+// Algorithmic bytes per row: LayerNorm reads 4*dim and writes sizeof(T)*dim; with the fused residual
+// add it also reads sizeof(T)*dim (delta) and writes 4*dim (the updated stream).
 #include "ap_common.h"
 
 namespace ap {
@@ -25,20 +26,108 @@ template <> __device__ __forceinline__ void store_vec4<bf16>(bf16* p, f32x4 v) {
     *(bf16x4*)p = h;
 }
 
-// One wave per row, whole row held in registers (dim <= 64 * 4 * kMaxVec).
+template <typename T> __device__ __forceinline__ f32x4 load_vec4(const T* p);
+template <> __device__ __forceinline__ f32x4 load_vec4<float>(const float* p) { return *(const f32x4*)p; }
+template <> __device__ __forceinline__ f32x4 load_vec4<f16>(const f16* p) {
+    const f16x4 h = *(const f16x4*)p;
+    return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+}
+template <> __device__ __forceinline__ f32x4 load_vec4<bf16>(const bf16* p) {
+    const bf16x4 h = *(const bf16x4*)p;
+    return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+}
+
+// ---- (residual add +) LayerNorm.  x: f32 rows (the residual stream); when `delta` is given the
+// row is first updated in place, x += delta * ls (the branch output a GEMM stored in TD, times the
+// optional LayerScale vector ls), then
+// normalised:  out = (x - mean) * rstd * gamma + beta  in TO.  Two-pass mean / variance on the
+// register-resident row, biased variance, eps inside the sqrt (nn.LayerNorm).
+//
+// Main kernel: 16 lanes per row, 4 rows per wave: reductions stay inside a DPP row (no LDS
+// permutes) and four rows in flight per wave hide the HBM latency.  dim = 64 * NV.
+
+
+__device__ __forceinline__ float row16_sum(float v) {
+    // xor-1, xor-2 (quad permutes), then mirror within 8 and within 16 lanes: all VALU + DPP
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    return v;
+}
+
+template <typename TD, typename TO, int NV>
+__global__ __launch_bounds__(256) void layernorm16_kernel(float* __restrict__ x, long stride,
+                                                          const TD* __restrict__ delta, long dstride,
+                                                          const float* __restrict__ ls, int rows, int dim,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps,
+                                                          TO* __restrict__ out) {
+    const int l16 = threadIdx.x & 15;
+    int row = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool live = row < rows;
+    if (!live) row = rows - 1;                       // keep all lanes in the DPP reductions
+    f32x4* src = (f32x4*)(x + (size_t)row * stride);
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = src[l16 + i * 16];
+    if (delta) {
+        const TD* dsrc = delta + (size_t)row * dstride;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            f32x4 d = load_vec4<TD>(dsrc + (l16 + i * 16) * 4);
+            if (ls) {
+                const f32x4 sc = ((const f32x4*)ls)[l16 + i * 16];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] *= sc[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i][e] += d[e];
+            if (live) src[l16 + i * 16] = v[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    const float mean = row16_sum(s) / (float)dim;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = v[i][e] - mean;
+            q += d * d;
+        }
+    const float rstd = 1.0f / sqrtf(row16_sum(q) / (float)dim + eps);
+    if (!live) return;
+    TO* dst = out + (size_t)row * dim;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = l16 + i * 16;
+        const f32x4 ga = ((const f32x4*)gamma)[idx];
+        const f32x4 be = ((const f32x4*)beta)[idx];
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * ga[e] + be[e];
+        store_vec4<TO>(dst + idx * 4, y);
+    }
+}
+
+// Generic kernel: one wave per row, whole row held in registers (dim <= 64 * 4 * kMaxVec).
 constexpr int kMaxVec = 8;
 
-template <typename T>
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long stride,
-                                                        int rows, int dim,
+template <typename TD, typename TO>
+__global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, long stride,
+                                                        const TD* __restrict__ delta, long dstride,
+                                                        const float* __restrict__ ls, int rows, int dim,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps,
-                                                        T* __restrict__ out) {
+                                                        TO* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int nvec = dim >> 2;
-    const f32x4* src = (const f32x4*)(x + (size_t)row * stride);
+    f32x4* src = (f32x4*)(x + (size_t)row * stride);
     f32x4 v[kMaxVec];
     float s = 0.f;
 #pragma unroll
@@ -46,6 +135,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         const int idx = lane + i * 64;
         if (idx < nvec) {
             v[i] = src[idx];
+            if (delta) {
+                f32x4 d = load_vec4<TD>(delta + (size_t)row * dstride + idx * 4);
+                if (ls) {
+                    const f32x4 sc = ((const f32x4*)ls)[idx];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) d[e] *= sc[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[i][e] += d[e];
+                src[idx] = v[i];
+            }
             s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
     }
@@ -63,7 +163,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         }
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)dim + eps);
-    T* dst = out + (size_t)row * dim;
+    TO* dst = out + (size_t)row * dim;
 #pragma unroll
     for (int i = 0; i < kMaxVec; ++i) {
         const int idx = lane + i * 64;
@@ -73,9 +173,26 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             f32x4 y;
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * ga[e] + be[e];
-            store_vec4<T>(dst + idx * 4, y);
+            store_vec4<TO>(dst + idx * 4, y);
         }
     }
+}
+
+template <typename TD, typename TO>
+int launch_ln_typed(float* x, long stride, const void* delta, long dstride, const float* ls, int rows, int dim,
+                    const float* gamma, const float* beta, float eps, void* out, hipStream_t stream) {
+    const TD* d = (const TD*)delta;
+    TO* o = (TO*)out;
+    if (dim == 768 || dim == 1024) {      // same kernel for any row count: results never depend on the batch size
+        dim3 g16((rows + 15) / 16), b16(256);
+        if (dim == 768) layernorm16_kernel<TD, TO, 12><<<g16, b16, 0, stream>>>(x, stride, d, dstride, ls, rows, dim, gamma, beta, eps, o);
+        else layernorm16_kernel<TD, TO, 16><<<g16, b16, 0, stream>>>(x, stride, d, dstride, ls, rows, dim, gamma, beta, eps, o);
+    } else {
+        dim3 grid((rows + 3) / 4), block(256);
+        layernorm_kernel<TD, TO><<<grid, block, 0, stream>>>(x, stride, d, dstride, ls, rows, dim, gamma, beta, eps, o);
+    }
+    AP_HIP_CHECK(hipGetLastError());
+    return AP_OK;
 }
 
 __global__ void cls_init_kernel(float* tok, const float* cls, const float* pos, int n, int tokens,
@@ -115,20 +232,28 @@ __global__ void chw_to_patchrows_kernel(const TI* __restrict__ x, int n, int S, 
 
 }  // namespace
 
+int launch_add_layernorm(int delta_dtype, int out_dtype, float* x, long stride, const void* delta,
+                         long dstride, const float* ls, int rows, int dim, const float* gamma, const float* beta,
+                         float eps, void* out, hipStream_t stream) {
+    AP_REQUIRE(dim % 4 == 0 && dim <= 64 * 4 * kMaxVec, "layernorm: unsupported dim %d", dim);
+    AP_REQUIRE(stride % 4 == 0 && (!delta || dstride % 4 == 0), "layernorm: row strides must be multiples of 4");
+    if (rows <= 0) return AP_OK;
+    if (!delta) delta_dtype = out_dtype;
+#define AP_LN(TD, TO) return launch_ln_typed<TD, TO>(x, stride, delta, dstride, ls, rows, dim, gamma, beta, eps, out, stream)
+    if (delta_dtype == AP_F16 && out_dtype == AP_F16) AP_LN(f16, f16);
+    if (delta_dtype == AP_BF16 && out_dtype == AP_BF16) AP_LN(bf16, bf16);
+    if (delta_dtype == AP_F32 && out_dtype == AP_F32) AP_LN(float, float);
+    if (delta_dtype == AP_F16 && out_dtype == AP_F32) AP_LN(f16, float);
+    if (delta_dtype == AP_BF16 && out_dtype == AP_F32) AP_LN(bf16, float);
+#undef AP_LN
+    set_error("layernorm: unsupported dtype pair (delta %d, out %d)", delta_dtype, out_dtype);
+    return AP_ERR_INVALID;
+}
+
 int launch_layernorm(int dtype, const float* x, long stride, int rows, int dim, const float* gamma,
                      const float* beta, float eps, void* out, hipStream_t stream) {
-    AP_REQUIRE(dim % 4 == 0 && dim <= 64 * 4 * kMaxVec, "layernorm: unsupported dim %d", dim);
-    AP_REQUIRE(stride % 4 == 0, "layernorm: row stride must be a multiple of 4");
-    if (rows <= 0) return AP_OK;
-    dim3 grid((rows + 3) / 4), block(256);
-    switch (dtype) {
-        case AP_F16: layernorm_kernel<f16><<<grid, block, 0, stream>>>(x, stride, rows, dim, gamma, beta, eps, (f16*)out); break;
-        case AP_BF16: layernorm_kernel<bf16><<<grid, block, 0, stream>>>(x, stride, rows, dim, gamma, beta, eps, (bf16*)out); break;
-        case AP_F32: layernorm_kernel<float><<<grid, block, 0, stream>>>(x, stride, rows, dim, gamma, beta, eps, (float*)out); break;
-        default: set_error("layernorm: unknown dtype %d", dtype); return AP_ERR_INVALID;
-    }
-    AP_HIP_CHECK(hipGetLastError());
-    return AP_OK;
+    return launch_add_layernorm(dtype, dtype, const_cast<float*>(x), stride, nullptr, 0, nullptr, rows, dim, gamma, beta,
+                                eps, out, stream);
 }
 
 int launch_layernorm_f32out(const float* x, long stride, int rows, int dim, const float* gamma,

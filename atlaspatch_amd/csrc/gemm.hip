@@ -182,10 +182,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[nt][mt][g4 * 4 + e] + bias[e];
                 if constexpr (EPI == EPI_BIAS_STORE) {
+                    if (g.gamma) {
+                        const f32x4 ga = *(const f32x4*)(g.gamma + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= ga[e];
+                    }
                     store4<T>((T*)g.out + orow + n, v);
                 } else if constexpr (EPI == EPI_BIAS_GELU) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                    for (int e = 0; e < 4; ++e) v[e] = sizeof(T) == 2 ? gelu_sigmoid_poly(v[e]) : gelu_erf(v[e]);
                     store4<T>((T*)g.out + orow + n, v);
                 } else if constexpr (EPI == EPI_BIAS_RESID) {
                     float* dst = (float*)g.out + orow + n;
@@ -227,8 +232,15 @@ int launch_typed(int epilogue, const GemmArgs& a, hipStream_t stream) {
 }  // namespace
 
 int launch_gemm(int dtype, int epilogue, const GemmArgs& a, hipStream_t stream) {
-    const int kt = kRowBytes / (int)dtype_size(dtype);
+    return launch_gemm_impl(dtype, epilogue, a, 0, 0, stream);
+}
+
+int launch_gemm_impl(int dtype, int epilogue, const GemmArgs& a, int impl, int variant, hipStream_t stream) {
     AP_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem %d x %d x %d", a.M, a.N, a.K);
+    AP_REQUIRE(impl == 0 || impl == 128 || impl == 256, "gemm: unknown implementation %d", impl);
+    if (impl == 256 || (impl == 0 && a.M >= 256 && gemm256_supports(dtype, epilogue, a)))
+        return launch_gemm256(dtype, epilogue, a, variant, stream);
+    const int kt = kRowBytes / (int)dtype_size(dtype);
     AP_REQUIRE(a.N % kTile == 0, "gemm: N=%d must be a multiple of %d", a.N, kTile);
     AP_REQUIRE(a.K % kt == 0, "gemm: K=%d must be a multiple of %d for this dtype", a.K, kt);
     AP_REQUIRE(a.lda >= a.K && a.ldw >= a.K, "gemm: leading dimensions smaller than K");

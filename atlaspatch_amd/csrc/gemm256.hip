@@ -1,0 +1,453 @@
+// Persistent 256x256-tile MFMA GEMM for the ViT encoder's large linears (f16 / bf16 operands):
+//     C[m][n] = sum_k Act[m][k] * W[n][k]   (+ fused epilogue),  both operands K-contiguous.
+//
+// One 512-thread workgroup per CU (grid = min(#CU, #tiles)) walks its list of 256(m) x 256(n)
+// output tiles; the K loop of all its tiles is ONE continuous stream of 64-element K-tiles that
+// never drains: while a tile's epilogue runs, the LDS-DMA for the next tile's first K-tiles is
+// already in flight.
+//
+//  * waves: 8 = 2 (wr, along m) x 4 (wc, along n); a wave owns 128 m x 64 n = 4 x 2 MFMA tiles of
+//    32x32 (v_mfma_f32_32x32x16_{f16,bf16}; 128 accumulator registers).  The MFMA "A" operand is the
+//    weight fragment so a lane ends up with 4 consecutive n of one m.
+//  * LDS (160 KiB): two K-tile buffers of 64 KiB + 8 x 4 KiB per-wave epilogue scratch.  A buffer
+//    holds four 16-KiB staging UNITS of 128 rows x 128 B, cut along the waves' output QUADRANTS
+//    rather than along the tile:  X0 / X1 = the first / second 64 m-rows of both wr groups,
+//    Y0 / Y1 = the first / second 32 n-rows of all four wc groups.  A K-tile is consumed in four
+//    phases  (X0,Y0) (X0,Y1) (X1,Y1) (X1,Y0)  of 8 MFMAs per wave, so every unit has ONE reading
+//    phase (Y0's fragment stays in registers for phase 3).  That makes a unit free two phases
+//    after it was read and lets a plain double buffer run ~4 phases (a whole K-tile) of prefetch:
+//        phase 0: read X0,Y0   stage Y1 of K-tile v+1      phase 2: read X1   stage X0 of v+2
+//        phase 1: read Y1      stage X1 of K-tile v+1      phase 3: -         stage Y0 of v+2
+//    A phase is  [ds_read fragments | s_waitcnt vmcnt(6)] s_barrier [8 MFMAs with the phase's unit
+//    staged between them: 2 x global_load_lds_dwordx4 per lane].  vmcnt(6) = "everything staged four
+//    phases ago has landed"; data is read no earlier than one phase after the wait that retires it
+//    and a unit is restaged no earlier than one barrier after its reading phase (raw s_barrier,
+//    never vmcnt(0) in the loop).  vmcnt retires in order and also counts the epilogue's global
+//    stores, so the first K-tile after an epilogue skips the counted wait (the epilogue drained
+//    the stream) and the stores drain under the next tile's MFMAs.
+//  * the LDS-DMA is issued from inline asm (SGPR base + 32-bit lane offset, M0 = LDS address): the
+//    compiler treats the builtin as a FLAT access and then turns every later LDS / VMEM wait into a
+//    full drain; hidden from it, the fragment reads get counted lgkmcnt(N) waits, so the first
+//    MFMAs of a phase start as soon as their own operands have arrived.
+//  * the LDS-DMA writes lane-linear, so the bank swizzle (16-B chunk ^= (row >> 1) & 7, conflict
+//    free for ds_read_b128's lane groups) is applied to the per-lane SOURCE address and again on
+//    the fragment read.
+//  * epilogue: bias (+GELU | *LayerScale) in registers, transposed through the wave's private LDS
+//    scratch (XOR-swizzled) so that global stores / the f32 residual read-modify-write are whole
+//    128-byte rows, 16 B per lane.
+//  * XCD-aware tile order: block b runs on XCD b % 8; each XCD owns a contiguous range of tile ids
+//    (n fastest), its 32 workgroups take consecutive ids, so concurrently running tiles share
+//    activation panels and weight panels in that XCD's L2.
+//
+// Roofline: MFMA (2*M*N*K flop per launch).
+#include "ap_common.h"
+
+namespace ap {
+namespace {
+
+constexpr int kBM = 256, kBN = 256;
+constexpr int kRowBytes = 128;                    // bytes of K per tile row (64 f16 / bf16)
+constexpr int kUnitBytes = 128 * kRowBytes;       // 16 KiB
+constexpr int kBufBytes = 4 * kUnitBytes;         // X0 X1 Y0 Y1
+constexpr int kScratchOff = 2 * kBufBytes;        // 128 KiB
+constexpr int kLdsBytes = kScratchOff + 8 * 4096; // 160 KiB
+enum { U_X0 = 0, U_X1 = 1, U_Y0 = 2, U_Y1 = 3 };
+
+template <typename T> struct Mma;
+template <> struct Mma<f16> {
+    using Frag = f16x8;
+    static __device__ __forceinline__ f32x16 run(Frag a, Frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mma<bf16> {
+    using Frag = bf16x8;
+    static __device__ __forceinline__ f32x16 run(Frag a, Frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+
+template <typename T> __device__ __forceinline__ u32x2 pack4(f32x4 v);
+template <> __device__ __forceinline__ u32x2 pack4<f16>(f32x4 v) {
+    f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+    return __builtin_bit_cast(u32x2, h);
+}
+template <> __device__ __forceinline__ u32x2 pack4<bf16>(f32x4 v) {
+    bf16x4 h = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+    return __builtin_bit_cast(u32x2, h);
+}
+
+// Two LDS-DMA loads of one staging unit (16 B per lane each): LDS rows [0, 64) and [64, 128) of the
+// unit slice owned by this wave.  base: wave-uniform global address, off0 / off1: per-lane byte
+// offsets, lds_dst: wave-uniform LDS byte address.  M0 is saved and restored (compiler-reserved).
+__device__ __forceinline__ void dma_unit(const char* base, uint32_t off0, uint32_t off1, uint32_t lds_dst) {
+    uint32_t keep;
+    const uint32_t lds_dst1 = lds_dst + 64 * kRowBytes;
+    asm volatile(              // only s_mov / s_nop besides the loads: SCC stays untouched
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %5\n\t"
+        "s_mov_b32 m0, %4\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, %5\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(off0), "v"(off1), "s"(lds_dst), "s"(lds_dst1), "s"(base)
+        : "memory");
+}
+
+#define AP_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+struct TileWalk {          // this workgroup's tile list: ids first, first + stride, ... (< end)
+    int first, stride, count, tiles_n;
+};
+
+// Position of one staging stream (which tile / K-tile its next units come from).
+struct Cursor {
+    int ti, kt;
+    const char* abase;     // Act + m0 * lda * 2   (wave-uniform)
+    const char* wbase;     // W + n0 * ldw * 2
+    uint32_t xo[2], yo[2]; // per-lane byte offsets of the two 64-row rounds of this stream's X / Y unit
+};
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) char smem[kLdsBytes];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int hi = lane >> 5, l31 = lane & 31;
+    using Frag = typename Mma<T>::Frag;
+
+    // ---- tile list (XCD-aware, see header)
+    TileWalk tw;
+    {
+        const int tiles_m = (g.M + kBM - 1) / kBM;
+        tw.tiles_n = g.N / kBN;
+        const int total = tiles_m * tw.tiles_n;
+        const int nblk = gridDim.x, b = blockIdx.x;
+        const int nx = nblk < 8 ? nblk : 8;                    // XCDs that received workgroups
+        const int xcd = b % nx, j = b / nx;
+        const int nwx = (nblk - xcd + nx - 1) / nx;            // workgroups on this XCD
+        const int t0 = (int)(((long)total * xcd) / nx), t1 = (int)(((long)total * (xcd + 1)) / nx);
+        tw.first = t0 + j;
+        tw.stride = nwx;
+        tw.count = tw.first < t1 ? (t1 - tw.first + nwx - 1) / nwx : 0;
+    }
+    if (tw.count == 0) return;
+    const int nk = g.K / 64;
+    // Start-time skew: equal tiles keep every CU in step, so all epilogues (the HBM write bursts)
+    // would coincide.  Workgroup j of an XCD starts j / nwx of a tile period late; the early ones are
+    // the ones that own one tile more.
+    if (g.skew_ticks > 0) {
+        const int nx = gridDim.x < 8 ? gridDim.x : 8;
+        const long long until = (long long)__builtin_amdgcn_s_memrealtime() +
+                                (long long)g.skew_ticks * (int)(blockIdx.x / nx) / tw.stride;
+        while ((long long)__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(16);
+    }
+
+    // ---- staging plan.  Round j of a unit covers unit rows j*64 + wave*8 + (lane >> 3); the lane's
+    //      16-byte source chunk is swizzled by the LDS row it lands on.
+    const int srow = wave * 8 + (lane >> 3);                                 // unit row within the round
+    const uint32_t schunk = (uint32_t)(((lane & 7) ^ ((srow >> 1) & 7)) << 4);
+    auto set_tile = [&](Cursor& c, int q, int ti) {
+        c.ti = ti;
+        const int id = tw.first + ti * tw.stride;
+        const int m0 = (id / tw.tiles_n) * kBM, n0 = (id % tw.tiles_n) * kBN;
+        c.abase = (const char*)g.A + (size_t)m0 * g.lda * 2;
+        c.wbase = (const char*)g.W + (size_t)n0 * g.ldw * 2;
+        const int mlast = g.M - 1 - m0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int xr_ = j * 128 + q * 64 + srow;                                // tile m-row
+            xr_ = xr_ < mlast ? xr_ : mlast;
+            const int yr_ = (j * 2 + (wave >> 2)) * 64 + q * 32 + (wave & 3) * 8 + (lane >> 3);   // tile n-row
+            c.xo[j] = (uint32_t)xr_ * (uint32_t)(g.lda * 2) + schunk;
+            c.yo[j] = (uint32_t)yr_ * (uint32_t)(g.ldw * 2) + schunk;
+        }
+    };
+    auto advance = [&](Cursor& c, int q) {
+        if (++c.kt == nk) {
+            if (c.ti + 1 < tw.count) { c.kt = 0; set_tile(c, q, c.ti + 1); }
+            else c.kt = nk - 1;                       // past the end: re-stage the last K-tile (harmless)
+        }
+    };
+    const uint32_t lds_wave = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + wave * 1024;
+    auto stage = [&](const Cursor& c, bool is_x, int buf, int unit) {
+        const char* base = (is_x ? c.abase : c.wbase) + (size_t)c.kt * kRowBytes;
+#ifdef AP_DMA_BUILTIN
+        char* dst = smem + buf * kBufBytes + unit * kUnitBytes + wave * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (is_x ? c.xo[0] : c.yo[0])),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (is_x ? c.xo[1] : c.yo[1])),
+                                         (__attribute__((address_space(3))) void*)(dst + 8192), 16, 0, 0);
+#else
+        dma_unit(base, is_x ? c.xo[0] : c.yo[0], is_x ? c.xo[1] : c.yo[1],
+                 lds_wave + buf * kBufBytes + unit * kUnitBytes);
+#endif
+    };
+
+    Cursor ca, cb;            // ca: X0 / Y0 stream (two K-tiles ahead), cb: Y1 / X1 stream (one ahead)
+    ca.kt = cb.kt = 0;
+    set_tile(ca, 0, 0);
+    set_tile(cb, 1, 0);
+
+    // ---- fragment read addresses (byte offsets into a buffer)
+    const int xr = (l31 >> 1) & 7;
+    int pa[4], pb[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int co = ((kk * 2 + hi) ^ xr) << 4;
+        pa[kk] = (wr * 64 + l31) * kRowBytes + co;          // + unit * 16K + rb * 32 rows
+        pb[kk] = (wc * 32 + l31) * kRowBytes + co;
+    }
+
+    f32x16 acc[2][4];         // [n block of 32][m block of 32]
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    };
+    zero_acc();
+
+    Frag fa[2][4], fb0[4], fb1[4];
+
+    // ---- prologue: K-tile 0 complete, X0 / Y0 of K-tile 1
+    stage(ca, true, 0, U_X0); stage(ca, false, 0, U_Y0); advance(ca, 0);
+    stage(cb, false, 0, U_Y1); stage(cb, true, 0, U_X1); advance(cb, 1);
+    stage(ca, true, 1, U_X0); stage(ca, false, 1, U_Y0); advance(ca, 0);
+    AP_VMCNT(8);              // X0 / Y0 of K-tile 0 have landed (phase 0 reads them)
+    __builtin_amdgcn_s_barrier();
+
+    // Phase boundary.  The counted wait retires what was staged four phases ago (allowed in flight:
+    // the 3 x 2 loads of the last three phases); the barrier publishes it and orders this phase's
+    // DMA (issued after it) behind every wave's fragment reads of the unit it overwrites.  The
+    // fragment reads written before it may be hoisted by the compiler into the previous phase's
+    // MFMA block (everything they read was published by the previous barrier); the wait may not.
+#define AP_PHASE_SYNC()                             \
+    __builtin_amdgcn_sched_barrier(0);              \
+    if (wait) AP_VMCNT(6);                          \
+    __builtin_amdgcn_sched_barrier(0);              \
+    __builtin_amdgcn_s_barrier();                   \
+    __builtin_amdgcn_sched_barrier(0)
+#define AP_MMA(ACC, B, A) ACC = Mma<T>::run(B, A, ACC)
+#ifdef AP_NO_READ_HOIST
+#define AP_NOHOIST() __builtin_amdgcn_sched_barrier(0)
+#else
+#define AP_NOHOIST()
+#endif
+
+    // wait = false only for the first K-tile after an epilogue: everything staged before the epilogue
+    // was drained there (vmcnt(0)), so its four phases need no counted wait and the epilogue's own
+    // stores keep draining under them.
+    auto ktile = [&](auto bufc, const bool wait) {
+        constexpr int BUF = decltype(bufc)::value;
+        const char* buf = smem + BUF * kBufBytes;
+        // ---------------- phase 0: (X0, Y0), stage Y1 of the next K-tile
+        AP_NOHOIST();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            fb0[kk] = *(const Frag*)(buf + U_Y0 * kUnitBytes + pb[kk]);
+            fa[0][kk] = *(const Frag*)(buf + U_X0 * kUnitBytes + pa[kk]);
+            fa[1][kk] = *(const Frag*)(buf + U_X0 * kUnitBytes + 32 * kRowBytes + pa[kk]);
+        }
+        AP_PHASE_SYNC();
+        AP_MMA(acc[0][0], fb0[0], fa[0][0]); AP_MMA(acc[0][1], fb0[0], fa[1][0]);
+        stage(cb, false, BUF ^ 1, U_Y1);
+        AP_MMA(acc[0][0], fb0[1], fa[0][1]); AP_MMA(acc[0][1], fb0[1], fa[1][1]);
+        AP_MMA(acc[0][0], fb0[2], fa[0][2]); AP_MMA(acc[0][1], fb0[2], fa[1][2]);
+        AP_MMA(acc[0][0], fb0[3], fa[0][3]); AP_MMA(acc[0][1], fb0[3], fa[1][3]);
+        // ---------------- phase 1: (X0, Y1), stage X1 of the next K-tile
+        AP_NOHOIST();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) fb1[kk] = *(const Frag*)(buf + U_Y1 * kUnitBytes + pb[kk]);
+        AP_PHASE_SYNC();
+        AP_MMA(acc[1][0], fb1[0], fa[0][0]); AP_MMA(acc[1][1], fb1[0], fa[1][0]);
+        stage(cb, true, BUF ^ 1, U_X1);
+        advance(cb, 1);
+        AP_MMA(acc[1][0], fb1[1], fa[0][1]); AP_MMA(acc[1][1], fb1[1], fa[1][1]);
+        AP_MMA(acc[1][0], fb1[2], fa[0][2]); AP_MMA(acc[1][1], fb1[2], fa[1][2]);
+        AP_MMA(acc[1][0], fb1[3], fa[0][3]); AP_MMA(acc[1][1], fb1[3], fa[1][3]);
+        // ---------------- phase 2: (X1, Y1), stage X0 of the K-tile after next
+        AP_NOHOIST();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            fa[0][kk] = *(const Frag*)(buf + U_X1 * kUnitBytes + pa[kk]);
+            fa[1][kk] = *(const Frag*)(buf + U_X1 * kUnitBytes + 32 * kRowBytes + pa[kk]);
+        }
+        AP_PHASE_SYNC();
+        AP_MMA(acc[1][2], fb1[0], fa[0][0]); AP_MMA(acc[1][3], fb1[0], fa[1][0]);
+        stage(ca, true, BUF, U_X0);
+        AP_MMA(acc[1][2], fb1[1], fa[0][1]); AP_MMA(acc[1][3], fb1[1], fa[1][1]);
+        AP_MMA(acc[1][2], fb1[2], fa[0][2]); AP_MMA(acc[1][3], fb1[2], fa[1][2]);
+        AP_MMA(acc[1][2], fb1[3], fa[0][3]); AP_MMA(acc[1][3], fb1[3], fa[1][3]);
+        // ---------------- phase 3: (X1, Y0)   (Y0 fragment still in registers), stage Y0 likewise
+        AP_PHASE_SYNC();
+        AP_MMA(acc[0][2], fb0[0], fa[0][0]); AP_MMA(acc[0][3], fb0[0], fa[1][0]);
+        stage(ca, false, BUF, U_Y0);
+        advance(ca, 0);
+        AP_MMA(acc[0][2], fb0[1], fa[0][1]); AP_MMA(acc[0][3], fb0[1], fa[1][1]);
+        AP_MMA(acc[0][2], fb0[2], fa[0][2]); AP_MMA(acc[0][3], fb0[2], fa[1][2]);
+        AP_MMA(acc[0][2], fb0[3], fa[0][3]); AP_MMA(acc[0][3], fb0[3], fa[1][3]);
+    };
+
+    char* scr = smem + kScratchOff + wave * 4096;
+    auto stamp = [&](int ti, int k) {
+        if (g.trace && ti < g.trace_tiles && threadIdx.x == 0)
+            g.trace[((size_t)blockIdx.x * g.trace_tiles + ti) * 8 + k] = (long long)__builtin_amdgcn_s_memrealtime();
+    };
+    for (int ti = 0; ti < tw.count; ++ti) {
+        stamp(ti, 0);
+        for (int kt = 0; kt < nk; kt += 2) {
+            ktile(std::integral_constant<int, 0>{}, ti == 0 || kt != 0);
+            ktile(std::integral_constant<int, 1>{}, true);
+        }
+        // ---------------- epilogue
+        stamp(ti, 1);
+        AP_VMCNT(0);          // the stream staged so far (next tile's first K-tiles) has landed
+        stamp(ti, 2);
+        // lane-derived epilogue constants are recomputed per tile from an opaque copy of the lane id:
+        // hoisted out of the tile loop they would live (spilled) across the whole K loop
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int hi = lane_e >> 5, l31 = lane_e & 31;
+        const int id = tw.first + ti * tw.stride;
+        const int m0 = (id / tw.tiles_n) * kBM + wr * 128, n0 = (id % tw.tiles_n) * kBN + wc * 64;
+        f32x4 bias[2][4], gam[2][4];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int n = n0 + nb * 32 + g4 * 8 + hi * 4;
+                bias[nb][g4] = *(const f32x4*)(g.bias + n);
+                if constexpr (EPI != EPI_BIAS_GELU) {
+                    if (g.gamma) gam[nb][g4] = *(const f32x4*)(g.gamma + n);
+                    else gam[nb][g4] = f32x4{1.f, 1.f, 1.f, 1.f};
+                }
+            }
+        if (g.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(ti, 3); }
+        const int rrow = lane_e >> 3, rc = lane_e & 7;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            if constexpr (EPI == EPI_BIAS_RESID) {
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            v[e] = (acc[nb][mb][g4 * 4 + e] + bias[nb][g4][e]) * gam[nb][g4][e];
+                        *(f32x4*)(scr + l31 * 128 + (((g4 * 2 + hi) ^ (l31 & 7)) << 4)) = v;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = i * 8 + rrow;
+                        const f32x4 v = *(const f32x4*)(scr + row * 128 + ((rc ^ (row & 7)) << 4));
+                        const int m = m0 + mb * 32 + row;
+                        if (m < g.M) {
+                            float* dst = (float*)g.out + (size_t)m * g.ldo + n0 + nb * 32 + rc * 4;
+                            f32x4 r = *(const f32x4*)dst;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) r[e] += v[e];
+                            *(f32x4*)dst = r;
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = acc[nb][mb][g4 * 4 + e] + bias[nb][g4][e];
+                            if constexpr (EPI == EPI_BIAS_GELU) v[e] = gelu_sigmoid_poly(v[e]);
+                            else v[e] *= gam[nb][g4][e];
+                        }
+                        *(u32x2*)(scr + l31 * 128 + (((nb * 4 + g4) ^ (l31 & 7)) << 4) + hi * 8) = pack4<T>(v);
+                    }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = i * 8 + rrow;
+                    const u32x4 v = *(const u32x4*)(scr + row * 128 + ((rc ^ (row & 7)) << 4));
+                    const int m = m0 + mb * 32 + row;
+                    if (m < g.M) *(u32x4*)((T*)g.out + (size_t)m * g.ldo + n0 + rc * 8) = v;
+                }
+            }
+        }
+        stamp(ti, 4);
+        zero_acc();
+    }
+    AP_VMCNT(0);
+#undef AP_PHASE_SYNC
+#undef AP_MMA
+}
+
+template <typename T, int EPI>
+int launch_epi(const GemmArgs& a, int num_cu, int variant, hipStream_t stream) {
+    const int tiles = ((a.M + kBM - 1) / kBM) * (a.N / kBN);
+    dim3 grid(tiles < num_cu ? tiles : num_cu), block(512);
+    (void)variant;
+    gemm256_kernel<T, EPI><<<grid, block, 0, stream>>>(a);
+    AP_HIP_CHECK(hipGetLastError());
+    return AP_OK;
+}
+
+template <typename T>
+int launch_typed(int epilogue, const GemmArgs& a, int num_cu, int variant, hipStream_t stream) {
+    switch (epilogue) {
+        case EPI_BIAS_STORE: return launch_epi<T, EPI_BIAS_STORE>(a, num_cu, variant, stream);
+        case EPI_BIAS_GELU: return launch_epi<T, EPI_BIAS_GELU>(a, num_cu, variant, stream);
+        case EPI_BIAS_RESID: return launch_epi<T, EPI_BIAS_RESID>(a, num_cu, variant, stream);
+    }
+    set_error("gemm256: unsupported epilogue %d", epilogue);
+    return AP_ERR_INVALID;
+}
+
+}  // namespace
+
+static long long* g_trace = nullptr;
+static int g_trace_tiles = 0;
+void set_gemm_trace(long long* buf, int tiles_per_wg) { g_trace = buf; g_trace_tiles = tiles_per_wg; }
+
+bool gemm256_supports(int dtype, int epilogue, const GemmArgs& a) {
+    if (dtype != AP_F16 && dtype != AP_BF16) return false;
+    if (epilogue != EPI_BIAS_STORE && epilogue != EPI_BIAS_GELU && epilogue != EPI_BIAS_RESID) return false;
+    if (a.N % kBN != 0 || a.K % 128 != 0 || a.K < 128) return false;
+    if (((size_t)a.lda * 2) % 16 != 0 || ((size_t)a.ldw * 2) % 16 != 0) return false;
+    if ((size_t)255 * a.lda * 2 + 128 > 0xffffffffull || (size_t)255 * a.ldw * 2 + 128 > 0xffffffffull) return false;
+    // 16-byte row stores: output row stride and base must keep 16-byte alignment
+    const size_t oes = epilogue == EPI_BIAS_RESID ? 4 : 2;
+    if (((size_t)a.ldo * oes) % 16 != 0 || ((uintptr_t)a.out & 15) != 0) return false;
+    return true;
+}
+
+int launch_gemm256(int dtype, int epilogue, const GemmArgs& a, int variant, hipStream_t stream) {
+    static int num_cu = 0;
+    if (num_cu == 0) {
+        int dev = 0;
+        AP_HIP_CHECK(hipGetDevice(&dev));
+        hipDeviceProp_t prop;
+        AP_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    AP_REQUIRE(gemm256_supports(dtype, epilogue, a), "gemm256: unsupported problem");
+    GemmArgs b = a;
+    b.trace = g_trace; b.trace_tiles = g_trace_tiles;
+    const int skew_pct = variant >> 4;
+    const int tiles = ((a.M + kBM - 1) / kBM) * (a.N / kBN);
+    // estimated tile period in 10-ns ticks: ~1.65 us per 64-deep K-tile + epilogue
+    b.skew_ticks = tiles > num_cu ? (int)((long long)((a.K / 64) * 165 + 400) * skew_pct / 100) : 0;
+    variant &= 15;
+    return dtype == AP_F16 ? launch_typed<f16>(epilogue, b, num_cu, variant, stream)
+                           : launch_typed<bf16>(epilogue, b, num_cu, variant, stream);
+}
+
+}  // namespace ap

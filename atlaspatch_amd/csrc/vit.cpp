@@ -7,6 +7,7 @@
 //   xn    T   [M, D]      LayerNorm output (GEMM A operand)
 //   qkv   T   [M, 3D]     packed q | k | v
 //   att   T   [M, D]      attention output
+//   delta T   [M, D]      branch output (proj / fc2) waiting to be added to tok by the next LayerNorm
 //   hid   T   [M, mlp]    GELU(fc1) ; the patch-row matrix [n*P, Kpe] aliases it
 // Weights are converted once to T, K-contiguous ([out, in], exactly the checkpoint layout).
 #include <cstring>
@@ -84,7 +85,7 @@ const Param* find(const ap_vit* m, const std::string& name) {
 }
 
 struct Workspace {
-    float* tok; void* xn; void* qkv; void* att; void* hid;
+    float* tok; void* xn; void* qkv; void* att; void* hid; void* delta;
     size_t total;
 };
 
@@ -98,12 +99,13 @@ Workspace carve(const ap_vit* m, int n, char* base) {
     const size_t o_xn = take(M * D * es);
     const size_t o_qkv = take(M * 3 * D * es);
     const size_t o_att = take(M * D * es);
+    const size_t o_delta = take(M * D * es);
     size_t hid_bytes = M * (size_t)m->cfg.mlp_dim * es;
     const size_t pe_bytes = (size_t)n * m->patches * m->kpe * es;
     if (pe_bytes > hid_bytes) hid_bytes = pe_bytes;
     const size_t o_hid = take(hid_bytes);
     w.tok = (float*)(base + o_tok); w.xn = base + o_xn; w.qkv = base + o_qkv;
-    w.att = base + o_att; w.hid = base + o_hid; w.total = off;
+    w.att = base + o_att; w.hid = base + o_hid; w.delta = base + o_delta; w.total = off;
     return w;
 }
 
@@ -126,13 +128,18 @@ int run_blocks(ap_vit* m, int n, const Workspace& w, float* out, hipStream_t str
                                       (const float*)find(m, "pos_embed")->dev, n, m->tokens, D,
                                       stream)) != AP_OK) return rc;
     }
+    // Residual stream: tok (f32) is only ever touched by the add+LayerNorm kernel.  A branch GEMM
+    // (proj, fc2) stores its output delta = acc + bias in T; the NEXT LayerNorm launch first folds
+    // it into the stream (tok += delta * layer_scale, in f32) and then normalises.
+    const void* pending = nullptr;       // branch output not yet added to tok
+    const float* pending_ls = nullptr;   // ... and its LayerScale vector (applied in f32 by the add)
     for (int i = 0; i < c.depth; ++i) {
         const std::string b = "blocks." + std::to_string(i) + ".";
         auto vec = [&](const char* s) { return (const float*)find(m, b + s)->dev; };
         auto mat = [&](const char* s) { return find(m, b + s); };
         { ScopedTimer t(m, AP_PROF_LAYERNORM, stream);
-          if ((rc = ap::launch_layernorm(dt, w.tok, D, M, D, vec("ln1.weight"), vec("ln1.bias"),
-                                         c.ln_eps, w.xn, stream)) != AP_OK) return rc; }
+          if ((rc = ap::launch_add_layernorm(dt, dt, w.tok, D, pending, D, pending_ls, M, D, vec("ln1.weight"),
+                                             vec("ln1.bias"), c.ln_eps, w.xn, stream)) != AP_OK) return rc; }
         {
             ap::GemmArgs g{};
             g.A = w.xn; g.lda = D; g.W = mat("qkv.weight")->dev; g.ldw = mat("qkv.weight")->ld;
@@ -147,13 +154,14 @@ int run_blocks(ap_vit* m, int n, const Workspace& w, float* out, hipStream_t str
             ap::GemmArgs g{};
             g.A = w.att; g.lda = D; g.W = mat("proj.weight")->dev; g.ldw = mat("proj.weight")->ld;
             g.M = M; g.N = D; g.K = D; g.bias = vec("proj.bias");
-            g.gamma = c.layer_scale ? vec("ls1") : nullptr; g.out = w.tok; g.ldo = D;
+            g.out = w.delta; g.ldo = D;
             ScopedTimer t(m, AP_PROF_GEMM_PROJ, stream);
-            if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_RESID, g, stream)) != AP_OK) return rc;
+            if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_STORE, g, stream)) != AP_OK) return rc;
         }
         { ScopedTimer t(m, AP_PROF_LAYERNORM, stream);
-          if ((rc = ap::launch_layernorm(dt, w.tok, D, M, D, vec("ln2.weight"), vec("ln2.bias"),
-                                         c.ln_eps, w.xn, stream)) != AP_OK) return rc; }
+          if ((rc = ap::launch_add_layernorm(dt, dt, w.tok, D, w.delta, D, c.layer_scale ? vec("ls1") : nullptr, M, D,
+                                             vec("ln2.weight"),
+                                             vec("ln2.bias"), c.ln_eps, w.xn, stream)) != AP_OK) return rc; }
         {
             ap::GemmArgs g{};
             g.A = w.xn; g.lda = D; g.W = mat("fc1.weight")->dev; g.ldw = mat("fc1.weight")->ld;
@@ -165,15 +173,17 @@ int run_blocks(ap_vit* m, int n, const Workspace& w, float* out, hipStream_t str
             ap::GemmArgs g{};
             g.A = w.hid; g.lda = c.mlp_dim; g.W = mat("fc2.weight")->dev; g.ldw = mat("fc2.weight")->ld;
             g.M = M; g.N = D; g.K = c.mlp_dim; g.bias = vec("fc2.bias");
-            g.gamma = c.layer_scale ? vec("ls2") : nullptr; g.out = w.tok; g.ldo = D;
+            g.out = w.delta; g.ldo = D;
             ScopedTimer t(m, AP_PROF_GEMM_FC2, stream);
-            if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_RESID, g, stream)) != AP_OK) return rc;
+            if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_STORE, g, stream)) != AP_OK) return rc;
         }
+        pending = w.delta;
+        pending_ls = c.layer_scale ? vec("ls2") : nullptr;
     }
-    // final LayerNorm on the CLS row of every image -> out f32 [n, D]
-    return ap::launch_layernorm(AP_F32, w.tok, (long)m->tokens * D, n, D,
-                                (const float*)find(m, "norm.weight")->dev,
-                                (const float*)find(m, "norm.bias")->dev, c.ln_eps, out, stream);
+    // final LayerNorm on the CLS row of every image (last fc2 output folded in first) -> out f32 [n, D]
+    return ap::launch_add_layernorm(dt, AP_F32, w.tok, (long)m->tokens * D, pending, (long)m->tokens * D, pending_ls, n, D,
+                                    (const float*)find(m, "norm.weight")->dev,
+                                    (const float*)find(m, "norm.bias")->dev, c.ln_eps, out, stream);
 }
 
 int check_forward_args(const ap_vit* m, int n, const void* in, const float* out, const void* ws,

@@ -127,6 +127,43 @@ int ap_vit_forward_u8(ap_vit* m, const uint8_t* patches, int n, int h, int w,
 int ap_vit_forward_chw(ap_vit* m, const void* x, int x_dtype, int n,
                        float* out, void* workspace, size_t workspace_bytes, ap_stream_t stream);
 
+/* ---- single operators of the encoder (the same kernels ap_vit_forward_* chains) ------
+ * The operator-level seam a plugin `forward_fn` (models/patch/custom.py:31-43) can bind when it
+ * builds its own block structure, and what the per-kernel parity tests call.  All pointers are
+ * device pointers; dtype is the MFMA operand type (AP_F16 / AP_BF16 / AP_F32).
+ *
+ * ap_gemm:  C[m][n] = sum_k A[m][k] * W[n][k] + bias[n], then the epilogue:
+ *   AP_EPI_BIAS        out T   [M, ldo] = C                       (nn.Linear)
+ *   AP_EPI_BIAS_GELU   out T   [M, ldo] = gelu_erf(C)             (Linear + nn.GELU())
+ *   AP_EPI_BIAS_RESID  out f32 [M, ldo] += C * (gamma ? gamma[n] : 1)   (residual add, LayerScale)
+ * A: T [M, lda], W: T [N, ldw] (both K-contiguous, the checkpoint's [out, in] layout), bias /
+ * gamma: f32 [N].  N % 128 == 0 and K % (128 / sizeof(T)) == 0.  impl: 0 = pick, 128 = the
+ * 128x128-tile kernel, 256 = the persistent 256x256-tile kernel (f16 / bf16, N % 256 == 0,
+ * K % 128 == 0); variant selects a schedule variant of the 256 kernel (0 = default). */
+#define AP_EPI_BIAS 0
+#define AP_EPI_BIAS_GELU 1
+#define AP_EPI_BIAS_RESID 2
+int ap_gemm(int dtype, int epilogue, const void* A, int lda, const void* W, int ldw,
+            int M, int N, int K, const float* bias, const float* gamma, void* out, int ldo,
+            int impl, int variant, ap_stream_t stream);
+
+/* Diagnostics for the persistent kernel: when device_buf is non-null every later impl-256 launch
+ * records, per (workgroup, tile) with tile < tiles_per_workgroup, eight int64 stamps of the
+ * 100-MHz wall clock: [0] tile start, [1] K loop done, [2] staged stream drained, [3] bias loaded,
+ * [4] epilogue done.  device_buf: int64 [grid, tiles_per_workgroup, 8].  Pass NULL to switch off. */
+int ap_gemm_trace(long long* device_buf, int tiles_per_workgroup);
+
+/* LayerNorm over the last dimension of f32 rows (row stride `stride` elements) -> dense
+ * out [rows, dim] of out_dtype (nn.LayerNorm, eps inside the sqrt, biased variance). */
+int ap_layernorm(int out_dtype, const float* x, long stride, int rows, int dim,
+                 const float* gamma, const float* beta, float eps, void* out, ap_stream_t stream);
+
+/* Multi-head self-attention on packed projections: qkv T [n * tokens, 3 * heads * head_dim]
+ * (q | k | v), out T [n * tokens, heads * head_dim]; softmax(q k^T / sqrt(head_dim)) v in f32
+ * (F.scaled_dot_product_attention without mask / dropout).  head_dim must be 64. */
+int ap_attention(int dtype, const void* qkv, void* out, int n, int tokens, int heads, int head_dim,
+                 ap_stream_t stream);
+
 /* ---- tissue mask -> patch coordinates ----------------------------------------------
  * Replaces utils/contours.py:41-131 (mask_to_contours, scale_contours) and the grid scan of
  * services/extraction.py:67-128 (_in_tissue, _iter_patch_entries, FourPointContainment). */

@@ -92,11 +92,13 @@ struct GemmArgs {
 void set_gemm_trace(long long* buf, int tiles_per_wg);
 
 int launch_gemm(int dtype, int epilogue, const GemmArgs& a, hipStream_t stream);
-// impl: 0 = pick (256x256 persistent kernel when it supports the problem), 128 / 256 = force;
+// impl: 0 = pick (256x256 persistent kernel when it supports the problem), 128 / 256 = force,
+// 257 = the experimental twin of the 256 kernel (see gemm256.hip);
 // variant: gemm256 tuning knob: bits 4.. = workgroup start skew in percent of the estimated tile time
 int launch_gemm_impl(int dtype, int epilogue, const GemmArgs& a, int impl, int variant, hipStream_t stream);
 bool gemm256_supports(int dtype, int epilogue, const GemmArgs& a);
 int launch_gemm256(int dtype, int epilogue, const GemmArgs& a, int variant, hipStream_t stream);
+int launch_gemm256_alt(int dtype, int epilogue, const GemmArgs& a, int variant, hipStream_t stream);   // A/B twin (impl 257)
 
 // ---- LayerNorm / attention / misc ---------------------------------------------------------
 // rows of f32 [rows, dim] (row stride `stride` elements) -> T [rows, dim] (dense)

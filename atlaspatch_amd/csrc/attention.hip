@@ -1,9 +1,11 @@
 // Fused multi-head attention for the ViT encoder (short sequences: T <= 288 tokens, head_dim 64).
 //
-// One workgroup (4 waves) per (image, head).  K and V^T of that head live in LDS for the
-// whole block (K: XOR-swizzled rows; V: transposed so that 4 consecutive keys of one
-// channel are 8/16 contiguous bytes); each wave owns 32-query blocks and keeps the whole
-// 32 x T score strip in registers -- no online-softmax rescaling is needed at these lengths.
+// One workgroup per (image, head): 8 waves for f16 / bf16 (one 32-query block each, so the seven
+// blocks of T = 197 run side by side and two resident workgroups give each SIMD four waves to hide
+// the K/V staging and Q load latency), 4 waves for f32.  K and V^T of that head live in LDS for
+// the whole block (K: XOR-swizzled rows; V: transposed so that 4 consecutive keys of one channel
+// are 8/16 contiguous bytes); each wave keeps its whole 32 x T score strip in registers -- no
+// online-softmax rescaling is needed at these lengths.
 //
 //   S^T = K Q^T   (MFMA A-operand = K rows from LDS, B-operand = Q rows from global):
 //         lane (q = lane & 31) holds the scores of ITS query against half of the keys, its
@@ -21,6 +23,7 @@
 //
 // Roofline: MFMA for the two contractions (4*T*T*64 flop per head); HBM traffic = read
 // q,k,v once + write o once = 4 * T * 64 * sizeof(T) bytes per head.
+#include <cstdlib>
 #include "ap_common.h"
 
 namespace ap {
@@ -61,9 +64,10 @@ __device__ __forceinline__ f32x16 mma16<bf16>(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-template <typename T, int NKT>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1))
+template <typename T, int NKT, int NW>
+__global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 2 : 1))
 void attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int tokens, int heads) {
+    constexpr int NT = NW * 64;
     using S = AttnSmem<T, NKT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;
@@ -81,13 +85,13 @@ void attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int tokens
 
     // ---------------- stage K (swizzled rows) and V^T
     if constexpr (sizeof(T) == 2) {
-        for (int idx = tid; idx < S::TP * 8; idx += 256) {
+        for (int idx = tid; idx < S::TP * 8; idx += NT) {
             const int t = idx >> 3, c = idx & 7;
             u32x4 v = {0u, 0u, 0u, 0u};
             if (t < tokens) v = *(const u32x4*)(Kg + (size_t)t * ld + c * 8);
             *(u32x4*)(Ks + t * S::kRowB + ((c ^ ((t >> 1) & 7)) << 4)) = v;
         }
-        for (int idx = tid; idx < (S::TP / 2) * 8; idx += 256) {
+        for (int idx = tid; idx < (S::TP / 2) * 8; idx += NT) {
             const int tp = idx >> 3, c = idx & 7;
             const int t0 = tp * 2;
             typename Vec8<T>::type v0, v1;
@@ -100,7 +104,7 @@ void attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int tokens
                 *(uint32_t*)(Vt + (c * 8 + e) * S::vRowB + tp * 4) = pack2<T>(v0[e], v1[e]);
         }
     } else {
-        for (int idx = tid; idx < S::TP * 16; idx += 256) {
+        for (int idx = tid; idx < S::TP * 16; idx += NT) {
             const int t = idx >> 4, c = idx & 15;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (t < tokens) v = *(const f32x4*)(Kg + (size_t)t * ld + c * 4);
@@ -116,7 +120,7 @@ void attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int tokens
     const float scale_log2 = 0.125f * 1.4426950408889634f;      // log2(e) / sqrt(64)
     const int nqb = (tokens + 31) >> 5;
 
-    for (int qb = wave; qb < nqb; qb += 4) {
+    for (int qb = wave; qb < nqb; qb += NT / 64) {
         int qrow = qb * 32 + l31;
         const bool qvalid = qrow < tokens;
         if (!qvalid) qrow = tokens - 1;
@@ -270,19 +274,26 @@ void attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int tokens
     }
 }
 
-template <typename T, int NKT>
-int launch_one(const void* qkv, void* out, int n, int tokens, int heads, hipStream_t stream) {
+template <typename T, int NKT, int NW>
+int launch_nw(const void* qkv, void* out, int n, int tokens, int heads, hipStream_t stream) {
     using S = AttnSmem<T, NKT>;
     static bool configured = false;
-    auto kern = attention_kernel<T, NKT>;
+    auto kern = attention_kernel<T, NKT, NW>;
     if (!configured) {
         AP_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          S::total));
         configured = true;
     }
-    kern<<<dim3(n * heads), dim3(256), S::total, stream>>>((const T*)qkv, (T*)out, tokens, heads);
+    kern<<<dim3(n * heads), dim3(NW * 64), S::total, stream>>>((const T*)qkv, (T*)out, tokens, heads);
     AP_HIP_CHECK(hipGetLastError());
     return AP_OK;
+}
+
+template <typename T, int NKT>
+int launch_one(const void* qkv, void* out, int n, int tokens, int heads, hipStream_t stream) {
+    static const int waves = [] { const char* e = getenv("AP_ATTN_WAVES"); return e ? atoi(e) : 4; }();
+    if (sizeof(T) == 2 && waves == 8) return launch_nw<T, NKT, 8>(qkv, out, n, tokens, heads, stream);
+    return launch_nw<T, NKT, 4>(qkv, out, n, tokens, heads, stream);
 }
 
 template <typename T>

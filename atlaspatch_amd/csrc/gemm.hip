@@ -101,13 +101,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
             dma16(srcA[s] + (size_t)kt * kRowBytes, base + kTileBytes + s * 1024);
     };
 
+    // accumulators start from the bias (same convention as the 256x256 kernel: results are
+    // bit-identical whichever kernel serves a problem)
     f32x16 acc[2][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 b4 = *(const f32x4*)(g.bias + n0 + wave_n * 64 + nt * 32 + g4 * 8 + hi * 4);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[nt][mt][g4 * 4 + e] = b4[e];
+        }
 
     const int xr = (l31 >> 1) & 7;                                  // row-dependent chunk xor
     const int rowW = (wave_n * 64 + l31) * kRowBytes;               // + nt * 32 rows
@@ -177,10 +183,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int n = n0 + wave_n * 64 + nt * 32 + g4 * 8 + hi * 4;
-                const f32x4 bias = *(const f32x4*)(g.bias + n);
                 f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[nt][mt][g4 * 4 + e] + bias[e];
+                for (int e = 0; e < 4; ++e) v[e] = acc[nt][mt][g4 * 4 + e];
                 if constexpr (EPI == EPI_BIAS_STORE) {
                     if (g.gamma) {
                         const f32x4 ga = *(const f32x4*)(g.gamma + n);
@@ -237,7 +242,8 @@ int launch_gemm(int dtype, int epilogue, const GemmArgs& a, hipStream_t stream) 
 
 int launch_gemm_impl(int dtype, int epilogue, const GemmArgs& a, int impl, int variant, hipStream_t stream) {
     AP_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem %d x %d x %d", a.M, a.N, a.K);
-    AP_REQUIRE(impl == 0 || impl == 128 || impl == 256, "gemm: unknown implementation %d", impl);
+    AP_REQUIRE(impl == 0 || impl == 128 || impl == 256 || impl == 257, "gemm: unknown implementation %d", impl);
+    if (impl == 257) return launch_gemm256_alt(dtype, epilogue, a, variant, stream);
     if (impl == 256 || (impl == 0 && a.M >= 256 && gemm256_supports(dtype, epilogue, a)))
         return launch_gemm256(dtype, epilogue, a, variant, stream);
     const int kt = kRowBytes / (int)dtype_size(dtype);

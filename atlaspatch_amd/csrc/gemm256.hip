@@ -32,7 +32,7 @@
 //  * the LDS-DMA writes lane-linear, so the bank swizzle (16-B chunk ^= (row >> 1) & 7, conflict
 //    free for ds_read_b128's lane groups) is applied to the per-lane SOURCE address and again on
 //    the fragment read.
-//  * epilogue: bias (+GELU | *LayerScale) in registers, transposed through the wave's private LDS
+//  * accumulators start from the bias; epilogue: (GELU | *LayerScale) in registers, transposed through the wave's private LDS
 //    scratch (XOR-swizzled) so that global stores / the f32 residual read-modify-write are whole
 //    128-byte rows, 16 B per lane.
 //  * XCD-aware tile order: block b runs on XCD b % 8; each XCD owns a contiguous range of tile ids
@@ -41,6 +41,15 @@
 //
 // Roofline: MFMA (2*M*N*K flop per launch).
 #include "ap_common.h"
+
+// The file is compiled twice: the product build, and (-DAP_G256_ALT) an experimental twin that
+// ap_gemm reaches as impl 257, so a schedule change can be A/B-timed inside one process
+// (tools/gemm_check.py); code under `#ifdef AP_G256_ALT` is the experiment.
+#ifdef AP_G256_ALT
+#define AP_G256_FN(name) name##_alt
+#else
+#define AP_G256_FN(name) name
+#endif
 
 namespace ap {
 namespace {
@@ -204,16 +213,28 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
         pb[kk] = (wc * 32 + l31) * kRowBytes + co;
     }
 
+    // Accumulators start from the bias (lane's 32 n values, the same for its four m blocks), so the
+    // epilogue has no bias pass; the next tile's bias is fetched while the current epilogue runs.
     f32x16 acc[2][4];         // [n block of 32][m block of 32]
-    auto zero_acc = [&]() {
+    f32x4 nbias[2][4];
+    auto load_bias = [&](int ti, int hi_) {
+        const int id = tw.first + ti * tw.stride;
+        const float* bp = g.bias + (id % tw.tiles_n) * kBN + wc * 64 + hi_ * 4;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+            for (int g4 = 0; g4 < 4; ++g4) nbias[nb][g4] = *(const f32x4*)(bp + nb * 32 + g4 * 8);
     };
-    zero_acc();
+    auto init_acc = [&]() {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[nb][mb][e] = nbias[nb][e >> 2][e & 3];
+    };
+    load_bias(0, hi);
+    init_acc();
 
     Frag fa[2][4], fb0[4], fb1[4];
 
@@ -318,18 +339,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
         const int hi = lane_e >> 5, l31 = lane_e & 31;
         const int id = tw.first + ti * tw.stride;
         const int m0 = (id / tw.tiles_n) * kBM + wr * 128, n0 = (id % tw.tiles_n) * kBN + wc * 64;
-        f32x4 bias[2][4], gam[2][4];
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int n = n0 + nb * 32 + g4 * 8 + hi * 4;
-                bias[nb][g4] = *(const f32x4*)(g.bias + n);
-                if constexpr (EPI != EPI_BIAS_GELU) {
-                    if (g.gamma) gam[nb][g4] = *(const f32x4*)(g.gamma + n);
-                    else gam[nb][g4] = f32x4{1.f, 1.f, 1.f, 1.f};
-                }
-            }
+        load_bias(ti + 1 < tw.count ? ti + 1 : ti, hi);        // next tile's bias lands while this epilogue runs
+        const bool has_gamma = EPI != EPI_BIAS_GELU && g.gamma != nullptr;
+        const float* gp = g.gamma + n0 + hi * 4;
         if (g.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(ti, 3); }
         const int rrow = lane_e >> 3, rc = lane_e & 7;
 #pragma unroll
@@ -341,8 +353,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
                     for (int g4 = 0; g4 < 4; ++g4) {
                         f32x4 v;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            v[e] = (acc[nb][mb][g4 * 4 + e] + bias[nb][g4][e]) * gam[nb][g4][e];
+                        for (int e = 0; e < 4; ++e) v[e] = acc[nb][mb][g4 * 4 + e];
+                        if (has_gamma) {
+                            const f32x4 ga = *(const f32x4*)(gp + nb * 32 + g4 * 8);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] *= ga[e];
+                        }
                         *(f32x4*)(scr + l31 * 128 + (((g4 * 2 + hi) ^ (l31 & 7)) << 4)) = v;
                     }
 #pragma unroll
@@ -367,9 +383,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
                         f32x4 v;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            v[e] = acc[nb][mb][g4 * 4 + e] + bias[nb][g4][e];
+                            v[e] = acc[nb][mb][g4 * 4 + e];
                             if constexpr (EPI == EPI_BIAS_GELU) v[e] = gelu_sigmoid_poly(v[e]);
-                            else v[e] *= gam[nb][g4][e];
+                        }
+                        if (has_gamma) {
+                            const f32x4 ga = *(const f32x4*)(gp + nb * 32 + g4 * 8);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] *= ga[e];
                         }
                         *(u32x2*)(scr + l31 * 128 + (((nb * 4 + g4) ^ (l31 & 7)) << 4) + hi * 8) = pack4<T>(v);
                     }
@@ -383,7 +403,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
             }
         }
         stamp(ti, 4);
-        zero_acc();
+        init_acc();
     }
     AP_VMCNT(0);
 #undef AP_PHASE_SYNC
@@ -413,11 +433,16 @@ int launch_typed(int epilogue, const GemmArgs& a, int num_cu, int variant, hipSt
 
 }  // namespace
 
-static long long* g_trace = nullptr;
-static int g_trace_tiles = 0;
-void set_gemm_trace(long long* buf, int tiles_per_wg) { g_trace = buf; g_trace_tiles = tiles_per_wg; }
+#ifndef AP_G256_ALT
+long long* g_gemm_trace = nullptr;
+int g_gemm_trace_tiles = 0;
+void set_gemm_trace(long long* buf, int tiles_per_wg) { g_gemm_trace = buf; g_gemm_trace_tiles = tiles_per_wg; }
+#else
+extern long long* g_gemm_trace;
+extern int g_gemm_trace_tiles;
+#endif
 
-bool gemm256_supports(int dtype, int epilogue, const GemmArgs& a) {
+bool AP_G256_FN(gemm256_supports)(int dtype, int epilogue, const GemmArgs& a) {
     if (dtype != AP_F16 && dtype != AP_BF16) return false;
     if (epilogue != EPI_BIAS_STORE && epilogue != EPI_BIAS_GELU && epilogue != EPI_BIAS_RESID) return false;
     if (a.N % kBN != 0 || a.K % 128 != 0 || a.K < 128) return false;
@@ -429,7 +454,7 @@ bool gemm256_supports(int dtype, int epilogue, const GemmArgs& a) {
     return true;
 }
 
-int launch_gemm256(int dtype, int epilogue, const GemmArgs& a, int variant, hipStream_t stream) {
+int AP_G256_FN(launch_gemm256)(int dtype, int epilogue, const GemmArgs& a, int variant, hipStream_t stream) {
     static int num_cu = 0;
     if (num_cu == 0) {
         int dev = 0;
@@ -438,9 +463,9 @@ int launch_gemm256(int dtype, int epilogue, const GemmArgs& a, int variant, hipS
         AP_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
         num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    AP_REQUIRE(gemm256_supports(dtype, epilogue, a), "gemm256: unsupported problem");
+    AP_REQUIRE(AP_G256_FN(gemm256_supports)(dtype, epilogue, a), "gemm256: unsupported problem");
     GemmArgs b = a;
-    b.trace = g_trace; b.trace_tiles = g_trace_tiles;
+    b.trace = g_gemm_trace; b.trace_tiles = g_gemm_trace_tiles;
     const int skew_pct = variant >> 4;
     const int tiles = ((a.M + kBM - 1) / kBM) * (a.N / kBN);
     // estimated tile period in 10-ns ticks: ~1.65 us per 64-deep K-tile + epilogue

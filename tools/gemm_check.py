@@ -35,8 +35,9 @@ def reference(A, W, bias, gamma, epi, resid):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
-    ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--impls", default="128:0,256:0,256:800")
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--impls", default="128:0,256:0,257:0")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.load()
@@ -95,19 +96,24 @@ def main():
         W = ((torch.rand((N, K), device=dev, generator=g) * 2 - 1) * (2.0 / K ** 0.5)).half()
         bias = torch.rand(N, device=dev, generator=g) - 0.5
         out = torch.zeros((M, N), device=dev, dtype=torch.float32 if epi == "resid" else torch.float16)
+        best = {}
         for impl, variant in impls:
             for _ in range(3):
                 run(lib, torch.float16, epi, A, W, bias, None, out, impl, variant, stream)
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(args.iters):
-                run(lib, torch.float16, epi, A, W, bias, None, out, impl, variant, stream)
-            e1.record()
-            torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / args.iters
+        torch.cuda.synchronize()
+        for rnd in range(args.rounds):          # interleaved rounds: A B A B ... (run-to-run drift cancels)
+            for impl, variant in impls:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.iters):
+                    run(lib, torch.float16, epi, A, W, bias, None, out, impl, variant, stream)
+                e1.record()
+                torch.cuda.synchronize()
+                best.setdefault((impl, variant), []).append(e0.elapsed_time(e1) / args.iters)
+        for (impl, variant), v in best.items():
+            ms = sorted(v)[len(v) // 2]
             tf = 2.0 * M * N * K / ms / 1e9
-            res.append({"gemm": name, "impl": impl, "variant": variant, "ms": round(ms, 4), "TF": round(tf, 1)})
+            res.append({"gemm": name, "impl": impl, "variant": variant, "ms_median": round(ms, 4), "ms_min": round(min(v), 4), "TF": round(tf, 1)})
             print(res[-1], flush=True)
     print(json.dumps(res))
 

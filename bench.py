@@ -166,14 +166,23 @@ def main():
         return
 
     value = world * K * B / elapsed
-    # ---- roofline of the dominant kernel: the fc1 GEMM (gemm_kernel<T, EPI_BIAS_GELU>), one shape per launch
+    # ---- roofline of the dominant kernel: the fc1 GEMM (gemm256_kernel<T, EPI_BIAS_GELU>), one shape per launch
     M = B * 197
     fc1_ms, fc1_n = prof["gemm_fc1"]
     flop_launch = 2.0 * M * 3072 * 768
     fc1_avg_s = (fc1_ms / max(1, fc1_n)) * 1e-3
     achieved = flop_launch / fc1_avg_s / 1e12 if fc1_n else 0.0
     peak = MFMA_PEAK[short] / 1e12
-    gemm_ms = sum(prof[k][0] for k in ("gemm_patch_embed", "gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2"))
+    # HBM bytes of that kernel from the PMC counters (separate rocprofv3 --pmc passes of this same command,
+    # summarised by tools/pmc_traffic.py into profiles/; FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if short != "f32" and B == 1024 and os.path.exists(tpath):
+        with open(tpath) as fh:
+            for kname, rec in json.load(fh).items():
+                if "gemm256_kernel" in kname and ("Li1E" in kname or "EPI_BIAS_GELU" in kname or ", 1>" in kname) \
+                        and ("DF16_" in kname) == (short == "f16"):
+                    traffic = rec["hbm_bytes_per_launch"]
     kernel_ms = {k: round(v[0] / K, 4) for k, v in prof.items()}
     line = {
         "metric": "patches/sec embedded (256x256, ViT-B/16)", "value": round(value, 1), "unit": "patches/s",
@@ -183,9 +192,11 @@ def main():
                                f"resident in HBM, ViT-B/16 (random-init), device batch {B}",
                    "tiles_per_step": B, "slide_tissue_tiles": int(n_slide), "grid_cells": cells,
                    "parallelism": f"slide-per-rank x{world}" + (" + RCCL all-gather of features" if world > 1 else "")},
-        "roofline": {"bound": "mfma", "kernel": "gemm_kernel<T,EPI_BIAS_GELU> (fc1: [B*197,768]x[768,3072])",
+        "roofline": {"bound": "mfma", "kernel": "gemm256_kernel<T,EPI_BIAS_GELU> (fc1: [B*197,768]x[768,3072], "
+                                                        "persistent 256x256-tile MFMA GEMM)",
                      "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "TFLOP/s",
-                     "frac": round(achieved / peak, 4), "traffic": None,
+                     "frac": round(achieved / peak, 4), "traffic": traffic,
+                     "algorithmic_bytes_per_launch": (M * 768 + 3072 * 768 + M * 3072) * 2.0,
                      "avg_launch_ms": round(fc1_avg_s * 1e3, 4), "launches": fc1_n,
                      "algorithmic_flop_per_launch": flop_launch},
         "end_to_end_model_tflops": round(value * FLOP_PER_PATCH_VIT_B16 / 1e12 / world, 1),

@@ -117,6 +117,8 @@ int launch_layernorm_f32out(const float* x, long stride, int rows, int dim, cons
 // qkv: T [n*tokens, 3*dim] (q | k | v), out: T [n*tokens, dim]
 int launch_attention(int dtype, const void* qkv, void* out, int n, int tokens, int heads,
                      int head_dim, hipStream_t stream);
+int launch_attention_flash(int dtype, const void* qkv, void* out, int n, int tokens, int heads,
+                           hipStream_t stream);
 int launch_cls_init(float* tok, const float* cls, const float* pos, int n, int tokens, int dim,
                     hipStream_t stream);
 int launch_convert(int dtype, const float* src, void* dst, size_t count, hipStream_t stream);

@@ -311,6 +311,13 @@ int launch_attention(int dtype, const void* qkv, void* out, int n, int tokens, i
     AP_REQUIRE(head_dim == kHD, "attention: head_dim %d unsupported (64 only)", head_dim);
     AP_REQUIRE(tokens > 0 && heads > 0, "attention: bad shape");
     if (n <= 0) return AP_OK;
+    // f16 / bf16: the tiled online-softmax kernel (attention_flash.hip; any length, 0.37 ms vs 0.49 ms for
+    // the strip kernel at n = 1024, T = 197, H = 12).  AP_ATTN_IMPL=strip selects the register-strip kernel
+    // below (T <= 288) for A/B timing; f32 always uses it.
+    if (dtype != AP_F32) {
+        static const bool strip = [] { const char* e = getenv("AP_ATTN_IMPL"); return e && e[0] == 's'; }();
+        if (!strip || tokens > 288) return launch_attention_flash(dtype, qkv, out, n, tokens, heads, stream);
+    }
     switch (dtype) {
         case AP_F16: return launch_by_len<f16>(qkv, out, n, tokens, heads, stream);
         case AP_BF16: return launch_by_len<bf16>(qkv, out, n, tokens, heads, stream);

@@ -1,0 +1,304 @@
+// Tiled ("flash") multi-head attention for f16 / bf16, head_dim 64, any sequence length:
+//     out = softmax(q k^T / sqrt(64)) v      per (image, head), f32 softmax, online rescaling.
+//
+// One workgroup = 8 waves = eight 32-query blocks of one (image, head); it walks the keys in tiles
+// of 64.  K and V tiles arrive by LDS-DMA (global_load_lds, 16 B per lane, one K and one V piece
+// per thread and tile) into a ring of four 16-KiB buffers, three tiles ahead of the one being
+// consumed (the kernel is bound by memory-level parallelism, not by bandwidth or MFMA rate: the
+// whole K / V of a 197-token head is in flight before the first tile is touched); both stay
+// ROW-major in LDS:
+//   * S^T = K Q^T: MFMA A-operand = K rows (ds_read_b128, rows XOR-swizzled on the DMA source
+//     address), B-operand = the wave's Q rows held in registers.  A lane owns one query and half
+//     of the tile's keys, its partner lane ^ 32 the other half: row max / row sum are in-register
+//     reductions plus one v_permlane32_swap.
+//   * O^T = V^T P^T: the A-operand needs 8 keys of ONE channel per lane, i.e. a column of the
+//     row-major V tile: it is read with the gfx950 transpose load ds_read_b64_tr_b16 (a 16-lane
+//     group turns a [4 keys][16 channels] block into 4 keys of its own channel per lane), two per
+//     fragment.  The k slots of this product are assigned to exactly the keys the S^T accumulators
+//     of the lane already hold, so P goes from accumulator to B-operand without leaving the lane.
+//     V rows are swizzled (16-B chunk ^= 4 * ((row >> 1) & 1)) so the four rows a half-wave reads
+//     fall on four different 64-byte bank groups.
+// Online softmax per tile: m' = max(m, rowmax), O *= 2^((m - m') c), l = l * 2^((m - m') c) + rowsum
+// with c = log2(e) / 8 folded into the exponent; the rescale is deferred while no row of the wave grew
+// by more than 2^8 (the kernel is VALU-bound: 32 exp + ~200 other VALU per wave and tile against 16 MFMAs).  Keys past the end are staged from the last valid
+// row (finite data) and masked to -inf.
+//
+// Roofline: MFMA (4 * T * T * 64 flop per head; padded to 32-query x 64-key tiles);
+// HBM traffic = q, k, v read once + o written once.
+#include "ap_common.h"
+
+namespace ap {
+namespace {
+
+constexpr int kHD = 64;
+constexpr int kKV = 64;                 // keys per tile
+constexpr int kTileBytes = kKV * 128;   // one K or V tile (64 rows x 128 B)
+constexpr int kNW = 8;                  // waves per workgroup
+constexpr int kNB = 4;                  // K/V ring buffers (prefetch distance kNB - 1)
+
+template <typename T> struct FMma;
+template <> struct FMma<f16> {
+    using Frag = f16x8;
+    static __device__ __forceinline__ f32x16 run(Frag a, Frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct FMma<bf16> {
+    using Frag = bf16x8;
+    static __device__ __forceinline__ f32x16 run(Frag a, Frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+
+// one LDS-DMA load (16 B per lane): LDS[lds_dst + lane * 16] <- base[off]; only s_mov / s_nop besides
+// the load, so SCC is untouched; M0 saved and restored (compiler-reserved)
+__device__ __forceinline__ void dma16(const char* base, uint32_t off, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %3\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(off), "s"(lds_dst), "s"(base)
+        : "memory");
+}
+
+__device__ __forceinline__ u32x2 tr_read(uint32_t lds_addr) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_addr) : "memory");
+    return v;
+}
+
+// v_permlane32_swap exchanges the upper half of its first operand with the lower half of its second:
+// fed two copies of v it leaves {v.lo, v.lo} and {v.hi, v.hi}.  Inline asm on two distinct registers
+// (through the builtin hipcc folded the two results of equal inputs into one); the two v_nop are the
+// wait states between a VALU write of an operand and the swap reading it.
+__device__ __forceinline__ void half_swap(float v, float& lo, float& hi) {
+    float a = v, b = v;
+    asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    lo = a;
+    hi = b;
+}
+__device__ __forceinline__ float half_swap_max(float v) {       // max(v[lane & 31], v[(lane & 31) + 32])
+    float lo, hi;
+    half_swap(v, lo, hi);
+    return fmaxf(lo, hi);
+}
+__device__ __forceinline__ float half_swap_sum(float v) {
+    float lo, hi;
+    half_swap(v, lo, hi);
+    return lo + hi;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kNW * 64, 4)
+void attention_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int tokens, int heads) {
+    __shared__ __attribute__((aligned(16))) char smem[kNB * 2 * kTileBytes];     // [buf][K | V]
+    using Frag = typename FMma<T>::Frag;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int img = blockIdx.x / heads, head = blockIdx.x - img * heads;
+    const int dim = heads * kHD;
+    const uint32_t ldb = (uint32_t)(3 * dim) * 2;                         // row stride in bytes
+    const char* base = (const char*)(qkv + (size_t)img * tokens * 3 * dim + head * kHD);
+    const char* kbase = base + (size_t)dim * 2;
+    const char* vbase = base + (size_t)dim * 4;
+    const int nkv = (tokens + kKV - 1) / kKV;
+
+    // ---- staging plan: thread -> (tile row = tid >> 3, LDS chunk = tid & 7); source chunk swizzled
+    const int srow = tid >> 3, spos = tid & 7;
+    const uint32_t kchunk = (uint32_t)((spos ^ ((srow >> 1) & 7)) << 4);
+    const uint32_t vchunk = (uint32_t)((spos ^ (((srow >> 1) & 1) << 2)) << 4);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + wave * 1024;
+    auto stage = [&](int j) {
+        int row = j * kKV + srow;
+        row = row < tokens ? row : tokens - 1;
+        const uint32_t roff = (uint32_t)row * ldb;
+        const uint32_t dst = lds0 + (j % kNB) * 2 * kTileBytes;
+        dma16(kbase, roff + kchunk, dst);
+        dma16(vbase, roff + vchunk, dst + kTileBytes);
+    };
+#pragma unroll
+    for (int j = 0; j < kNB - 1; ++j)
+        if (j < nkv) stage(j);
+
+    // ---- this wave's queries
+    const int qb = blockIdx.y * kNW + wave;
+    int qrow = qb * 32 + l31;
+    const bool qvalid = qrow < tokens;
+    if (!qvalid) qrow = tokens - 1;
+    Frag qf[4];
+    {
+        const T* qp = (const T*)(base + (size_t)qrow * ldb);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const Frag*)(qp + kk * 16 + hi * 8);
+    }
+
+    // ---- fragment addresses inside a buffer
+    const int xr = (l31 >> 1) & 7;
+    uint32_t ka[4];                               // K: row l31 (+32 per key block), chunk (2 kk + hi) ^ xr
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) ka[kk] = (uint32_t)(l31 * 128 + (((kk * 2 + hi) ^ xr) << 4));
+    // V (transpose load): lane = (group g = lane >> 4, s = lane & 15) points at 8 bytes of key row
+    // 4 * (g >> 1) + (s >> 2) (+ 16 s' + {0, 8}), channels (g & 1) * 16 + 4 * (s & 3) .. + 3 (+ 32 it)
+    const int g = lane >> 4, s16 = lane & 15;
+    const int vrow = 4 * (g >> 1) + (s16 >> 2);                          // 0 .. 7
+    const int vcol = ((g & 1) * 32 + (s16 & 3) * 8);                     // byte offset inside the 64-B half
+    uint32_t va[2];                                                      // it = 0, 1 (row swizzle folded in)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int chunk = (it * 4 + (vcol >> 4)) ^ (((vrow >> 1) & 1) << 2);
+        va[it] = (uint32_t)(kTileBytes + vrow * 128 + (chunk << 4) + (vcol & 15));
+    }
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+    const float c = 0.125f * 1.4426950408889634f;                        // log2(e) / sqrt(64)
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x16 ot[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ot[it][e] = 0.f;
+
+    const bool active = qb * 32 < tokens;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // Deferred rescale (log2 domain): the running max is only raised, and O / l only rescaled, when some
+    // row of the wave grew by more than kDefer; otherwise P is taken against the old max and is bounded
+    // by 2^kDefer (exact in f32 accumulation, well inside the f16 / bf16 range as an MFMA operand).
+    constexpr float kDefer = 8.0f;
+
+    auto tile = [&](const char* buf, uint32_t bufa, int j, bool full) {
+        // ---------------- S^T = K Q^T  (32 queries x 64 keys); first MFMA of a block takes C = 0
+        f32x16 st[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            if (kb == 1 && !full) break;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const Frag kf = *(const Frag*)(buf + kb * 32 * 128 + ka[kk]);
+                st[kb] = FMma<T>::run(kf, qf[kk], kk == 0 ? zero16 : st[kb]);
+            }
+        }
+        if ((j + 1) * kKV > tokens) {                                     // mask keys past the end
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                if (kb == 1 && !full) break;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = j * kKV + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (key >= tokens) st[kb][r] = -INFINITY;
+                }
+            }
+        }
+        // ---------------- online softmax
+        float mx = st[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[0][r]);
+        if (full) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[1][r]);
+        }
+        mx = half_swap_max(mx);
+        if (__any((mx - m_run) * c > kDefer)) {
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+            m_run = m_new;
+            l_run *= alpha;
+            if (j > 0) {
+#pragma unroll
+                for (int it = 0; it < 2; ++it)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) ot[it][e] *= alpha;
+            }
+        }
+        const float mb = m_run * c;
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            if (kb == 1 && !full) break;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(st[kb][r] * c - mb);
+                st[kb][r] = p;
+                psum += p;
+            }
+        }
+        l_run += psum;
+
+        // ---------------- O^T += V^T P^T
+#pragma unroll
+        for (int sp = 0; sp < 4; ++sp) {                                  // 16-key steps
+            if (sp >= 2 && !full) break;
+            Frag pf;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pf[e] = (T)st[sp >> 1][(sp & 1) * 8 + e];
+            u32x2 v0a = tr_read(bufa + va[0] + sp * 16 * 128), v0b = tr_read(bufa + va[0] + sp * 16 * 128 + 8 * 128);
+            u32x2 v1a = tr_read(bufa + va[1] + sp * 16 * 128), v1b = tr_read(bufa + va[1] + sp * 16 * 128 + 8 * 128);
+            // the loads' destinations count as written only from here on (hipcc does not track asm loads)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v0a), "+v"(v0b), "+v"(v1a), "+v"(v1b) :: "memory");
+            const u32x4 f0 = {v0a[0], v0a[1], v0b[0], v0b[1]}, f1 = {v1a[0], v1a[1], v1b[0], v1b[1]};
+            ot[0] = FMma<T>::run(__builtin_bit_cast(Frag, f0), pf, ot[0]);
+            ot[1] = FMma<T>::run(__builtin_bit_cast(Frag, f1), pf, ot[1]);
+        }
+    };
+
+    for (int j = 0; j < nkv; ++j) {
+        if (j + kNB - 1 < nkv) stage(j + kNB - 1);
+        // tile j has landed when at most the 2 loads of each younger staged tile are still in flight
+        const int ahead = nkv - 1 - j < kNB - 1 ? nkv - 1 - j : kNB - 1;
+        if (ahead >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (ahead == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const char* buf = smem + (j % kNB) * 2 * kTileBytes;
+        const uint32_t bufa = lds_base + (j % kNB) * 2 * kTileBytes;
+
+        // A wave without queries (8th wave at T = 197) only stages and keeps the barriers; a tile whose
+        // second 32-key block lies wholly past the end (keys 224..255 at T = 197) runs as a half tile.
+        if (active) tile(buf, bufa, j, j * kKV + 32 < tokens);
+        __builtin_amdgcn_s_barrier();            // every wave is done with this buffer before it is restaged
+    }
+
+    const float inv = 1.0f / half_swap_sum(l_run);
+    if (qvalid && active) {
+        T* op = out + ((size_t)img * tokens + qrow) * dim + head * kHD;
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                T* dst = op + it * 32 + g4 * 8 + hi * 4;
+                if constexpr (sizeof(T) == 2) {
+                    u32x2 o;
+                    {
+                        const T a = (T)(ot[it][g4 * 4 + 0] * inv), b = (T)(ot[it][g4 * 4 + 1] * inv);
+                        const T cc = (T)(ot[it][g4 * 4 + 2] * inv), d = (T)(ot[it][g4 * 4 + 3] * inv);
+                        o[0] = (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
+                        o[1] = (uint32_t)__builtin_bit_cast(uint16_t, cc) | ((uint32_t)__builtin_bit_cast(uint16_t, d) << 16);
+                    }
+                    *(u32x2*)dst = o;
+                }
+            }
+    }
+}
+
+}  // namespace
+
+int launch_attention_flash(int dtype, const void* qkv, void* out, int n, int tokens, int heads,
+                           hipStream_t stream) {
+    AP_REQUIRE(dtype == AP_F16 || dtype == AP_BF16, "attention_flash: f16 / bf16 only");
+    AP_REQUIRE((size_t)tokens * 3 * heads * kHD * 2 < 0xffffffffull, "attention_flash: sequence too long");
+    if (n <= 0) return AP_OK;
+    const int nqb = (tokens + 31) / 32;
+    dim3 grid(n * heads, (nqb + kNW - 1) / kNW), block(kNW * 64);
+    if (dtype == AP_F16) attention_flash_kernel<f16><<<grid, block, 0, stream>>>((const f16*)qkv, (f16*)out, tokens, heads);
+    else attention_flash_kernel<bf16><<<grid, block, 0, stream>>>((const bf16*)qkv, (bf16*)out, tokens, heads);
+    AP_HIP_CHECK(hipGetLastError());
+    return AP_OK;
+}
+
+}  // namespace ap

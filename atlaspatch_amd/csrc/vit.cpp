@@ -219,7 +219,8 @@ int ap_vit_create(const ap_vit_config* cfg, ap_vit** out) {
     AP_REQUIRE(c.compute_dtype == AP_F16 || c.compute_dtype == AP_BF16 || c.compute_dtype == AP_F32,
                "vit_create: compute dtype %d", c.compute_dtype);
     const int g = c.image_size / c.patch_size;
-    AP_REQUIRE(1 + g * g <= 288, "vit_create: %d tokens exceed this build's attention limit (288)", 1 + g * g);
+    AP_REQUIRE(c.compute_dtype != AP_F32 || 1 + g * g <= 288,
+               "vit_create: %d tokens exceed the float32 attention kernel's limit (288); use float16 / bfloat16", 1 + g * g);
     ap_vit* m = new ap_vit();
     m->cfg = c;
     m->grid = g; m->patches = g * g; m->tokens = 1 + g * g;

@@ -1,0 +1,155 @@
+"""Per-operator parity of the HIP kernels behind the C ABI (ap_gemm / ap_layernorm / ap_attention)
+against a plain PyTorch fp32 reference of the same op on the same (dtype-rounded) inputs.
+
+Tolerances: f32 results ~1e-5; f16 / bf16 results are rounded to the operand type, so the bound is
+half an ulp of the output magnitude plus operand rounding (written per test)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+EPI = {"bias": 0, "gelu": 1, "resid": 2}
+
+
+@pytest.fixture(scope="module")
+def env():
+    from atlaspatch_amd import _lib
+    dev = torch.device("cuda:0")
+    return _lib, _lib.load(), dev, _lib.current_stream_ptr(dev)
+
+
+def _gemm(env, dt, epi, A, W, bias, gamma, out, impl):
+    _lib, lib, dev, stream = env
+    M, K = A.shape
+    _lib.check(lib.ap_gemm(_lib.torch_dtype_code(dt), EPI[epi], A.data_ptr(), A.stride(0), W.data_ptr(), W.stride(0),
+                           M, W.shape[0], K, bias.data_ptr(), gamma.data_ptr() if gamma is not None else None,
+                           out.data_ptr(), out.stride(0), impl, 0, stream), "ap_gemm")
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("epi", ["bias", "gelu", "resid"])
+@pytest.mark.parametrize("shape", [(300, 256, 128), (1182, 768, 768), (100, 256, 384), (3941, 768, 3072),
+                                   (20000, 2304, 768)])
+def test_gemm_persistent_kernel_vs_torch(env, dt, epi, shape):
+    """256x256 persistent kernel (impl 256): ragged M, one-tile and multi-tile-per-workgroup problems, all
+    epilogues; also bit-identical to the 128x128 kernel (the product may pick either by problem size)."""
+    _lib, lib, dev, stream = env
+    M, N, K = shape
+    g = torch.Generator(device=dev).manual_seed(M + N + K)
+    A = (torch.rand((M, K), device=dev, generator=g) * 2 - 1).to(dt)
+    W = ((torch.rand((N, K), device=dev, generator=g) * 2 - 1) * (2.0 / K ** 0.5)).to(dt)
+    bias = torch.rand(N, device=dev, generator=g) - 0.5
+    gamma = torch.rand(N, device=dev, generator=g) + 0.5 if epi != "gelu" and M % 2 else None
+    resid = torch.rand((M, N), device=dev, generator=g) if epi == "resid" else None
+    ref = A.float() @ W.float().t() + bias
+    if epi == "gelu":
+        ref = torch.nn.functional.gelu(ref)
+    elif gamma is not None:
+        ref = ref * gamma
+    if epi == "resid":
+        ref = resid + ref
+    outs = {}
+    for impl in (256, 128):
+        out = resid.clone() if epi == "resid" else torch.full((M, N), float("nan"), device=dev, dtype=dt)
+        _gemm(env, dt, epi, A, W, bias, gamma, out, impl)
+        outs[impl] = out
+    # |C| <= ~4: half an ulp of f16 is 2e-3, of bf16 1.6e-2; the f32 residual epilogue is exact to f32 rounding
+    tol = 2e-4 if epi == "resid" else (3e-3 if dt == torch.float16 else 2e-2)
+    assert (outs[256].float() - ref).abs().max().item() <= tol
+    assert torch.equal(outs[256], outs[128])
+
+
+def test_gemm_f32_exact_mfma(env):
+    _lib, lib, dev, stream = env
+    g = torch.Generator(device=dev).manual_seed(3)
+    M, N, K = 777, 384, 160
+    A = torch.rand((M, K), device=dev, generator=g) * 2 - 1
+    W = (torch.rand((N, K), device=dev, generator=g) * 2 - 1) * 0.2
+    bias = torch.rand(N, device=dev, generator=g)
+    out = torch.empty((M, N), device=dev)
+    _gemm(env, torch.float32, "bias", A, W, bias, None, out, 0)
+    ref = (A.double() @ W.double().t() + bias).float()
+    assert (out - ref).abs().max().item() <= 2e-5
+
+
+def test_gemm_repeatable(env):
+    """Race screen: the same launch five times must be bit-identical (counted-vmcnt LDS-DMA pipeline)."""
+    _lib, lib, dev, stream = env
+    g = torch.Generator(device=dev).manual_seed(0)
+    A = (torch.rand((50000, 768), device=dev, generator=g) * 2 - 1).half()
+    W = ((torch.rand((2304, 768), device=dev, generator=g) * 2 - 1) * 0.07).half()
+    bias = torch.rand(2304, device=dev, generator=g)
+    outs = []
+    for _ in range(5):
+        out = torch.empty((50000, 2304), device=dev, dtype=torch.float16)
+        _gemm(env, torch.float16, "bias", A, W, bias, None, out, 256)
+        outs.append(out)
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.6e-2), (torch.float32, 2e-5)])
+@pytest.mark.parametrize("rows,dim", [(1, 768), (37, 768), (1000, 1024), (50, 512)])
+def test_layernorm_vs_torch(env, dt, tol, rows, dim):
+    _lib, lib, dev, stream = env
+    g = torch.Generator(device=dev).manual_seed(rows + dim)
+    x = torch.randn((rows, dim), device=dev, generator=g) * 3 + 1
+    gamma = torch.rand(dim, device=dev, generator=g) + 0.5
+    beta = torch.rand(dim, device=dev, generator=g) - 0.5
+    out = torch.empty((rows, dim), device=dev, dtype=dt)
+    _lib.check(lib.ap_layernorm(_lib.torch_dtype_code(dt), x.data_ptr(), dim, rows, dim, gamma.data_ptr(), beta.data_ptr(),
+                                1e-6, out.data_ptr(), stream))
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.layer_norm(x, (dim,), gamma, beta, 1e-6)
+    assert (out.float() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item() / 2)
+
+
+def _attn_ref(qkv, n, T, H):
+    q, k, v = qkv.float().view(n, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+    p = torch.softmax(q @ k.transpose(-1, -2) / 8.0, -1)
+    return (p @ v).permute(0, 2, 1, 3).reshape(n * T, H * 64)
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float16, 4e-3), (torch.bfloat16, 3e-2), (torch.float32, 2e-5)])
+@pytest.mark.parametrize("shape", [(3, 197, 12), (2, 50, 16), (1, 257, 12), (5, 1, 12), (2, 785, 12), (1, 1025, 4)])
+def test_attention_vs_torch(env, dt, tol, shape):
+    """|out| <= 6: half an ulp of the output + the rounding of P to the MFMA operand type."""
+    _lib, lib, dev, stream = env
+    n, T, H = shape
+    if dt == torch.float32 and T > 288:
+        pytest.skip("float32 attention is the register-strip kernel (T <= 288)")
+    g = torch.Generator(device=dev).manual_seed(T)
+    qkv = (torch.randn((n * T, 3 * H * 64), device=dev, generator=g) * 1.5).to(dt)
+    out = torch.full((n * T, H * 64), float("nan"), device=dev, dtype=dt)
+    _lib.check(lib.ap_attention(_lib.torch_dtype_code(dt), qkv.data_ptr(), out.data_ptr(), n, T, H, 64, stream))
+    torch.cuda.synchronize()
+    assert (out.float() - _attn_ref(qkv, n, T, H)).abs().max().item() <= tol
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float16, 4e-3), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("shape", [(2, 197, 12, 150), (1, 785, 12, 700), (1, 300, 4, 70)])
+def test_attention_forced_rescale(env, dt, tol, shape):
+    """The online-softmax rescale is deferred while the running max grows by < 2^8: force the branch with a
+    key whose score against one query jumps far above everything seen before it (full-tensor reference)."""
+    _lib, lib, dev, stream = env
+    n, T, H, at = shape
+    g = torch.Generator(device=dev).manual_seed(at)
+    qkv = torch.randn((n * T, 3 * H * 64), device=dev, generator=g).to(dt)
+    v = qkv.view(n, T, 3, H, 64)
+    v[:, at, 1] = v[:, 5, 0] * 6.0
+    v[:, at + 3, 1] *= 5.0
+    out = torch.full((n * T, H * 64), float("nan"), device=dev, dtype=dt)
+    _lib.check(lib.ap_attention(_lib.torch_dtype_code(dt), qkv.data_ptr(), out.data_ptr(), n, T, H, 64, stream))
+    torch.cuda.synchronize()
+    assert (out.float() - _attn_ref(qkv, n, T, H)).abs().max().item() <= tol
+
+
+def test_operator_error_paths(env):
+    _lib, lib, dev, stream = env
+    x = torch.zeros(16, device=dev)
+    assert lib.ap_gemm(1, 0, None, 0, None, 0, 1, 1, 1, None, None, None, 0, 0, 0, stream) == -1
+    assert lib.ap_gemm(1, 7, x.data_ptr(), 128, x.data_ptr(), 128, 4, 128, 128, x.data_ptr(), None, x.data_ptr(), 128, 0, 0,
+                       stream) == -1
+    assert lib.ap_attention(1, x.data_ptr(), x.data_ptr(), 1, 4, 1, 32, stream) == -1     # head_dim != 64
+    assert b"head_dim" in lib.ap_last_error()

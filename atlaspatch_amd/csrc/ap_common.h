@@ -119,6 +119,9 @@ int launch_attention(int dtype, const void* qkv, void* out, int n, int tokens, i
                      int head_dim, hipStream_t stream);
 int launch_attention_flash(int dtype, const void* qkv, void* out, int n, int tokens, int heads,
                            hipStream_t stream);
+// attentional pooling (attn_pool.hip): kv T [n*tokens, 2*heads*64] (k | v), q f32 [heads*64] -> out T [n, heads*64]
+int launch_attn_pool(int dtype, const void* kv, const float* q, void* out, int n, int tokens, int heads,
+                     hipStream_t stream);
 int launch_cls_init(float* tok, const float* cls, const float* pos, int n, int tokens, int dim,
                     hipStream_t stream);
 int launch_convert(int dtype, const float* src, void* dst, size_t count, hipStream_t stream);

@@ -1,0 +1,100 @@
+// Attentional pooling with few learned queries (open_clip AttentionalPooler as CONCH's visual tower uses
+// it: n_queries = 1): per (image, head) softmax(q_h . k_t / sqrt(64)) over all tokens t, weighted sum of v_t.
+// The query is input independent (ln_q(query) projected by q_proj), so it arrives as a constant f32 vector.
+//
+//   kv : T [n * tokens, 2 * P]   (k | v, each P = heads * 64 wide), q : f32 [P], out : T [n, P]
+//
+// One 256-thread workgroup per (image, head).  Pass 1: a thread takes whole key rows (64 channels = 128 B,
+// eight 16-byte loads) and leaves the scaled score in LDS; block max / sum; pass 2: thread = (channel,
+// token group of 4), so a wave reads one 128-byte V row per step; the four groups are reduced through LDS.
+// HBM-bound: k and v are read once (2 * tokens * 128 B per head).
+#include "ap_common.h"
+
+namespace ap {
+namespace {
+
+template <typename T> struct PoolVec;
+template <> struct PoolVec<f16> { using v8 = f16x8; };
+template <> struct PoolVec<bf16> { using v8 = bf16x8; };
+
+__device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float o = __shfl_xor(v, off, 64);
+        v = is_max ? fmaxf(v, o) : v + o;
+    }
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    const float a = red[0], b = red[1], c = red[2], d = red[3];
+    return is_max ? fmaxf(fmaxf(a, b), fmaxf(c, d)) : (a + b) + (c + d);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_pool_kernel(const T* __restrict__ kv, const float* __restrict__ q,
+                                                        T* __restrict__ out, int tokens, int heads) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];       // scores[tokens] | red[4] | part[4][64]
+    float* scores = sm;
+    float* red = sm + ((tokens + 3) & ~3);
+    float* part = red + 4;
+    using V8 = typename PoolVec<T>::v8;
+    const int img = blockIdx.x / heads, head = blockIdx.x - img * heads;
+    const int P = heads * 64;
+    const size_t ld = (size_t)2 * P;
+    const T* kbase = kv + (size_t)img * tokens * ld + head * 64;
+    const T* vbase = kbase + P;
+    const float* qh = q + head * 64;
+
+    float qr[64];
+#pragma unroll
+    for (int c = 0; c < 64; ++c) qr[c] = qh[c];
+    float mx = -INFINITY;
+    for (int t = threadIdx.x; t < tokens; t += 256) {
+        const T* kp = kbase + (size_t)t * ld;
+        float s = 0.f;
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) {
+            const V8 kk = *(const V8*)(kp + c8 * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s = __builtin_fmaf((float)kk[e], qr[c8 * 8 + e], s);
+        }
+        s *= 0.125f;
+        scores[t] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = block_reduce(mx, red, true);
+    float sum = 0.f;
+    for (int t = threadIdx.x; t < tokens; t += 256) {
+        const float p = __expf(scores[t] - mx);
+        scores[t] = p;
+        sum += p;
+    }
+    sum = block_reduce(sum, red, false);          // its barriers also publish scores[]
+    const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    float acc = 0.f;
+    for (int t = grp; t < tokens; t += 4) acc = __builtin_fmaf(scores[t], (float)vbase[(size_t)t * ld + c], acc);
+    part[grp * 64 + c] = acc;
+    __syncthreads();
+    if (grp == 0) {
+        const float o = ((part[c] + part[64 + c]) + (part[128 + c] + part[192 + c])) / sum;
+        out[(size_t)img * P + head * 64 + c] = (T)o;
+    }
+}
+
+}  // namespace
+
+int launch_attn_pool(int dtype, const void* kv, const float* q, void* out, int n, int tokens, int heads,
+                     hipStream_t stream) {
+    AP_REQUIRE(dtype == AP_F16 || dtype == AP_BF16, "attn_pool: f16 / bf16 only");
+    AP_REQUIRE(tokens > 0 && tokens <= 12000, "attn_pool: %d tokens unsupported", tokens);
+    if (n <= 0) return AP_OK;
+    const size_t lds = ((size_t)((tokens + 3) & ~3) + 4 + 256) * sizeof(float);
+    dim3 grid(n * heads), block(256);
+    if (dtype == AP_F16) attn_pool_kernel<f16><<<grid, block, lds, stream>>>((const f16*)kv, q, (f16*)out, tokens, heads);
+    else attn_pool_kernel<bf16><<<grid, block, lds, stream>>>((const bf16*)kv, q, (bf16*)out, tokens, heads);
+    AP_HIP_CHECK(hipGetLastError());
+    return AP_OK;
+}
+
+}  // namespace ap

@@ -180,10 +180,41 @@ int run_blocks(ap_vit* m, int n, const Workspace& w, float* out, hipStream_t str
         pending = w.delta;
         pending_ls = c.layer_scale ? vec("ls2") : nullptr;
     }
-    // final LayerNorm on the CLS row of every image (last fc2 output folded in first) -> out f32 [n, D]
-    return ap::launch_add_layernorm(dt, AP_F32, w.tok, (long)m->tokens * D, pending, (long)m->tokens * D, pending_ls, n, D,
-                                    (const float*)find(m, "norm.weight")->dev,
-                                    (const float*)find(m, "norm.bias")->dev, c.ln_eps, out, stream);
+    if (c.pool == AP_POOL_CLS)
+        // final LayerNorm on the CLS row of every image (last fc2 output folded in first) -> out f32 [n, D]
+        return ap::launch_add_layernorm(dt, AP_F32, w.tok, (long)m->tokens * D, pending, (long)m->tokens * D, pending_ls,
+                                        n, D, (const float*)find(m, "norm.weight")->dev,
+                                        (const float*)find(m, "norm.bias")->dev, c.ln_eps, out, stream);
+
+    // ---- AP_POOL_ATTN (CONCH visual tower): final LN on ALL tokens, then the one-query attentional pooler.
+    // Buffers: y f32 [M, D] reuses qkv, xk T [M, D] = xn, kv T [M, 2P] reuses hid, pooled T [n, P] = att,
+    // o32 f32 [n, P] reuses delta.
+    const int P = c.pool_dim;
+    auto pv = [&](const char* s) { return (const float*)find(m, std::string("attn_pool.") + s)->dev; };
+    float* y = (float*)w.qkv;
+    if ((rc = ap::launch_add_layernorm(dt, AP_F32, w.tok, D, pending, D, pending_ls, M, D,
+                                       (const float*)find(m, "norm.weight")->dev,
+                                       (const float*)find(m, "norm.bias")->dev, c.ln_eps, y, stream)) != AP_OK) return rc;
+    if ((rc = ap::launch_layernorm(dt, y, D, M, D, pv("ln_k.weight"), pv("ln_k.bias"), c.pool_ln_eps, w.xn,
+                                   stream)) != AP_OK) return rc;
+    {
+        const Param* wkv = find(m, "attn_pool.kv.weight");
+        ap::GemmArgs g{};
+        g.A = w.xn; g.lda = D; g.W = wkv->dev; g.ldw = wkv->ld; g.M = M; g.N = 2 * P; g.K = D;
+        g.bias = pv("kv.bias"); g.out = w.hid; g.ldo = 2 * P;
+        if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_STORE, g, stream)) != AP_OK) return rc;
+    }
+    if ((rc = ap::launch_attn_pool(dt, w.hid, pv("q"), w.att, n, m->tokens, c.pool_heads, stream)) != AP_OK) return rc;
+    float* o32 = (float*)w.delta;
+    AP_HIP_CHECK(hipMemsetAsync(o32, 0, (size_t)n * P * sizeof(float), stream));
+    {
+        const Param* wo = find(m, "attn_pool.out.weight");
+        ap::GemmArgs g{};
+        g.A = w.att; g.lda = P; g.W = wo->dev; g.ldw = wo->ld; g.M = n; g.N = P; g.K = P;
+        g.bias = pv("out.bias"); g.out = o32; g.ldo = P;
+        if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_RESID, g, stream)) != AP_OK) return rc;    // 0 + (acc + bias), f32
+    }
+    return ap::launch_layernorm(AP_F32, o32, P, n, P, pv("ln_out.weight"), pv("ln_out.bias"), c.pool_ln_eps, out, stream);
 }
 
 int check_forward_args(const ap_vit* m, int n, const void* in, const float* out, const void* ws,
@@ -218,6 +249,13 @@ int ap_vit_create(const ap_vit_config* cfg, ap_vit** out) {
     AP_REQUIRE(c.depth > 0, "vit_create: depth %d", c.depth);
     AP_REQUIRE(c.compute_dtype == AP_F16 || c.compute_dtype == AP_BF16 || c.compute_dtype == AP_F32,
                "vit_create: compute dtype %d", c.compute_dtype);
+    AP_REQUIRE(c.pool == AP_POOL_CLS || c.pool == AP_POOL_ATTN, "vit_create: pool %d", c.pool);
+    if (c.pool == AP_POOL_ATTN) {
+        AP_REQUIRE(c.compute_dtype != AP_F32, "vit_create: the attentional pooler runs in float16 / bfloat16 only");
+        AP_REQUIRE(c.pool_heads > 0 && c.pool_dim == c.pool_heads * 64 && c.pool_dim % 128 == 0 &&
+                   2 * c.pool_dim <= c.mlp_dim && 2 * c.pool_dim <= 3 * c.dim,
+                   "vit_create: pool_dim %d / pool_heads %d (heads of 64, multiple of 128)", c.pool_dim, c.pool_heads);
+    }
     const int g = c.image_size / c.patch_size;
     AP_REQUIRE(c.compute_dtype != AP_F32 || 1 + g * g <= 288,
                "vit_create: %d tokens exceed the float32 attention kernel's limit (288); use float16 / bfloat16", 1 + g * g);
@@ -246,6 +284,14 @@ int ap_vit_create(const ap_vit_config* cfg, ap_vit** out) {
         add(b + "fc1.weight", c.mlp_dim, D, true); add(b + "fc1.bias", 1, c.mlp_dim, false);
         add(b + "fc2.weight", D, c.mlp_dim, true); add(b + "fc2.bias", 1, D, false);
         if (c.layer_scale) { add(b + "ls1", 1, D, false); add(b + "ls2", 1, D, false); }
+    }
+    if (c.pool == AP_POOL_ATTN) {
+        const int P = c.pool_dim;
+        add("attn_pool.ln_k.weight", 1, D, false); add("attn_pool.ln_k.bias", 1, D, false);
+        add("attn_pool.kv.weight", 2 * P, D, true); add("attn_pool.kv.bias", 1, 2 * P, false);
+        add("attn_pool.q", 1, P, false);
+        add("attn_pool.out.weight", P, P, true); add("attn_pool.out.bias", 1, P, false);
+        add("attn_pool.ln_out.weight", 1, P, false); add("attn_pool.ln_out.bias", 1, P, false);
     }
     if (rc != AP_OK) { ap_vit_destroy(m); return rc; }
     *out = m;
@@ -299,7 +345,7 @@ size_t ap_vit_workspace_bytes(const ap_vit* m, int n) {
     return carve(m, n, nullptr).total;
 }
 
-int ap_vit_embed_dim(const ap_vit* m) { return m ? m->cfg.dim : 0; }
+int ap_vit_embed_dim(const ap_vit* m) { return !m ? 0 : (m->cfg.pool == AP_POOL_ATTN ? m->cfg.pool_dim : m->cfg.dim); }
 
 int ap_vit_profile_enable(ap_vit* m, int on) {
     AP_REQUIRE(m, "vit_profile_enable: null handle");

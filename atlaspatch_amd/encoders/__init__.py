@@ -7,7 +7,7 @@ from .base import FeatureExtractor, HipViTFeatureExtractor, PatchFeatureExtracto
 from .custom import (CustomEncoderComponents, CustomEncoderLoader, register_custom_encoder,
                      register_feature_extractors_from_module, register_hip_vit_encoder)
 from .registry import PatchFeatureExtractorRegistry
-from .vit import register_uni, register_vits
+from .vit import register_conch, register_uni, register_vits
 
 __all__ = ["FeatureExtractor", "HipViTFeatureExtractor", "PatchFeatureExtractor",
            "PatchFeatureExtractorRegistry", "build_default_registry", "CustomEncoderComponents",
@@ -17,11 +17,12 @@ __all__ = ["FeatureExtractor", "HipViTFeatureExtractor", "PatchFeatureExtractor"
 
 def build_default_registry(*, device="cuda", num_workers: int = 0,
                            dtype: torch.dtype = torch.float32) -> PatchFeatureExtractorRegistry:
-    """Built-in extractors of this build: the ViT family on the native HIP path.  Builders are
+    """Built-in extractors of this build: the ViT family (vit_b_16, vit_l_16, uni_v1, conch_v1) on the native HIP path.  Builders are
     lazy (nothing touches the GPU until ``create``), so this is safe on a CPU-only host, exactly
     like the reference's registry which the CLI instantiates at import (cli.py:50)."""
     dev = torch.device(device)
     registry = PatchFeatureExtractorRegistry()
     register_vits(registry, device=dev, num_workers=num_workers, dtype=dtype)
     register_uni(registry, device=dev, num_workers=num_workers, dtype=dtype)
+    register_conch(registry, device=dev, num_workers=num_workers, dtype=dtype)
     return registry

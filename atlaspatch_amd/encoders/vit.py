@@ -26,6 +26,8 @@ logger = logging.getLogger("atlaspatch_amd.encoders.vit")
 
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
+OPENAI_CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+OPENAI_CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
 
 ARCHS = {
     # name: image, patch, dim, depth, heads, mlp, eps, layer_scale
@@ -35,6 +37,12 @@ ARCHS = {
                      ln_eps=1e-6, layer_scale=False),
     "uni_v1": dict(image_size=224, patch_size=16, dim=1024, depth=24, heads=16, mlp_dim=4096,
                    ln_eps=1e-6, layer_scale=True),
+    # CONCH v1 visual tower (models/patch/conch.py:20-64 -> conch.open_clip_custom "conch_ViT-B-16" [3P, package
+    # absent offline]): timm ViT-B/16 trunk at 448 px (785 tokens) + open_clip AttentionalPooler with ONE
+    # contrastive query (d_model 512, 8 heads, context 768) + LayerNorm; encode_image(proj_contrast=False,
+    # normalize=False) returns that 512-vector.
+    "conch_v1": dict(image_size=448, patch_size=16, dim=768, depth=12, heads=12, mlp_dim=3072,
+                     ln_eps=1e-6, layer_scale=False, pool="attn", pool_dim=512, pool_heads=8, pool_ln_eps=1e-5),
 }
 
 
@@ -123,6 +131,50 @@ def canonical_state_dict(sd: dict, *, depth: int, layer_scale: bool, source: str
     return out
 
 
+def attn_pool_canonical(pool: dict, *, pool_eps: float = 1e-5) -> dict:
+    """open_clip ``AttentionalPooler`` (+ the LayerNorm after it) -> ``attn_pool.*`` parameters.
+
+    ``pool`` holds the module's own tensors: ``query`` [1, P], ``ln_q.weight|bias``, ``ln_k.weight|bias``,
+    ``attn.q_proj_weight`` [P, P], ``attn.k_proj_weight`` / ``attn.v_proj_weight`` [P, C], ``attn.in_proj_bias``
+    [3P], ``attn.out_proj.weight|bias`` and ``ln_out.weight|bias`` (CONCH: ``visual.ln_contrast``).
+    The projected query is input independent and is folded here (float64 on the host)."""
+    f = lambda k: pool[k].detach().to(torch.float64, copy=True).cpu()
+    P = pool["attn.q_proj_weight"].shape[0]
+    q = torch.nn.functional.layer_norm(f("query").reshape(1, P), (P,), f("ln_q.weight"), f("ln_q.bias"), pool_eps)
+    q = q @ f("attn.q_proj_weight").T + f("attn.in_proj_bias")[:P]
+    out = {"attn_pool.q": q.reshape(-1),
+           "attn_pool.ln_k.weight": f("ln_k.weight"), "attn_pool.ln_k.bias": f("ln_k.bias"),
+           "attn_pool.kv.weight": torch.cat([f("attn.k_proj_weight"), f("attn.v_proj_weight")], 0),
+           "attn_pool.kv.bias": f("attn.in_proj_bias")[P:],
+           "attn_pool.out.weight": f("attn.out_proj.weight"), "attn_pool.out.bias": f("attn.out_proj.bias"),
+           "attn_pool.ln_out.weight": f("ln_out.weight"), "attn_pool.ln_out.bias": f("ln_out.bias")}
+    return {k: v.to(torch.float32).contiguous() for k, v in out.items()}
+
+
+def conch_state_dicts(sd: dict) -> tuple[dict, dict]:
+    """Split a CONCH v1 checkpoint (open_clip_custom CoCa; key names from the public package [3P], unverified
+    offline) into the timm trunk state dict and the pooler tensors ``attn_pool_canonical`` expects."""
+    trunk = {k[len("visual.trunk."):]: v for k, v in sd.items() if k.startswith("visual.trunk.")}
+    pre = "visual.attn_pool_contrast."
+    pool = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+    pool["ln_out.weight"] = sd["visual.ln_contrast.weight"]
+    pool["ln_out.bias"] = sd["visual.ln_contrast.bias"]
+    return trunk, pool
+
+
+def random_attn_pool(arch: dict, seed: int = 0) -> dict:
+    """Seeded AttentionalPooler tensors (module-style names) for tests / benchmarks."""
+    g = torch.Generator().manual_seed(seed + 7919)
+    P, C = arch["pool_dim"], arch["dim"]
+    w = lambda *shape, s=0.02: torch.randn(*shape, generator=g) * s
+    return {"query": torch.randn(1, P, generator=g), "ln_q.weight": 1.0 + w(P, s=0.1), "ln_q.bias": w(P),
+            "ln_k.weight": 1.0 + w(C, s=0.1), "ln_k.bias": w(C),
+            "attn.q_proj_weight": w(P, P, s=0.05), "attn.k_proj_weight": w(P, C, s=0.05),
+            "attn.v_proj_weight": w(P, C, s=0.05), "attn.in_proj_bias": w(3 * P),
+            "attn.out_proj.weight": w(P, P, s=0.05), "attn.out_proj.bias": w(P),
+            "ln_out.weight": 1.0 + w(P, s=0.1), "ln_out.bias": w(P)}
+
+
 def random_canonical_state_dict(arch: dict, seed: int = 0) -> dict:
     """Seeded random-init weights (trunc-normal-ish sigma 0.02, LN gamma ~ 1): there are no
     pretrained checkpoints offline."""
@@ -146,6 +198,8 @@ def random_canonical_state_dict(arch: dict, seed: int = 0) -> dict:
         if arch.get("layer_scale"):
             sd[b + "ls1"] = torch.full((d,), 1e-5) + w(d, s=1e-6)
             sd[b + "ls2"] = torch.full((d,), 1e-5) + w(d, s=1e-6)
+    if arch.get("pool") == "attn":
+        sd.update(attn_pool_canonical(random_attn_pool(arch, seed), pool_eps=arch.get("pool_ln_eps", 1e-5)))
     return sd
 
 
@@ -161,10 +215,13 @@ class HipViT:
         self.device = torch.device(device)
         self.dtype = dtype
         self.arch = dict(arch)
-        self.embed_dim = int(arch["dim"])
+        attn_pool = arch.get("pool") == "attn"
+        self.embed_dim = int(arch["pool_dim"] if attn_pool else arch["dim"])
         cfg = _lib.VitConfig(arch["image_size"], arch["patch_size"], arch["dim"], arch["depth"],
                              arch["heads"], arch["mlp_dim"], float(arch["ln_eps"]),
-                             1 if arch.get("layer_scale") else 0, _lib.torch_dtype_code(dtype))
+                             1 if arch.get("layer_scale") else 0, _lib.torch_dtype_code(dtype),
+                             1 if attn_pool else 0, int(arch.get("pool_dim", 0)), int(arch.get("pool_heads", 0)),
+                             float(arch.get("pool_ln_eps", 1e-5)))
         handle = C.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(self.lib.ap_vit_create(C.byref(cfg), C.byref(handle)), "ap_vit_create")
@@ -285,11 +342,32 @@ def build_hip_vit_extractor(*, name: str, arch, device, dtype, state_dict: Optio
                 f"No weights for '{name}': set ATLASPATCH_WEIGHTS_DIR to a directory holding "
                 f"{name}.safetensors/.pt (torchvision, timm or HF ViT key names), or set "
                 "ATLASPATCH_RANDOM_INIT=<seed> for seeded random weights (benchmarks/tests).")
+    pool_state = None
+    if spec.get("pool") == "attn" and source != "canonical":
+        if any(k.startswith("visual.trunk.") for k in state_dict):          # a CONCH checkpoint
+            state_dict, pool = conch_state_dicts(state_dict)
+            pool_state = attn_pool_canonical(pool, pool_eps=spec.get("pool_ln_eps", 1e-5))
+        else:                                                                # trunk dict + "attn_pool.*" tensors
+            pool_state = {k: v for k, v in state_dict.items() if k.startswith("attn_pool.")}
+            state_dict = {k: v for k, v in state_dict.items() if not k.startswith("attn_pool.")}
     state = canonical_state_dict(state_dict, depth=spec["depth"], layer_scale=bool(spec.get("layer_scale")),
                                  source=source)
+    if pool_state:
+        state.update({k: v.detach().to(torch.float32).cpu().contiguous() for k, v in pool_state.items()})
     vit = HipViT(spec, state, device=torch.device(device), dtype=dtype)
     return HipViTFeatureExtractor(name=name, vit=vit, mean=mean or IMAGENET_MEAN, std=std or IMAGENET_STD,
                                   max_batch=max_batch, host_resize=host_resize, expect_size=expect_size)
+
+
+def register_conch(registry, *, device, dtype=torch.float32, num_workers: int = 0) -> None:
+    """conch_v1 (models/patch/conch.py:20-64): open_clip image transform = Resize(448, bicubic) + CenterCrop(448)
+    + ToTensor + Normalize(OpenAI CLIP mean / std) [3P]; the resize runs on the host with Pillow, the rest on
+    the device.  float16 / bfloat16 only (the reference's config 5 runs it in fp16)."""
+    from PIL import Image
+    registry.register("conch_v1", lambda: build_hip_vit_extractor(
+        name="conch_v1", arch="conch_v1", device=device, dtype=dtype, random_init_seed=_env_seed(),
+        mean=OPENAI_CLIP_MEAN, std=OPENAI_CLIP_STD, host_resize=(448, Image.Resampling.BICUBIC), expect_size=448,
+        max_batch=256))
 
 
 def _env_seed() -> Optional[int]:

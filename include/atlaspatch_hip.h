@@ -81,7 +81,17 @@ typedef struct ap_vit_config {
     int layer_scale;     /* 1: per-branch gamma (timm init_values, uni.py:35) */
     int compute_dtype;   /* AP_F16 / AP_BF16 / AP_F32: MFMA operand type; accumulation,
                             residual stream, LayerNorm and softmax are always f32 */
+    int pool;            /* AP_POOL_CLS: final LN, class token (vit.py, uni.py).
+                            AP_POOL_ATTN: final LN on all tokens, then the attentional pooler of
+                            CONCH's visual tower with ONE query (models/patch/conch.py:52,
+                            encode_image(proj_contrast=False, normalize=False)): LN_k, k/v
+                            projection to pool_dim, softmax pooling per head, out_proj, LN */
+    int pool_dim;        /* 512 (conch_v1); heads of 64 */
+    int pool_heads;      /* 8 */
+    float pool_ln_eps;   /* 1e-5 (open_clip LayerNorm) */
 } ap_vit_config;
+#define AP_POOL_CLS 0
+#define AP_POOL_ATTN 1
 
 int ap_vit_create(const ap_vit_config* cfg, ap_vit** out);
 void ap_vit_destroy(ap_vit* m);
@@ -93,12 +103,16 @@ void ap_vit_destroy(ap_vit* m);
  *   blocks.<i>.proj.weight [dim,dim] | .bias   blocks.<i>.ls1 [dim]
  *   blocks.<i>.ln2.weight|bias  blocks.<i>.fc1.weight [mlp,dim] | .bias
  *   blocks.<i>.fc2.weight [dim,mlp] | .bias    blocks.<i>.ls2 [dim]
+ * AP_POOL_ATTN adds (P = pool_dim):
+ *   attn_pool.ln_k.weight|bias [dim]   attn_pool.kv.weight [2P, dim] (rows k_proj; v_proj)   attn_pool.kv.bias [2P]
+ *   attn_pool.q [P]  (the projected query q_proj(ln_q(query)) + bias: input independent, computed by the host)
+ *   attn_pool.out.weight [P, P] | .bias [P]   attn_pool.ln_out.weight|bias [P]
  * Synchronous (copies before returning). */
 int ap_vit_set_param(ap_vit* m, const char* name, const float* host, size_t count);
 int ap_vit_finalize(ap_vit* m);   /* checks every parameter was set */
 
 size_t ap_vit_workspace_bytes(const ap_vit* m, int n);
-int ap_vit_embed_dim(const ap_vit* m);
+int ap_vit_embed_dim(const ap_vit* m);   /* dim (AP_POOL_CLS) or pool_dim (AP_POOL_ATTN) */
 
 /* Optional per-launch timing with HIP events recorded on the forward's own stream (what
  * bench.py's roofline block reads).  Off by default; when on, every kernel launch of a forward

@@ -135,3 +135,84 @@ def extract_batch(sd: dict, patches, *, heads: int, batch_size: int | None = Non
         x = preprocess_center_crop(chunk)
         outs.append(vit_forward_hf(sd, x, heads=heads, eps=eps, layer_scale=layer_scale))
     return torch.cat(outs, 0).to(torch.float32).numpy()
+
+
+# ----------------------------------------------------------------------------- CONCH v1 visual tower
+# models/patch/conch.py:20-64 calls conch.open_clip_custom.create_model_from_pretrained("conch_ViT-B-16") and
+# ``model.encode_image(x, proj_contrast=False, normalize=False)``.  The ``conch`` package is absent here (parity
+# unpinned); this restates its published structure: timm ViT-B/16 trunk at 448 px (forward_features: all tokens,
+# final LayerNorm) -> open_clip ``AttentionalPooler`` with one query -> LayerNorm.  The pooler's attention is run by
+# torch's own ``multi_head_attention_forward`` with separate q/k/v projection weights, i.e. exactly what the
+# ``nn.MultiheadAttention(d_model, n_head, kdim=context_dim, vdim=context_dim)`` inside that module executes.
+OPENAI_CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+OPENAI_CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+@torch.inference_mode()
+def vit_tokens_canonical(sd: dict, x: torch.Tensor, *, heads: int, depth: int, eps: float = 1e-6) -> torch.Tensor:
+    """timm ``VisionTransformer.forward_features`` from canonical parameter names: [n,3,S,S] -> [n, 1+P, D]."""
+    w, b = sd["patch_embed.weight"], sd["patch_embed.bias"]
+    d = w.shape[0]
+    n = x.shape[0]
+    pe = F.conv2d(x, w, b, stride=w.shape[-1]).flatten(2).transpose(1, 2)
+    tok = torch.cat([sd["cls_token"].view(1, 1, d).expand(n, -1, -1), pe], dim=1) + sd["pos_embed"][None]
+    dh = d // heads
+    for i in range(depth):
+        p = f"blocks.{i}."
+        h = F.layer_norm(tok, (d,), sd[p + "ln1.weight"], sd[p + "ln1.bias"], eps)
+        qkv = h @ sd[p + "qkv.weight"].T + sd[p + "qkv.bias"]
+        t = tok.shape[1]
+        q, k, v = qkv.view(n, t, 3, heads, dh).permute(2, 0, 3, 1, 4)
+        att = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(dh), dim=-1)
+        ctx = (att @ v).transpose(1, 2).reshape(n, t, d)
+        out = ctx @ sd[p + "proj.weight"].T + sd[p + "proj.bias"]
+        if p + "ls1" in sd:
+            out = out * sd[p + "ls1"]
+        tok = tok + out
+        h = F.layer_norm(tok, (d,), sd[p + "ln2.weight"], sd[p + "ln2.bias"], eps)
+        m = F.gelu(h @ sd[p + "fc1.weight"].T + sd[p + "fc1.bias"]) @ sd[p + "fc2.weight"].T + sd[p + "fc2.bias"]
+        if p + "ls2" in sd:
+            m = m * sd[p + "ls2"]
+        tok = tok + m
+    return F.layer_norm(tok, (d,), sd["norm.weight"], sd["norm.bias"], eps)
+
+
+@torch.inference_mode()
+def attentional_pooler(pool: dict, tokens: torch.Tensor, *, n_head: int, eps: float = 1e-5) -> torch.Tensor:
+    """open_clip ``AttentionalPooler.forward`` (transformer.py): tokens [n, L, C] -> [n, n_queries, P]."""
+    c = tokens.shape[-1]
+    p_dim = pool["attn.q_proj_weight"].shape[0]
+    x = F.layer_norm(tokens, (c,), pool["ln_k.weight"], pool["ln_k.bias"], eps).permute(1, 0, 2)     # NLD -> LND
+    n = x.shape[1]
+    q = F.layer_norm(pool["query"], (p_dim,), pool["ln_q.weight"], pool["ln_q.bias"], eps)
+    out, _ = F.multi_head_attention_forward(
+        q.unsqueeze(1).expand(-1, n, -1), x, x, p_dim, n_head, None, pool["attn.in_proj_bias"], None, None, False, 0.0,
+        pool["attn.out_proj.weight"], pool["attn.out_proj.bias"], training=False, need_weights=False,
+        use_separate_proj_weight=True, q_proj_weight=pool["attn.q_proj_weight"],
+        k_proj_weight=pool["attn.k_proj_weight"], v_proj_weight=pool["attn.v_proj_weight"])
+    return out.permute(1, 0, 2)
+
+
+def conch_preprocess(patches_u8, size: int = 448) -> torch.Tensor:
+    """open_clip image_transform(is_train=False): Resize(size, bicubic) + CenterCrop(size) + ToTensor + Normalize."""
+    from PIL import Image
+    arrs = []
+    for p in patches_u8:
+        img = Image.fromarray(np.asarray(p))
+        w, h = img.size
+        if min(w, h) != size:
+            nw, nh = (size, int(size * h / w)) if w <= h else (int(size * w / h), size)
+            img = img.resize((nw, nh), Image.Resampling.BICUBIC)
+        arrs.append(np.asarray(img))
+    return preprocess_center_crop(np.stack(arrs, 0), crop=size, mean=OPENAI_CLIP_MEAN, std=OPENAI_CLIP_STD)
+
+
+@torch.inference_mode()
+def conch_encode_image(trunk_sd: dict, pool: dict, patches_u8, *, heads: int = 12, depth: int = 12,
+                       pool_heads: int = 8, size: int = 448) -> np.ndarray:
+    """``encode_image(x, proj_contrast=False, normalize=False)``: LN(attn_pool_contrast(trunk(x))[:, 0])."""
+    x = conch_preprocess(patches_u8, size)
+    tokens = vit_tokens_canonical(trunk_sd, x, heads=heads, depth=depth)
+    pooled = attentional_pooler(pool, tokens, n_head=pool_heads)[:, 0]
+    p_dim = pooled.shape[-1]
+    return F.layer_norm(pooled, (p_dim,), pool["ln_out.weight"], pool["ln_out.bias"], 1e-5).numpy()

@@ -234,3 +234,44 @@ def test_synth_tiles_bit_exact():
     got = out.cpu().numpy()
     for i, (x, y) in enumerate(xy):
         assert np.array_equal(got[i], render_region(spec, int(x), int(y), 256, 256, 0)), i
+
+
+# ----------------------------------------------------------------------------- CONCH v1 (a16)
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 5e-3), (torch.bfloat16, 3e-2)])
+def test_conch_visual_tower_vs_oracle(dtype, tol):
+    """ViT-B/16 trunk at 448 px (785 tokens: the tiled attention kernel) + one-query attentional pooler + LN,
+    against the torch fp32 restatement whose pooler attention is torch's own multi_head_attention_forward.
+    Parity unpinned against the real package (absent); tolerance = norm-wise relative error vs the fp32 CPU path."""
+    from atlaspatch_amd.encoders.vit import (ARCHS, OPENAI_CLIP_MEAN, OPENAI_CLIP_STD, attn_pool_canonical,
+                                             build_hip_vit_extractor, random_attn_pool, random_canonical_state_dict)
+    from oracle import vit_oracle
+    from PIL import Image
+    arch = dict(ARCHS["conch_v1"]); arch["depth"] = 2
+    trunk_arch = {k: v for k, v in arch.items() if not k.startswith("pool")}
+    trunk = random_canonical_state_dict(trunk_arch, seed=11)
+    pool = random_attn_pool(arch, seed=11)
+    state = dict(trunk); state.update(attn_pool_canonical(pool))
+    rng = np.random.default_rng(5)
+    tiles = [rng.integers(0, 256, (256, 256, 3), dtype=np.uint8) for _ in range(3)]
+    want = vit_oracle.conch_encode_image(trunk, pool, tiles, heads=12, depth=2, pool_heads=8)
+    ex = build_hip_vit_extractor(name="conch_test", arch=arch, state_dict=state, source="canonical", device=_dev(),
+                                 dtype=dtype, mean=OPENAI_CLIP_MEAN, std=OPENAI_CLIP_STD,
+                                 host_resize=(448, Image.Resampling.BICUBIC), expect_size=448)
+    got = ex.extract_batch(tiles, batch_size=32)
+    ex.cleanup()
+    assert got.shape == (3, 512) and got.dtype == np.float32
+    assert _rel(got, want) <= tol, _rel(got, want)
+
+
+def test_conch_registered_and_float32_rejected():
+    from atlaspatch_amd.encoders import build_default_registry
+    from atlaspatch_amd import _lib
+    reg = build_default_registry(device="cuda", dtype=torch.float32)
+    assert "conch_v1" in reg.available()
+    import os
+    os.environ["ATLASPATCH_RANDOM_INIT"] = "3"
+    try:
+        with pytest.raises(_lib.HipLibraryError):
+            reg.create("conch_v1")          # float32: 785 tokens exceed the f32 attention kernel / pooler is f16|bf16
+    finally:
+        os.environ.pop("ATLASPATCH_RANDOM_INIT", None)

@@ -96,3 +96,26 @@ def test_tile_ring_matches_direct_forward():
     want = ex.extract_batch(list(tiles), batch_size=32)
     assert np.array_equal(got, want)
     ex.cleanup()
+
+
+def test_cli_process_conch_and_uni_fp16(tmp_path, monkeypatch):
+    """BASELINE configs 3 / 5 in miniature: `process` with uni_v1 (ViT-L/16 + LayerScale, host bicubic 224) and
+    conch_v1 (448-px trunk + attentional pooler) in float16 on one small synthetic slide -> both feature sets in
+    one H5, rows aligned with coords."""
+    from click.testing import CliRunner
+    from atlaspatch_amd.cli import cli
+    from atlaspatch_amd.utils.h5 import h5
+
+    monkeypatch.setenv("ATLASPATCH_RANDOM_INIT", "1")
+    slide, raw = _make_slide(str(tmp_path), "s2.synth", width=6000, height=5000, seed=3)
+    out = tmp_path / "out"
+    args = ["process", slide, "-o", str(out), "--patch-size", "256", "--target-mag", "20",
+            "--feature-extractors", "uni_v1,conch_v1", "--feature-precision", "float16"]
+    res = CliRunner().invoke(cli, args, catch_exceptions=False)
+    assert res.exit_code == 0 and "failures: 0" in res.output, res.output
+    with h5.File(out / "patches" / "s2.h5", "r") as f:
+        n = f["coords"].shape[0]
+        uni, conch = f["features"]["uni_v1"][:], f["features"]["conch_v1"][:]
+    assert n > 0 and uni.shape == (n, 1024) and conch.shape == (n, 512)
+    assert np.isfinite(uni).all() and np.isfinite(conch).all()
+    assert np.abs(conch).max() > 0.1 and np.unique(np.round(conch[:, 0], 3)).size > 1

@@ -5,8 +5,8 @@ Quirks kept on purpose: ``--tissue-thresh`` defaults to 0.0 here although the da
 0.01; ``--feature-precision`` defaults to float16 although the dataclass default is float32;
 ``--skip-existing`` is on by default; the group reports version 0.2.0.
 
-Differences (stated, not hidden): ``--save-images``, ``--no-fast-mode`` and the ``--visualize-*`` flags
-are accepted but not implemented in this build and raise; segmentation uses the analytic mask for
+Differences (stated, not hidden): the ``--visualize-*`` flags are accepted but not implemented in this build
+and raise (``--no-fast-mode`` and ``--save-images`` run on the device path); segmentation uses the analytic mask for
 ``.synth`` slides and needs a plugged-in ``SegmentationService`` (or SAM2 support, not in this build)
 for real slides.  When launched under ``torch.distributed.run`` slides are sharded one per rank.
 """

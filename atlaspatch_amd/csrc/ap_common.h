@@ -85,6 +85,7 @@ struct GemmArgs {
     const float* pos;        // EPI_PATCH_EMBED: [P + 1, N]
     void* out; int ldo;      // T (STORE / GELU) or f32 (RESID / PATCH_EMBED)
     int P;                   // EPI_PATCH_EMBED: patches per image
+    int ablate;              // gemm256 A/B twin only: timing ablation flags (results invalid when set)
     int skew_ticks;          // gemm256 only: start-time spread across an XCD's workgroups (100 MHz ticks)
     long long* trace;        // gemm256 diagnostics: per (workgroup, tile) 8 x 100-MHz time stamps, or null
     int trace_tiles;         //   tiles recorded per workgroup
@@ -128,6 +129,10 @@ int launch_convert(int dtype, const float* src, void* dst, size_t count, hipStre
 // [n,3,S,S] (f32 or T) -> patch rows T [n*g*g, ld]
 int launch_chw_to_patchrows(int x_dtype, int dtype, const void* x, int n, int S, int ps, void* dst,
                             int ld, hipStream_t stream);
+
+// content statistics (content.hip): counts [n, 2] = (#gray < black_thresh, #(S < sat_thresh && V >= value_thresh))
+int tile_content_counts(const uint8_t* tiles, int n, int h, int w, int black_thresh, int sat_thresh,
+                        int value_thresh, unsigned* counts, hipStream_t stream);
 
 // K1 (preproc.hip)
 int get_norm_lut(const float mean[3], const float stdv[3], int dtype, hipStream_t stream,

@@ -19,7 +19,7 @@ void set_error(const char* fmt, ...) {
 
 extern "C" {
 
-int ap_abi_version(void) { return 3; }
+int ap_abi_version(void) { return 4; }
 
 const char* ap_last_error(void) { return ap::g_error; }
 
@@ -47,6 +47,12 @@ int ap_preproc_u8hwc_to_patchrows(const uint8_t* src, int n, int h, int w, int c
                                   ap_stream_t stream) {
     return ap::preproc_patchrows(src, n, h, w, crop_top, crop_left, oh, ow, ps, mean, stdv, dst, ld,
                                  dst_dtype, (hipStream_t)stream);
+}
+
+int ap_tile_content_counts(const uint8_t* tiles, int n, int h, int w, int black_thresh, int white_sat_thresh,
+                           int white_value_thresh, uint32_t* counts, ap_stream_t stream) {
+    return ap::tile_content_counts(tiles, n, h, w, black_thresh, white_sat_thresh, white_value_thresh,
+                                   (unsigned*)counts, (hipStream_t)stream);
 }
 
 int ap_gemm(int dtype, int epilogue, const void* A, int lda, const void* W, int ldw, int M, int N,

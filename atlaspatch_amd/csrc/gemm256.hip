@@ -184,7 +184,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
         }
     };
     const uint32_t lds_wave = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + wave * 1024;
+#ifdef AP_G256_ALT
+    bool dma_off = false;
+#endif
     auto stage = [&](const Cursor& c, bool is_x, int buf, int unit) {
+#ifdef AP_G256_ALT
+        if ((g.ablate & 4) && dma_off) return;
+#endif
         const char* base = (is_x ? c.abase : c.wbase) + (size_t)c.kt * kRowBytes;
 #ifdef AP_DMA_BUILTIN
         char* dst = smem + buf * kBufBytes + unit * kUnitBytes + wave * 1024;
@@ -244,18 +250,33 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
     stage(ca, true, 1, U_X0); stage(ca, false, 1, U_Y0); advance(ca, 0);
     AP_VMCNT(8);              // X0 / Y0 of K-tile 0 have landed (phase 0 reads them)
     __builtin_amdgcn_s_barrier();
+#ifdef AP_G256_ALT
+    dma_off = true;
+#endif
 
     // Phase boundary.  The counted wait retires what was staged four phases ago (allowed in flight:
     // the 3 x 2 loads of the last three phases); the barrier publishes it and orders this phase's
     // DMA (issued after it) behind every wave's fragment reads of the unit it overwrites.  The
     // fragment reads written before it may be hoisted by the compiler into the previous phase's
     // MFMA block (everything they read was published by the previous barrier); the wait may not.
+#ifdef AP_G256_ALT
+    // ablation twin (timing only, results are wrong when a flag is set): skew_ticks bit 28 = no counted wait,
+    // bit 29 = no barrier, bit 30 = no LDS-DMA after the prologue
+    const bool abl_nowait = (g.ablate & 1) != 0, abl_nobar = (g.ablate & 2) != 0;
+#define AP_PHASE_SYNC()                             \
+    __builtin_amdgcn_sched_barrier(0);              \
+    if (wait && !abl_nowait) AP_VMCNT(6);           \
+    __builtin_amdgcn_sched_barrier(0);              \
+    if (!abl_nobar) __builtin_amdgcn_s_barrier();   \
+    __builtin_amdgcn_sched_barrier(0)
+#else
 #define AP_PHASE_SYNC()                             \
     __builtin_amdgcn_sched_barrier(0);              \
     if (wait) AP_VMCNT(6);                          \
     __builtin_amdgcn_sched_barrier(0);              \
     __builtin_amdgcn_s_barrier();                   \
     __builtin_amdgcn_sched_barrier(0)
+#endif
 #define AP_MMA(ACC, B, A) ACC = Mma<T>::run(B, A, ACC)
 #ifdef AP_NO_READ_HOIST
 #define AP_NOHOIST() __builtin_amdgcn_sched_barrier(0)
@@ -466,10 +487,11 @@ int AP_G256_FN(launch_gemm256)(int dtype, int epilogue, const GemmArgs& a, int v
     AP_REQUIRE(AP_G256_FN(gemm256_supports)(dtype, epilogue, a), "gemm256: unsupported problem");
     GemmArgs b = a;
     b.trace = g_gemm_trace; b.trace_tiles = g_gemm_trace_tiles;
-    const int skew_pct = variant >> 4;
+    const int skew_pct = (variant >> 4) & 0xfff;
     const int tiles = ((a.M + kBM - 1) / kBM) * (a.N / kBN);
     // estimated tile period in 10-ns ticks: ~1.65 us per 64-deep K-tile + epilogue
     b.skew_ticks = tiles > num_cu ? (int)((long long)((a.K / 64) * 165 + 400) * skew_pct / 100) : 0;
+    b.ablate = variant & 15;
     variant &= 15;
     return dtype == AP_F16 ? launch_typed<f16>(epilogue, b, num_cu, variant, stream)
                            : launch_typed<bf16>(epilogue, b, num_cu, variant, stream);

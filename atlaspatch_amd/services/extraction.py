@@ -8,8 +8,13 @@ reference's signature and H5 output; the work is done by the device path:
          --grid point-in-polygon + ballot compaction (HIP)--> coords int32 [N, 5]
 
 No cross-contour de-duplication and no clipping to the slide, exactly like the reference
-(SURVEY.md 9.4).  ``fast_mode=False`` content filters and ``--save-images`` are outside
-this build's scope and raise.
+(SURVEY.md 9.4).
+
+``fast_mode=False`` (reference extraction.py:105-116) and ``--save-images`` (:112-128, storage.py:163-248) read
+every candidate tile: here the tiles go through the pinned tile ring into HBM in batches, the black / white
+statistics are computed by ``ap_tile_content_counts`` (OpenCV's fixed-point RGB2GRAY / RGB2HSV, bit exact), rows
+are dropped in order with the reference's ``fraction >= 0.7`` rule, and kept tiles are written as
+``images/<stem>/<stem>_x{X}_y{Y}.png`` with Pillow exactly like ``H5PatchWriter._save_patch_image``.
 """
 from __future__ import annotations
 
@@ -21,7 +26,7 @@ import numpy as np
 
 from ..core.config import ExtractionConfig, OutputConfig
 from ..core.models import ExtractionResult, Slide
-from ..core.paths import build_run_root, patch_h5_path
+from ..core.paths import build_run_root, images_dir, patch_h5_path
 from ..core.wsi.iwsi import IWSI
 from ..utils.contours import DeviceContours
 from .geometry import PatchGeometry, prepare_geometry
@@ -86,13 +91,15 @@ class PatchExtractionService(ExtractionService):
     def extract(self, wsi: IWSI, mask: np.ndarray, *, slide: Slide) -> ExtractionResult:
         from .storage import H5PatchWriter
 
-        if not self.cfg.fast_mode:
-            raise NotImplementedError("--no-fast-mode content filters are not part of this build")
-        if self.output_cfg.save_images:
-            raise NotImplementedError("--save-images is not part of this build")
         (build_run_root(self.output_cfg, self.cfg) / "patches").mkdir(parents=True, exist_ok=True)
         out_h5 = patch_h5_path(slide, self.output_cfg, self.cfg)
         coords, geometry = self.coords(wsi, mask)
+        img_dir = None
+        if self.output_cfg.save_images:
+            img_dir = images_dir(slide, self.output_cfg, self.cfg)
+            img_dir.mkdir(parents=True, exist_ok=True)
+        if not self.cfg.fast_mode or img_dir is not None:
+            coords = self._filter_and_save(wsi, coords, slide=slide, img_dir=img_dir)
         width0, height0 = wsi.get_size(lv=0)
         step = self.cfg.step_size or self.cfg.patch_size
         extra = {"filename": slide.path.name}
@@ -106,5 +113,62 @@ class PatchExtractionService(ExtractionService):
                                slide_stem=slide.stem, wsi_path=str(wsi.path), extra_file_attrs=extra)
         total = writer.write_coords_array(out_h5, coords)
         logger.debug("Wrote %d coords for %s to %s", total, slide.path.name, out_h5)
-        return ExtractionResult(slide=slide, h5_path=Path(out_h5), num_patches=int(total), image_dir=None,
+        return ExtractionResult(slide=slide, h5_path=Path(out_h5), num_patches=int(total), image_dir=img_dir,
                                 coords=None, patch_size_level0=geometry.patch_size_level0)
+
+    # ------------------------------------------------------------------ non-fast mode / --save-images
+    def _filter_and_save(self, wsi: IWSI, coords: np.ndarray, *, slide: Slide, img_dir, batch: int = 256) -> np.ndarray:
+        """Read every candidate tile (reference extraction.py:105-128), drop black / white ones when fast_mode is
+        off, save the kept ones when ``img_dir`` is set.  Returns the kept rows, order preserved."""
+        import concurrent.futures as futures
+
+        import torch
+        from PIL import Image
+
+        from ..utils.image import tile_content_flags
+
+        if not torch.cuda.is_available():
+            from .. import _lib
+            raise _lib.HipLibraryError("--no-fast-mode / --save-images read tiles through the HIP device path; "
+                                       "no HIP device is available (there is no CPU fallback)")
+        device = torch.device("cuda", torch.cuda.current_device())
+        ps = int(self.cfg.patch_size)
+        n = int(coords.shape[0])
+        keep = np.ones(n, dtype=bool)
+        host = torch.empty((batch, ps, ps, 3), dtype=torch.uint8).pin_memory()
+        view = host.numpy()
+        writers = futures.ThreadPoolExecutor(max_workers=max(2, min(8, __import__("os").cpu_count() or 4)),
+                                             thread_name_prefix="patch-img") if img_dir is not None else None
+        readers = futures.ThreadPoolExecutor(max_workers=4, thread_name_prefix="tile")
+        pending = []
+
+        def read(i, row):
+            x, y, rw, rh, lv = (int(v) for v in row)
+            tile = wsi.extract((x, y), lv=lv, wh=(rw, rh), mode="array")
+            if tile.shape[0] != ps or tile.shape[1] != ps:
+                raise NotImplementedError("tiles that need cv2.resize to patch_size are not part of this build")
+            view[i] = tile
+
+        try:
+            for lo in range(0, n, batch):
+                hi = min(n, lo + batch)
+                list(readers.map(lambda i: read(i - lo, coords[i]), range(lo, hi)))
+                if not self.cfg.fast_mode:
+                    tiles = host[:hi - lo].to(device, non_blocking=False)
+                    black, white = tile_content_flags(tiles, black_thresh=self.cfg.black_threshold,
+                                                      white_thresh=self.cfg.white_threshold)
+                    keep[lo:hi] = ~(black | white)          # is_black first, then is_white (extraction.py:113-116)
+                if writers is not None:
+                    for i in range(lo, hi):
+                        if keep[i]:
+                            x, y = int(coords[i, 0]), int(coords[i, 1])
+                            pending.append(writers.submit(
+                                lambda arr, path: Image.fromarray(arr).save(str(path)), view[i - lo].copy(),
+                                img_dir / f"{slide.stem}_x{x}_y{y}.png"))
+            for f in pending:
+                f.result()
+        finally:
+            readers.shutdown(wait=True)
+            if writers is not None:
+                writers.shutdown(wait=True)
+        return np.ascontiguousarray(coords[keep])

@@ -63,6 +63,16 @@ int ap_preproc_u8hwc_to_patchrows(const uint8_t* src, int n, int h, int w,
                                   const float mean[3], const float stdv[3],
                                   void* dst, int ld, int dst_dtype, ap_stream_t stream);
 
+/* ---- tile content statistics (--no-fast-mode filters) -------------------------------
+ * Replaces utils/image.py:7-41 (is_black_patch / is_white_patch), which services/extraction.py:112-116
+ * applies to every candidate tile: counts[i] = { #pixels with cv2 RGB2GRAY < black_thresh,
+ * #pixels with cv2 RGB2HSV S < white_sat_thresh and V >= white_value_thresh } (OpenCV's 8-bit fixed-point
+ * conversions, bit-exact).  The caller compares count / (h*w) with 0.7 like the reference.
+ * tiles: device uint8 [n, h, w, 3] (16-byte aligned, h*w % 16 == 0); counts: device uint32 [n, 2]. */
+int ap_tile_content_counts(const uint8_t* tiles, int n, int h, int w, int black_thresh,
+                           int white_sat_thresh, int white_value_thresh, uint32_t* counts,
+                           ap_stream_t stream);
+
 /* ---- ViT encoder -------------------------------------------------------------------
  * Replaces `forward_fn(batch) or model(batch)` of models/patch/base.py:100 for the
  * ViT family the reference registers as vit_b_16 / vit_l_16 (models/patch/vit.py:9-38)

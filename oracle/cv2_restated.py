@@ -264,3 +264,41 @@ def pointPolygonTest_scalar(contour, pt) -> int:
             dist = -dist
         counter += dist > 0
     return -1 if counter % 2 == 0 else 1
+
+
+# ----------------------------------------------------------------------------- colour conversions (8-bit)
+# Used by atlas_patch/utils/image.py:14,33 (is_black_patch / is_white_patch), which
+# services/extraction.py:112-116 applies to every candidate tile when fast_mode is off.
+# OpenCV's 8-bit paths are integer fixed point (modules/imgproc/src/color_yuv / color_hsv):
+#   RGB2GRAY: gray = descale(R*4899 + G*9617 + B*1868, 14) = (... + (1 << 13)) >> 14
+#   RGB2HSV (hrange 180):  V = max, diff = V - min,
+#             S = (diff * sdiv_table[V] + (1 << 11)) >> 12,  sdiv_table[v] = saturate_cast<int>((255 << 12) / (1. * v))
+#             (saturate_cast<int>(double) = cvRound: round half to even), sdiv_table[0] = 0.
+_SDIV = np.zeros(256, np.int64)
+_SDIV[1:] = np.rint((255 << 12) / np.arange(1, 256, dtype=np.float64)).astype(np.int64)
+
+
+def cvtColor_RGB2GRAY(rgb: np.ndarray) -> np.ndarray:
+    a = rgb.astype(np.int64)
+    return ((a[..., 0] * 4899 + a[..., 1] * 9617 + a[..., 2] * 1868 + (1 << 13)) >> 14).astype(np.uint8)
+
+
+def cvtColor_RGB2HSV_sv(rgb: np.ndarray):
+    """(S, V) planes of cv2.cvtColor(rgb, COLOR_RGB2HSV) for uint8 input (H is not used by the path)."""
+    a = rgb.astype(np.int64)
+    v = a.max(-1)
+    diff = v - a.min(-1)
+    s = (diff * _SDIV[v] + (1 << 11)) >> 12
+    return s.astype(np.uint8), v.astype(np.uint8)
+
+
+def is_black_patch(patch: np.ndarray, rgb_thresh: int = 40, min_fraction: float = 0.7) -> bool:
+    """utils/image.py:7-18."""
+    gray = cvtColor_RGB2GRAY(patch)
+    return bool(float((gray < rgb_thresh).mean()) >= float(min_fraction))
+
+
+def is_white_patch(patch: np.ndarray, sat_thresh: int = 5, min_fraction: float = 0.7, value_thresh: int = 200) -> bool:
+    """utils/image.py:21-41."""
+    s, v = cvtColor_RGB2HSV_sv(patch)
+    return bool(float(((s < sat_thresh) & (v >= value_thresh)).mean()) >= float(min_fraction))

@@ -119,3 +119,41 @@ def test_cli_process_conch_and_uni_fp16(tmp_path, monkeypatch):
     assert n > 0 and uni.shape == (n, 1024) and conch.shape == (n, 512)
     assert np.isfinite(uni).all() and np.isfinite(conch).all()
     assert np.abs(conch).max() > 0.1 and np.unique(np.round(conch[:, 0], 3)).size > 1
+
+
+def test_cli_no_fast_mode_and_save_images(tmp_path):
+    """segment-and-get-coords --no-fast-mode --save-images: rows = oracle coords minus tiles the cv2-restated
+    is_black / is_white reject (reference extraction.py:105-116), one PNG per kept row with the tile's pixels."""
+    from click.testing import CliRunner
+    from PIL import Image
+    from atlaspatch_amd.cli import cli
+    from atlaspatch_amd.core.wsi.synth_pixels import SynthSpec, analytic_mask, render_region
+    from atlaspatch_amd.utils.h5 import h5
+    from oracle import coords_oracle, cv2_restated as cv2r
+
+    slide, raw = _make_slide(str(tmp_path), "s3.synth", width=9000, height=7000, seed=11)
+    out = tmp_path / "out"
+    res = CliRunner().invoke(cli, ["segment-and-get-coords", slide, "-o", str(out), "--patch-size", "256",
+                                   "--target-mag", "20", "--no-fast-mode", "--save-images"], catch_exceptions=False)
+    assert res.exit_code == 0 and "failures: 0" in res.output, res.output
+    spec = SynthSpec(width=raw["width"], height=raw["height"], seed=raw["seed"])
+    cand, _ = coords_oracle.coords_from_mask(analytic_mask(spec), level0_wh=(spec.width, spec.height),
+                                             downsamples=[1.0, 4.0, 16.0], src_mag=20, tgt_mag=20, patch_size=256,
+                                             step_size=None, tissue_thresh=0.0)
+    keep = []
+    for row in cand:
+        tile = render_region(spec, int(row[0]), int(row[1]), 256, 256, 0)
+        if cv2r.is_black_patch(tile, rgb_thresh=50) or cv2r.is_white_patch(tile, sat_thresh=15):
+            continue
+        keep.append(row)
+    want = np.asarray(keep, np.int32).reshape(-1, 5)
+    with h5.File(out / "patches" / "s3.h5", "r") as f:
+        got = f["coords"][:]
+        assert f.attrs["num_patches"] == got.shape[0]
+    assert 0 < want.shape[0] < cand.shape[0], "the slide should have both kept and rejected candidate tiles"
+    assert np.array_equal(got, want)
+    pngs = sorted((out / "images" / "s3").glob("*.png"))
+    assert len(pngs) == want.shape[0]
+    x, y = int(want[3, 0]), int(want[3, 1])
+    img = np.asarray(Image.open(out / "images" / "s3" / f"s3_x{x}_y{y}.png"))
+    assert np.array_equal(img, render_region(spec, x, y, 256, 256, 0))

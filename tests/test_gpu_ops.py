@@ -153,3 +153,32 @@ def test_operator_error_paths(env):
                        stream) == -1
     assert lib.ap_attention(1, x.data_ptr(), x.data_ptr(), 1, 4, 1, 32, stream) == -1     # head_dim != 64
     assert b"head_dim" in lib.ap_last_error()
+
+
+def test_tile_content_counts_bit_exact_vs_cv2_restatement(env):
+    """--no-fast-mode filters: device counts == the integer restatement of cv2's RGB2GRAY / RGB2HSV on the host."""
+    from atlaspatch_amd.utils.image import tile_content_counts, tile_content_flags
+    from oracle import cv2_restated as cv2r
+    _lib, lib, dev, stream = env
+    rng = np.random.default_rng(0)
+    tiles = rng.integers(0, 256, (9, 256, 256, 3), dtype=np.uint8)
+    tiles[1] = 0                                                    # black
+    tiles[2] = 245                                                  # white
+    tiles[3] = rng.integers(230, 256, (256, 256, 1), dtype=np.uint8)   # bright greys: S = 0
+    tiles[4] = rng.integers(0, 60, (256, 256, 3), dtype=np.uint8)  # dark noise around the black threshold
+    tiles[5, :, :, 0] = 250; tiles[5, :, :, 1] = rng.integers(236, 251, (256, 256)); tiles[5, :, :, 2] = 246   # S near threshold
+    tiles[6, :180] = 255                                            # 70.3 % white rows
+    tiles[7, :179] = 255                                            # 69.9 %
+    d = torch.from_numpy(tiles).to(dev)
+    for bt, st in ((50, 15), (40, 5), (1, 1), (255, 255)):
+        got = tile_content_counts(d, black_thresh=bt, sat_thresh=st)
+        want = np.zeros((9, 2), np.int64)
+        for i, t in enumerate(tiles):
+            want[i, 0] = int((cv2r.cvtColor_RGB2GRAY(t) < bt).sum())
+            s, v = cv2r.cvtColor_RGB2HSV_sv(t)
+            want[i, 1] = int(((s < st) & (v >= 200)).sum())
+        assert np.array_equal(got, want), (bt, st)
+    black, white = tile_content_flags(d, black_thresh=50, white_thresh=15)
+    assert [bool(cv2r.is_black_patch(t, rgb_thresh=50)) for t in tiles] == black.tolist()
+    assert [bool(cv2r.is_white_patch(t, sat_thresh=15)) for t in tiles] == white.tolist()
+    assert black[1] and white[2] and white[6] and not white[7]

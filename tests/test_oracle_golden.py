@@ -163,3 +163,21 @@ def test_vit_oracle_matches_reference_extract_batch(golden_dir):
         if n:
             ref = g[f"L2_n{n}_out"]
             assert np.linalg.norm(out - ref) / np.linalg.norm(ref) < 2e-5
+
+
+def test_cv2_colour_restatement_known_answers():
+    """Known-answer values of OpenCV's 8-bit RGB2GRAY / RGB2HSV (documented BT.601 weights and the
+    255 * (max - min) / max saturation, both in fixed point with round-to-nearest)."""
+    from oracle import cv2_restated as cv2r
+    px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255], [0, 0, 0], [128, 64, 64], [10, 200, 30],
+                    [201, 200, 199], [199, 199, 199]]], np.uint8)
+    assert cv2r.cvtColor_RGB2GRAY(px)[0].tolist() == [76, 150, 29, 255, 0, 83, 124, 200, 199]
+    s, v = cv2r.cvtColor_RGB2HSV_sv(px)
+    assert v[0].tolist() == [255, 255, 255, 255, 0, 128, 200, 201, 199]
+    assert s[0].tolist() == [255, 255, 255, 0, 0, 128, 242, 3, 0]
+    white = np.full((8, 8, 3), 240, np.uint8)
+    black = np.full((8, 8, 3), 20, np.uint8)
+    assert cv2r.is_white_patch(white, sat_thresh=15) and not cv2r.is_black_patch(white, rgb_thresh=50)
+    assert cv2r.is_black_patch(black, rgb_thresh=50) and not cv2r.is_white_patch(black, sat_thresh=15)
+    mixed = white.copy(); mixed[:3] = (200, 30, 30)             # 62.5 % white < 0.7
+    assert not cv2r.is_white_patch(mixed, sat_thresh=15)

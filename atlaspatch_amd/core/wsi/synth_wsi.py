@@ -72,6 +72,34 @@ class SynthWSI(IWSI):
             return Image.fromarray(region)
         raise ValueError(f"Invalid mode: {mode}")
 
+    def extract_batch_device(self, rows: np.ndarray, device, patch_size: int):
+        """Optional IWSI capability (device tile source): uint8 [n, ps, ps, 3] in HBM for coords rows
+        (x, y, read_w, read_h, level), or None when the backend cannot serve them on the device.  The synthetic
+        slide's pixel function runs as ``ap_synth_tiles`` (bit-identical to ``render_region``, tested), which
+        stands in for a GPU tile decoder; real backends decode on the host and go through the tile ring."""
+        import torch
+        from ... import _lib
+        self._ensure_loaded()
+        rows = np.asarray(rows)
+        if rows.size == 0:
+            return torch.empty((0, patch_size, patch_size, 3), dtype=torch.uint8, device=device)
+        lv = int(rows[0, 4])
+        if np.any(rows[:, 4] != lv) or np.any(rows[:, 2] != patch_size) or np.any(rows[:, 3] != patch_size):
+            return None
+        lib = _lib.load()
+        cache = getattr(self, "_dev_ellipses", None)
+        if cache is None or cache.device != torch.device(device):
+            cache = torch.from_numpy(self.spec.ellipses()).to(device)
+            self._dev_ellipses = cache
+        xy = torch.from_numpy(np.ascontiguousarray(rows[:, :2], dtype=np.int32)).to(device)
+        tiles = torch.empty((rows.shape[0], patch_size, patch_size, 3), dtype=torch.uint8, device=device)
+        with torch.cuda.device(device):
+            _lib.check(lib.ap_synth_tiles(xy.data_ptr(), rows.shape[0], patch_size, int(round(self.ds[lv])), lv,
+                                          self.spec.width, self.spec.height, self.spec.seed, cache.data_ptr(),
+                                          cache.shape[0], tiles.data_ptr(), _lib.current_stream_ptr(device)),
+                       "ap_synth_tiles")
+        return tiles
+
     def get_size(self, lv: int = 0) -> Tuple[int, int]:
         self._ensure_loaded()
         return self.dims[lv]

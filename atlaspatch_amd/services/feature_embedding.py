@@ -200,15 +200,34 @@ class PatchFeatureEmbeddingService(FeatureEmbeddingService):
         from .tile_ring import TileRing
         coords = read_coords(result.h5_path)
         batch = max(self.feature_cfg.batch_size, min(1024, max(1, coords.shape[0])))
+        feats = self._embed_device_source(coords, wsi, extractor, batch)
+        if feats is not None:
+            return feats
         if self._ring is None or self._ring.batch != batch or self._ring.ps != self.cfg.patch_size:
             if self._ring is not None:
                 self._ring.close()
             self._ring = TileRing(device=extractor.device, batch=batch, patch_size=self.cfg.patch_size,
-                                  slots=2, workers=max(1, self.feature_cfg.num_workers))
+                                  slots=3, workers=max(1, self.feature_cfg.num_workers))
         with torch.cuda.device(extractor.device):
             return self._ring.run(coords, self._read_tile(wsi),
                                   lambda tiles, out: extractor.vit.forward_u8(tiles, extractor.mean, extractor.std, out),
                                   extractor.embedding_dim)
+
+    def _embed_device_source(self, coords: np.ndarray, wsi: IWSI, extractor, batch: int):
+        """Backends that can materialise tiles in HBM themselves (``extract_batch_device``, e.g. the synthetic
+        slide) skip the host ring: tiles never cross PCIe.  ATLASPATCH_HOST_TILES=1 forces the ring."""
+        source = getattr(wsi, "extract_batch_device", None)
+        if source is None or os.environ.get("ATLASPATCH_HOST_TILES"):
+            return None
+        n = int(coords.shape[0])
+        out = torch.empty((n, extractor.embedding_dim), dtype=torch.float32, device=extractor.device)
+        with torch.cuda.device(extractor.device):
+            for lo in range(0, n, batch):
+                tiles = source(coords[lo:lo + batch], extractor.device, self.cfg.patch_size)
+                if tiles is None:
+                    return None
+                extractor.vit.forward_u8(tiles, extractor.mean, extractor.std, out[lo:lo + tiles.shape[0]])
+            return out.cpu().numpy()
 
     def embed_all(self, results: list[ExtractionResult], *, wsi_loader, progress=None) -> list[tuple]:
         failures: list[tuple] = []

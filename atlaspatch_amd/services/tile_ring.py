@@ -8,7 +8,8 @@ Replaces the reference's serial main-thread tile loop (services/feature_embeddin
         -> encoder forward on the compute stream (waits on the copy event)
         -> features copied back asynchronously into a pinned [N, D] matrix
 
-A slot is reused only after the forward that read it has finished (event).  The ring is sized
+A pinned host slot is refilled as soon as its H2D copy has completed; the device slot is reused only after the
+forward that read it has finished (the copy stream waits on that event, the CPU does not).  The ring is sized
 in tiles, not bytes: ``slots x batch`` tiles of ``ps x ps x 3`` bytes (2 x 1024 x 196 608 B =
 403 MB pinned at the defaults), trivial next to 288 GB of HBM, and deep enough to cover the
 ~ms-scale decode latency of real slides.
@@ -23,7 +24,7 @@ import torch
 
 
 class TileRing:
-    def __init__(self, *, device: torch.device, batch: int, patch_size: int, slots: int = 2,
+    def __init__(self, *, device: torch.device, batch: int, patch_size: int, slots: int = 3,
                  workers: int = 4) -> None:
         self.device = device
         self.batch = int(batch)
@@ -35,7 +36,8 @@ class TileRing:
                     for _ in range(self.slots)]
         self.copy_stream = torch.cuda.Stream(device=device)
         self.free_events: list[torch.cuda.Event | None] = [None] * self.slots
-        self.pool = futures.ThreadPoolExecutor(max_workers=max(1, int(workers)), thread_name_prefix="tile")
+        self.workers = max(1, int(workers))
+        self.pool = futures.ThreadPoolExecutor(max_workers=self.workers, thread_name_prefix="tile")
 
     def run(self, coords: np.ndarray, read_tile: Callable[[int, int, int, int, int], np.ndarray],
             forward: Callable[[torch.Tensor, torch.Tensor], None], out_dim: int) -> np.ndarray:
@@ -55,18 +57,21 @@ class TileRing:
         def fill(slot: int, b: int):
             lo, hi = b * self.batch, min(n_total, (b + 1) * self.batch)
             view = self.host[slot].numpy()
+            count = hi - lo
+            chunk = max(1, -(-count // (4 * self.workers)))          # a few tasks per worker, not one per tile
 
-            def one(i):
-                x, y, rw, rh, lv = (int(v) for v in coords[lo + i])
-                view[i] = read_tile(x, y, rw, rh, lv)
+            def some(start):
+                for i in range(start, min(count, start + chunk)):
+                    x, y, rw, rh, lv = (int(v) for v in coords[lo + i])
+                    view[i] = read_tile(x, y, rw, rh, lv)
 
-            return [self.pool.submit(one, i) for i in range(hi - lo)], hi - lo
+            return [self.pool.submit(some, s) for s in range(0, count, chunk)], count
 
         pending = {}
-        ahead = min(nb, self.slots)
-        for b in range(ahead):                       # prime the ring
+        for b in range(min(nb, self.slots)):         # prime the ring
             if self.free_events[b % self.slots] is not None:
                 self.free_events[b % self.slots].synchronize()
+                self.free_events[b % self.slots] = None
             pending[b] = fill(b % self.slots, b)
         for b in range(nb):
             slot = b % self.slots
@@ -74,6 +79,8 @@ class TileRing:
             for t in tasks:
                 t.result()
             with torch.cuda.stream(self.copy_stream):
+                if self.free_events[slot] is not None:           # device slot: the forward that read it is done
+                    self.copy_stream.wait_event(self.free_events[slot])
                 self.dev[slot][:count].copy_(self.host[slot][:count], non_blocking=True)
                 copied = torch.cuda.Event()
                 copied.record(self.copy_stream)
@@ -86,10 +93,9 @@ class TileRing:
             self.free_events[slot] = done
             nxt = b + self.slots
             if nxt < nb:
-                # the host slot may be refilled once its H2D copy has completed
+                # the pinned host slot may be refilled as soon as its H2D copy has completed; the device slot is
+                # protected by the copy stream waiting on `done` above, so the CPU never waits for a forward
                 copied.synchronize()
-                # ... and the device slot + out buffer are reused only after `done`
-                done.synchronize()
                 pending[nxt] = fill(slot, nxt)
         torch.cuda.synchronize(self.device)
         return out_host.numpy()

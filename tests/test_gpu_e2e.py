@@ -157,3 +157,26 @@ def test_cli_no_fast_mode_and_save_images(tmp_path):
     x, y = int(want[3, 0]), int(want[3, 1])
     img = np.asarray(Image.open(out / "images" / "s3" / f"s3_x{x}_y{y}.png"))
     assert np.array_equal(img, render_region(spec, x, y, 256, 256, 0))
+
+
+def test_device_tile_source_equals_host_ring(tmp_path, monkeypatch):
+    """Synthetic slides serve tiles straight from HBM (extract_batch_device -> ap_synth_tiles); the features must
+    be bit-identical to the host path (render_region -> pinned ring -> H2D)."""
+    from click.testing import CliRunner
+    from atlaspatch_amd.cli import cli
+    from atlaspatch_amd.utils.h5 import h5
+
+    monkeypatch.setenv("ATLASPATCH_RANDOM_INIT", "2")
+    slide, _ = _make_slide(str(tmp_path), "s4.synth", width=8000, height=6000, seed=5)
+    feats = {}
+    for mode in ("device", "host"):
+        if mode == "host":
+            monkeypatch.setenv("ATLASPATCH_HOST_TILES", "1")
+        out = tmp_path / mode
+        res = CliRunner().invoke(cli, ["process", slide, "-o", str(out), "--patch-size", "256", "--target-mag", "20",
+                                       "--feature-extractors", "vit_b_16", "--feature-precision", "float16",
+                                       "--feature-num-workers", "4"], catch_exceptions=False)
+        assert res.exit_code == 0 and "failures: 0" in res.output, res.output
+        with h5.File(out / "patches" / "s4.h5", "r") as f:
+            feats[mode] = f["features"]["vit_b_16"][:]
+    assert feats["device"].shape[0] > 0 and np.array_equal(feats["device"], feats["host"])

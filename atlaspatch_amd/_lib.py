@@ -62,6 +62,22 @@ SIGNATURES = {
     "ap_layernorm": (C.c_int, [C.c_int, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                C.c_float, C.c_void_p, C.c_void_p]),
     "ap_attention": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ap_sgemm": (C.c_int, [C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_int, C.c_int,
+                           C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.c_long,
+                           C.c_void_p, C.c_long, C.c_long, C.c_void_p]),
+    "ap_softmax_rows": (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]),
+    "ap_sam2_patchify": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p,
+                                   C.c_void_p]),
+    "ap_window_partition": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "ap_window_unpartition": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "ap_maxpool2x2": (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "ap_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ap_add_rowvec": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "ap_gelu": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ap_upsample2x_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ap_convt2x2_shuffle": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p]),
+    "ap_bilinear_up4_threshold": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "ap_contours_from_mask": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_double,
                                         C.c_double, C.POINTER(C.c_void_p), C.c_void_p]),
     "ap_contours_destroy": (None, [C.c_void_p]),

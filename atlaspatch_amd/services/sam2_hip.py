@@ -1,0 +1,334 @@
+"""SAM2.1 Hiera-T image path on the HIP float32 operator set (reference: services/segmentation.py:25-180).
+
+``Sam2HipPredictor`` mirrors ``_SAM2Predictor``: ``predict_image(thumbnail)`` = PIL BILINEAR resize to 1024 x 1024,
+``set_image`` + ``predict(box=[0, 0, w, h], multimask_output=False, return_logits=False)``, PIL NEAREST resize of the
+mask back to the thumbnail.  The network itself (Hiera trunk, FpnNeck, prompt encoder, two-way mask decoder, see
+oracle/sam2_oracle.py for the structure and its sources) runs as a chain of the C-ABI kernels in
+``csrc/sam2_ops.hip`` plus ``ap_layernorm``: torch only owns the device buffers.  Everything that depends on the
+weights alone is folded on the host once: positional embedding (bicubic background + tiled window), the box-prompt
+tokens of the constant box, the dense positional encoding, ``no_mask_embed`` / ``no_mem_embed`` sums.
+
+There is no CPU fallback: without the library or a HIP device construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+MEAN = (0.485, 0.456, 0.406)
+STD = (0.229, 0.224, 0.225)
+STAGES = (1, 2, 7, 2)
+EMBED = 96
+WINDOW_SPEC = (8, 4, 14, 7)
+GLOBAL_BLOCKS = (5, 7, 9)
+
+
+def block_plan():
+    """[(dim_in, dim_out, heads, window, q_pool)] per block + stage ends (sam2 hieradet.py Hiera.__init__)."""
+    stage_ends = [sum(STAGES[:i]) - 1 for i in range(1, len(STAGES) + 1)]
+    q_pool_blocks = [x + 1 for x in stage_ends[:-1]][:3]
+    plan, dim, heads, cur = [], EMBED, 1, 1
+    for i in range(sum(STAGES)):
+        dim_out, window = dim, WINDOW_SPEC[cur - 1]              # the window size lags by one block
+        if i in GLOBAL_BLOCKS:
+            window = 0
+        if i - 1 in stage_ends:
+            dim_out, heads, cur = dim * 2, heads * 2, cur + 1
+        plan.append((dim, dim_out, heads, window, i in q_pool_blocks))
+        dim = dim_out
+    return plan, stage_ends
+
+
+class Sam2HipPredictor:
+    def __init__(self, state_dict: dict, *, device="cuda", mask_threshold: float = 0.0) -> None:
+        self.device = torch.device(device)
+        if self.device.type != "cuda" or not torch.cuda.is_available():
+            raise _lib.HipLibraryError("the SAM2 segmenter needs a HIP device ('cuda' on PyTorch-ROCm); there is no CPU fallback")
+        self.lib = _lib.load()
+        self.mask_threshold = float(mask_threshold)
+        self.input_size = 1024
+        self.plan, self.stage_ends = block_plan()
+        f = lambda t: t.detach().to(torch.float32).contiguous()
+        sd = {k: f(v) for k, v in state_dict.items()}
+        dev = lambda t: t.to(self.device).contiguous()
+        self.w = {}
+        t = "image_encoder.trunk."
+        self.w["pe.w"] = dev(sd[t + "patch_embed.proj.weight"].reshape(EMBED, 147))
+        self.w["pe.b"] = dev(sd[t + "patch_embed.proj.bias"])
+        # positional embedding: weights only -> folded once (hieradet.py _get_pos_embed)
+        pos = torch.nn.functional.interpolate(sd[t + "pos_embed"], size=(256, 256), mode="bicubic")
+        win = sd[t + "pos_embed_window"]
+        pos = pos + win.tile([x // y for x, y in zip(pos.shape, win.shape)])
+        self.w["pos"] = dev(pos.permute(0, 2, 3, 1).reshape(256 * 256, EMBED))
+        for i, (din, dout, heads, window, qpool) in enumerate(self.plan):
+            b = f"{t}blocks.{i}."
+            for name in ("norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight",
+                         "attn.proj.bias", "norm2.weight", "norm2.bias", "mlp.layers.0.weight", "mlp.layers.0.bias",
+                         "mlp.layers.1.weight", "mlp.layers.1.bias"):
+                self.w[f"b{i}.{name}"] = dev(sd[b + name])
+            if din != dout:
+                self.w[f"b{i}.proj.weight"] = dev(sd[b + "proj.weight"]); self.w[f"b{i}.proj.bias"] = dev(sd[b + "proj.bias"])
+        for n in range(4):
+            self.w[f"neck{n}.w"] = dev(sd[f"image_encoder.neck.convs.{n}.conv.weight"].reshape(256, -1))
+            self.w[f"neck{n}.b"] = dev(sd[f"image_encoder.neck.convs.{n}.conv.bias"])
+        d = "sam_mask_decoder."
+        self.w["s0.w"] = dev(sd[d + "conv_s0.weight"].reshape(32, 256)); self.w["s0.b"] = dev(sd[d + "conv_s0.bias"])
+        self.w["s1.w"] = dev(sd[d + "conv_s1.weight"].reshape(64, 256)); self.w["s1.b"] = dev(sd[d + "conv_s1.bias"])
+        # image embedding gets no_mem_embed (directly_add_no_mem_embed) and, inside the decoder, no_mask_embed: one vector
+        self.w["embed_add"] = dev(sd["no_mem_embed"].reshape(256) + sd["sam_prompt_encoder.no_mask_embed.weight"].reshape(256))
+        sparse, dense_pe = self._prompt_constants(sd)
+        tokens = torch.cat([sd[d + "obj_score_token.weight"], sd[d + "iou_token.weight"], sd[d + "mask_tokens.weight"], sparse], 0)
+        self.w["tokens"] = dev(tokens)                       # [9, 256]
+        self.w["image_pe"] = dev(dense_pe)                   # [4096, 256]
+        for l in range(2):
+            b = f"{d}transformer.layers.{l}."
+            for a in ("self_attn", "cross_attn_token_to_image", "cross_attn_image_to_token"):
+                for pj in ("q_proj", "k_proj", "v_proj", "out_proj"):
+                    self.w[f"d{l}.{a}.{pj}.w"] = dev(sd[b + f"{a}.{pj}.weight"]); self.w[f"d{l}.{a}.{pj}.b"] = dev(sd[b + f"{a}.{pj}.bias"])
+            for k in range(1, 5):
+                self.w[f"d{l}.norm{k}.w"] = dev(sd[b + f"norm{k}.weight"]); self.w[f"d{l}.norm{k}.b"] = dev(sd[b + f"norm{k}.bias"])
+            for k in range(2):
+                self.w[f"d{l}.mlp{k}.w"] = dev(sd[b + f"mlp.layers.{k}.weight"]); self.w[f"d{l}.mlp{k}.b"] = dev(sd[b + f"mlp.layers.{k}.bias"])
+        for pj in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            self.w[f"dfin.{pj}.w"] = dev(sd[d + f"transformer.final_attn_token_to_image.{pj}.weight"])
+            self.w[f"dfin.{pj}.b"] = dev(sd[d + f"transformer.final_attn_token_to_image.{pj}.bias"])
+        self.w["dfin.norm.w"] = dev(sd[d + "transformer.norm_final_attn.weight"]); self.w["dfin.norm.b"] = dev(sd[d + "transformer.norm_final_attn.bias"])
+        # ConvTranspose2d weight [Cin, Cout, 2, 2] -> GEMM weight [Cout * 4, Cin] (row co * 4 + dy * 2 + dx)
+        self.w["up0.w"] = dev(sd[d + "output_upscaling.0.weight"].permute(1, 2, 3, 0).reshape(64 * 4, 256))
+        self.w["up0.b"] = dev(sd[d + "output_upscaling.0.bias"])
+        self.w["up1.w"] = dev(sd[d + "output_upscaling.1.weight"]); self.w["up1.b"] = dev(sd[d + "output_upscaling.1.bias"])
+        self.w["up3.w"] = dev(sd[d + "output_upscaling.3.weight"].permute(1, 2, 3, 0).reshape(32 * 4, 64))
+        self.w["up3.b"] = dev(sd[d + "output_upscaling.3.bias"])
+        for k in range(3):
+            self.w[f"hyper{k}.w"] = dev(sd[d + f"output_hypernetworks_mlps.0.layers.{k}.weight"])
+            self.w[f"hyper{k}.b"] = dev(sd[d + f"output_hypernetworks_mlps.0.layers.{k}.bias"])
+
+    # ------------------------------------------------------------------ constants of the box prompt
+    @staticmethod
+    def _prompt_constants(sd: dict, size: int = 1024):
+        p = "sam_prompt_encoder."
+        g = sd[p + "pe_layer.positional_encoding_gaussian_matrix"]
+
+        def pe(coords01):
+            c = 2 * math.pi * ((2 * coords01 - 1) @ g)
+            return torch.cat([torch.sin(c), torch.cos(c)], dim=-1)
+
+        # box [0, 0, size, size] -> corners + 0.5 (labels 2, 3) and one padding point (label -1, encoding zeroed)
+        pts = torch.tensor([[0.5, 0.5], [size + 0.5, size + 0.5], [0.0, 0.0]])
+        emb = pe(pts / float(size))
+        emb[2] = sd[p + "not_a_point_embed.weight"][0]
+        emb[0] += sd[p + "point_embeddings.2.weight"][0]
+        emb[1] += sd[p + "point_embeddings.3.weight"][0]
+        grid = (torch.arange(64, dtype=torch.float32) + 0.5) / 64
+        yy, xx = torch.meshgrid(grid, grid, indexing="ij")
+        return emb, pe(torch.stack([xx, yy], dim=-1)).reshape(4096, 256)
+
+    # ------------------------------------------------------------------ thin op wrappers (device pointers only)
+    def _buf(self, *shape) -> torch.Tensor:
+        return torch.empty(shape, dtype=torch.float32, device=self.device)
+
+    def _stream(self):
+        return _lib.current_stream_ptr(self.device)
+
+    def _gemm(self, a, w, n, k, *, bias=None, act=0, resid=None, out=None, m=None, lda=None, ldw=None, ldo=None, ldr=None,
+              batch=1, sa=0, sw=0, so=0, sr=0, w_kn=False, alpha=1.0):
+        m = a.shape[0] if m is None else m
+        out = self._buf(m, n) if out is None else out
+        _lib.check(self.lib.ap_sgemm(a.data_ptr(), lda if lda is not None else k, sa, w.data_ptr(),
+                                     ldw if ldw is not None else (n if w_kn else k), sw, 1 if w_kn else 0, batch, m, n, k,
+                                     C.c_float(alpha), bias.data_ptr() if bias is not None else None, act,
+                                     resid.data_ptr() if resid is not None else None, ldr if ldr is not None else n, sr,
+                                     out.data_ptr(), ldo if ldo is not None else n, so, self._stream()), "ap_sgemm")
+        return out
+
+    def _ln(self, x, rows, dim, w, b, eps, out=None):
+        out = self._buf(rows, dim) if out is None else out
+        _lib.check(self.lib.ap_layernorm(_lib.AP_F32, x.data_ptr(), dim, rows, dim, w.data_ptr(), b.data_ptr(), C.c_float(eps),
+                                         out.data_ptr(), self._stream()), "ap_layernorm")
+        return out
+
+    def _attention(self, q, k, v, *, nb, heads, tq, tk, d, ldq, ldk, ldv):
+        """q [nb*tq, ldq], k / v [nb*tk, ld*] with head h at column h*d  ->  [nb*tq, heads*d]."""
+        out = self._buf(nb * tq, heads * d)
+        scores = self._buf(nb * heads, tq, tk)
+        scale = 1.0 / math.sqrt(d)
+        for h in range(heads):          # batched over windows; heads are column offsets
+            qh, kh, vh = q[:, h * d:], k[:, h * d:], v[:, h * d:]
+            sh = scores[h * nb:]
+            self._gemm(qh, kh, tk, d, m=tq, lda=ldq, ldw=ldk, out=sh, ldo=tk, batch=nb, sa=tq * ldq, sw=tk * ldk, so=tq * tk,
+                       alpha=scale)
+            _lib.check(self.lib.ap_softmax_rows(sh.data_ptr(), tk, nb * tq, tk, self._stream()), "ap_softmax_rows")
+            self._gemm(sh, vh, d, tk, m=tq, lda=tk, ldw=ldv, out=out[:, h * d:], ldo=heads * d, batch=nb, sa=tq * tk,
+                       sw=tk * ldv, so=tq * heads * d, w_kn=True)
+        return out
+
+    # ------------------------------------------------------------------ network
+    def _trunk(self, image_u8: torch.Tensor):
+        lib, st = self.lib, self._stream()
+        cols = self._buf(256 * 256, 147)
+        _lib.check(lib.ap_sam2_patchify(image_u8.data_ptr(), 1024, 1024, _lib.f3(MEAN), _lib.f3(STD), cols.data_ptr(), st))
+        x = self._gemm(cols, self.w["pe.w"], EMBED, 147, bias=self.w["pe.b"], resid=self.w["pos"])      # [65536, 96]
+        H = W = 256
+        feats = []
+        for i, (din, dout, heads, window, qpool) in enumerate(self.plan):
+            g = lambda n: self.w[f"b{i}.{n}"]
+            rows = H * W
+            xn = self._ln(x, rows, din, g("norm1.weight"), g("norm1.bias"), 1e-6)
+            shortcut = x
+            if din != dout:
+                shortcut = self._gemm(xn, g("proj.weight"), dout, din, bias=g("proj.bias"))
+                if qpool:
+                    pooled = self._buf((H // 2) * (W // 2), dout)
+                    _lib.check(lib.ap_maxpool2x2(shortcut.data_ptr(), dout, 1, H, W, dout, pooled.data_ptr(), st))
+                    shortcut = pooled
+            if window > 0:
+                nwy, nwx = -(-H // window), -(-W // window)
+                nb, hh, ww = nwy * nwx, window, window
+                win = self._buf(nb * hh * ww, din)
+                _lib.check(lib.ap_window_partition(xn.data_ptr(), 1, H, W, din, window, win.data_ptr(), st))
+                xn = win
+            else:
+                nb, hh, ww = 1, H, W
+            t_k = hh * ww
+            qkv = self._gemm(xn, g("attn.qkv.weight"), 3 * dout, din, bias=g("attn.qkv.bias"))              # [nb*t_k, 3*dout]
+            d = dout // heads
+            q, ldq, t_q = qkv, 3 * dout, t_k
+            if qpool:
+                qp = self._buf(nb * (hh // 2) * (ww // 2), dout)
+                _lib.check(lib.ap_maxpool2x2(qkv.data_ptr(), 3 * dout, nb, hh, ww, dout, qp.data_ptr(), st))
+                q, ldq, hh, ww = qp, dout, hh // 2, ww // 2
+                t_q = hh * ww
+            a = self._attention(q, qkv[:, dout:], qkv[:, 2 * dout:], nb=nb, heads=heads, tq=t_q, tk=t_k, d=d,
+                                ldq=ldq, ldk=3 * dout, ldv=3 * dout)
+            a = self._gemm(a, g("attn.proj.weight"), dout, dout, bias=g("attn.proj.bias"))
+            if qpool:
+                H, W = H // 2, W // 2
+                window = window // 2
+            if window > 0:
+                un = self._buf(H * W, dout)
+                _lib.check(lib.ap_window_unpartition(a.data_ptr(), 1, H, W, dout, window, un.data_ptr(), st))
+                a = un
+            x2 = self._buf(H * W, dout)
+            _lib.check(lib.ap_add(x2.data_ptr(), shortcut.data_ptr(), a.data_ptr(), H * W * dout, st))
+            xn2 = self._ln(x2, H * W, dout, g("norm2.weight"), g("norm2.bias"), 1e-6)
+            hid = self._gemm(xn2, g("mlp.layers.0.weight"), 4 * dout, dout, bias=g("mlp.layers.0.bias"), act=1)
+            x = self._gemm(hid, g("mlp.layers.1.weight"), dout, 4 * dout, bias=g("mlp.layers.1.bias"), resid=x2)
+            if i in self.stage_ends:
+                feats.append((x, H, W, dout))
+        return feats
+
+    def image_features(self, image_u8: torch.Tensor):
+        """set_image: uint8 [1024, 1024, 3] on the device -> (embed [4096, 256] incl. no_mem + no_mask embeds,
+        feat_s0 [65536, 32], feat_s1 [16384, 64])."""
+        feats = self._trunk(image_u8)
+        lat = [self._gemm(x, self.w[f"neck{3 - i}.w"], 256, c, bias=self.w[f"neck{3 - i}.b"]) for i, (x, h, w, c) in enumerate(feats)]
+        # top-down only into level 2 (stride 16) from level 3 (stride 32): FpnNeck fpn_top_down_levels [2, 3], nearest
+        lvl2 = self._buf(64 * 64, 256)
+        _lib.check(self.lib.ap_upsample2x_add(lvl2.data_ptr(), lat[2].data_ptr(), lat[3].data_ptr(), 32, 32, 256, self._stream()))
+        s0 = self._gemm(lat[0], self.w["s0.w"], 32, 256, bias=self.w["s0.b"])
+        s1 = self._gemm(lat[1], self.w["s1.w"], 64, 256, bias=self.w["s1.b"])
+        embed = self._buf(4096, 256)
+        _lib.check(self.lib.ap_add_rowvec(embed.data_ptr(), lvl2.data_ptr(), self.w["embed_add"].data_ptr(), 4096, 256, self._stream()))
+        return embed, s0, s1
+
+    def _dec_attn(self, prefix, q, k, v, tq, tk, internal):
+        w = self.w
+        qp = self._gemm(q, w[prefix + ".q_proj.w"], internal, 256, bias=w[prefix + ".q_proj.b"])
+        kp = self._gemm(k, w[prefix + ".k_proj.w"], internal, 256, bias=w[prefix + ".k_proj.b"])
+        vp = self._gemm(v, w[prefix + ".v_proj.w"], internal, 256, bias=w[prefix + ".v_proj.b"])
+        a = self._attention(qp, kp, vp, nb=1, heads=8, tq=tq, tk=tk, d=internal // 8, ldq=internal, ldk=internal, ldv=internal)
+        return a, w[prefix + ".out_proj.w"], w[prefix + ".out_proj.b"], internal
+
+    def mask_logits(self, embed, s0, s1) -> torch.Tensor:
+        """predict (multimask_output=False): -> logits [256, 256] of mask token 0."""
+        lib, st, w = self.lib, self._stream(), self.w
+        tokens, image_pe = w["tokens"], w["image_pe"]
+        nt = tokens.shape[0]
+
+        def add(a, b, n):
+            o = self._buf(n)
+            _lib.check(lib.ap_add(o.data_ptr(), a.data_ptr(), b.data_ptr(), n, st), "ap_add")
+            return o
+
+        queries, keys = tokens, embed
+        for l in range(2):
+            p = f"d{l}."
+            ln = lambda x, rows, k: self._ln(x, rows, 256, w[p + f"norm{k}.w"], w[p + f"norm{k}.b"], 1e-5)
+            if l == 0:
+                a, ow, ob, internal = self._dec_attn(p + "self_attn", queries, queries, queries, nt, nt, 256)
+                queries = self._gemm(a, ow, 256, internal, bias=ob)
+            else:
+                q = add(queries, tokens, nt * 256).view(nt, 256)
+                a, ow, ob, internal = self._dec_attn(p + "self_attn", q, q, queries, nt, nt, 256)
+                queries = self._gemm(a, ow, 256, internal, bias=ob, resid=queries)
+            queries = ln(queries, nt, 1)
+            q = add(queries, tokens, nt * 256).view(nt, 256)
+            k = add(keys, image_pe, 4096 * 256).view(4096, 256)
+            a, ow, ob, internal = self._dec_attn(p + "cross_attn_token_to_image", q, k, keys, nt, 4096, 128)
+            queries = ln(self._gemm(a, ow, 256, internal, bias=ob, resid=queries), nt, 2)
+            hid = self._gemm(queries, w[p + "mlp0.w"], 2048, 256, bias=w[p + "mlp0.b"], act=2)
+            queries = ln(self._gemm(hid, w[p + "mlp1.w"], 256, 2048, bias=w[p + "mlp1.b"], resid=queries), nt, 3)
+            q = add(queries, tokens, nt * 256).view(nt, 256)
+            k = add(keys, image_pe, 4096 * 256).view(4096, 256)
+            a, ow, ob, internal = self._dec_attn(p + "cross_attn_image_to_token", k, q, queries, 4096, nt, 128)
+            keys = ln(self._gemm(a, ow, 256, internal, bias=ob, resid=keys), 4096, 4)
+        q = add(queries, tokens, nt * 256).view(nt, 256)
+        k = add(keys, image_pe, 4096 * 256).view(4096, 256)
+        a, ow, ob, internal = self._dec_attn("dfin", q, k, keys, nt, 4096, 128)
+        queries = self._ln(self._gemm(a, ow, 256, internal, bias=ob, resid=queries), nt, 256, w["dfin.norm.w"], w["dfin.norm.b"], 1e-5)
+        # upscaling: ConvT(256->64) + feat_s1 -> LayerNorm2d -> GELU -> ConvT(64->32) + feat_s0 -> GELU
+        g0 = self._gemm(keys, w["up0.w"], 256, 256)                                     # [4096, 64*4]
+        u1 = self._buf(128 * 128, 64)
+        _lib.check(lib.ap_convt2x2_shuffle(g0.data_ptr(), w["up0.b"].data_ptr(), s1.data_ptr(), u1.data_ptr(), 64, 64, 64, 0, st))
+        u1 = self._ln(u1, 128 * 128, 64, w["up1.w"], w["up1.b"], 1e-6)
+        _lib.check(lib.ap_gelu(u1.data_ptr(), 128 * 128 * 64, st))
+        g1 = self._gemm(u1, w["up3.w"], 128, 64)                                        # [16384, 32*4]
+        up = self._buf(256 * 256, 32)
+        _lib.check(lib.ap_convt2x2_shuffle(g1.data_ptr(), w["up3.b"].data_ptr(), s0.data_ptr(), up.data_ptr(), 128, 128, 32, 1, st))
+        h = queries[2:3]                                                                 # mask token 0 (obj, iou, mask0..3, prompts)
+        h = self._gemm(h, w["hyper0.w"], 256, 256, bias=w["hyper0.b"], act=2)
+        h = self._gemm(h, w["hyper1.w"], 256, 256, bias=w["hyper1.b"], act=2)
+        h = self._gemm(h, w["hyper2.w"], 32, 256, bias=w["hyper2.b"])                    # [1, 32]
+        return self._gemm(up, h, 1, 32).view(256, 256)                                   # logits[p] = sum_c up[p][c] * h[c]
+
+    # ------------------------------------------------------------------ reference-facing API
+    @torch.inference_mode()
+    def predict_logits(self, image_u8_1024: np.ndarray) -> torch.Tensor:
+        img = torch.from_numpy(np.ascontiguousarray(image_u8_1024)).to(self.device)
+        with torch.cuda.device(self.device):
+            return self.mask_logits(*self.image_features(img))
+
+    @torch.inference_mode()
+    def predict_image(self, image, *, resize_to_input: bool = True) -> np.ndarray:
+        """services/segmentation.py:120-140."""
+        from PIL import Image
+        arr = np.array(image.convert("RGB"), copy=True) if isinstance(image, Image.Image) else np.ascontiguousarray(image)
+        if arr.dtype != np.uint8:
+            arr = (arr * 255).astype(np.uint8) if arr.dtype.kind == "f" and arr.max() <= 1.0 else arr.astype(np.uint8)
+        orig = (int(arr.shape[0]), int(arr.shape[1]))
+        if orig != (self.input_size, self.input_size):
+            arr = np.array(Image.fromarray(arr).resize((self.input_size, self.input_size), Image.Resampling.BILINEAR), copy=True)
+        logits = self.predict_logits(arr)
+        mask = self._buf(1024, 1024)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ap_bilinear_up4_threshold(logits.data_ptr(), 256, C.c_float(self.mask_threshold), mask.data_ptr(),
+                                                          self._stream()))
+        out = mask.cpu().numpy()
+        if resize_to_input and orig != (self.input_size, self.input_size):
+            pil = Image.fromarray((out * 255).astype(np.uint8), mode="L").resize((orig[1], orig[0]), resample=Image.Resampling.NEAREST)
+            out = np.asarray(pil, dtype=np.float32) / 255.0
+        return out
+
+    def close(self) -> None:
+        self.w = {}
+
+
+def load_sam2_state_dict(checkpoint_path) -> dict:
+    obj = torch.load(str(checkpoint_path), map_location="cpu", weights_only=True)
+    return obj["model"] if isinstance(obj, dict) and "model" in obj else obj

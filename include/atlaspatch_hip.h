@@ -188,6 +188,41 @@ int ap_layernorm(int out_dtype, const float* x, long stride, int rows, int dim,
 int ap_attention(int dtype, const void* qkv, void* out, int n, int tokens, int heads, int head_dim,
                  ap_stream_t stream);
 
+/* ---- float32 operator set of the SAM2 (Hiera-T) tissue segmenter ------------------------
+ * Replaces the torch modules behind SAM2ImagePredictor.set_image / predict as the reference drives them
+ * (services/segmentation.py:120-140: one 1024 x 1024 thumbnail per slide, box prompt = whole image,
+ * multimask_output=False, mask_threshold 0.0).  The host chains these (atlaspatch_amd/services/sam2_hip.py);
+ * all tensors are float32, channels-last ([tokens, C]), device pointers.
+ *
+ * ap_sgemm: out[b][m][n] = act(alpha * sum_k A[b][m][k] * W[b][n][k] + bias[n]) + resid[b][m][n]
+ *   (W[b][k][n] when w_is_kn).  act: 0 none, 1 GELU (erf), 2 ReLU.  ld* = row strides, stride* = batch strides
+ *   in elements; bias / resid may be NULL.  Any M, N, K. */
+int ap_sgemm(const float* A, long lda, long strideA, const float* W, long ldw, long strideW, int w_is_kn,
+             int batch, int M, int N, int K, float alpha, const float* bias, int act,
+             const float* resid, long ldr, long strideR, float* out, long ldo, long strideO, ap_stream_t stream);
+int ap_softmax_rows(float* x, long ld, int rows, int cols, ap_stream_t stream);     /* in place */
+/* uint8 [h, w, 3] -> rows [(h/4)*(w/4), 147] of ((x/255) - mean) / std in (c, ky, kx) order: the im2col of
+ * Hiera's PatchEmbed conv (7x7, stride 4, pad 3). */
+int ap_sam2_patchify(const uint8_t* image, int h, int w, const float mean[3], const float stdv[3], float* out,
+                     ap_stream_t stream);
+/* hieradet.py window_partition / window_unpartition on [b, h, w, c]: windows [b * ceil(h/ws) * ceil(w/ws), ws*ws, c],
+ * zero padded / cropped. */
+int ap_window_partition(const float* x, int b, int h, int w, int c, int ws, float* win, ap_stream_t stream);
+int ap_window_unpartition(const float* win, int b, int h, int w, int c, int ws, float* x, ap_stream_t stream);
+/* 2x2 stride-2 max pool on [b, h, w, c] whose pixels are ld_in elements apart -> dense [b, h/2, w/2, c] */
+int ap_maxpool2x2(const float* in, long ld_in, int b, int h, int w, int c, float* out, ap_stream_t stream);
+int ap_add(float* out, const float* a, const float* b, size_t n, ap_stream_t stream);
+int ap_add_rowvec(float* out, const float* a, const float* vec, size_t rows, int cols, ap_stream_t stream);
+int ap_gelu(float* x, size_t n, ap_stream_t stream);
+/* FpnNeck top-down: out [2h, 2w, c] = lateral + nearest-x2(prev [h, w, c]) */
+int ap_upsample2x_add(float* out, const float* lateral, const float* prev, int h, int w, int c, ap_stream_t stream);
+/* ConvTranspose2d(kernel 2, stride 2) epilogue: g [h*w, cout*4] (column co*4 + dy*2 + dx) -> out [2h, 2w, cout]
+ * = g + bias[co] (+ skip) (GELU when act = 1) */
+int ap_convt2x2_shuffle(const float* g, const float* bias, const float* skip, float* out, int h, int w, int cout,
+                        int act, ap_stream_t stream);
+/* postprocess_masks: bilinear x4 (align_corners False) of logits [size, size], then > threshold -> float {0,1} */
+int ap_bilinear_up4_threshold(const float* logits, int size, float threshold, float* mask, ap_stream_t stream);
+
 /* ---- tissue mask -> patch coordinates ----------------------------------------------
  * Replaces utils/contours.py:41-131 (mask_to_contours, scale_contours) and the grid scan of
  * services/extraction.py:67-128 (_in_tissue, _iter_patch_entries, FourPointContainment). */

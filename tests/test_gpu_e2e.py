@@ -180,3 +180,45 @@ def test_device_tile_source_equals_host_ring(tmp_path, monkeypatch):
         with h5.File(out / "patches" / "s4.h5", "r") as f:
             feats[mode] = f["features"]["vit_b_16"][:]
     assert feats["device"].shape[0] > 0 and np.array_equal(feats["device"], feats["host"])
+
+
+def test_segment_and_get_coords_with_sam2_on_an_image_slide(tmp_path, monkeypatch):
+    """Real (non-synthetic) slide path: a PNG through the Pillow backend, SAM2 Hiera-T segmenter on the HIP
+    operator set (seeded random weights: the mask is arbitrary, the plumbing is what is checked), device coords,
+    H5 output; the coords must equal the oracle's for the mask the segmenter produced."""
+    from click.testing import CliRunner
+    from PIL import Image
+    from atlaspatch_amd.cli import cli
+    from atlaspatch_amd.core.config import SegmentationConfig
+    from atlaspatch_amd.core.wsi.image_wsi import ImageWSI
+    from atlaspatch_amd.services.segmentation import SAM2SegmentationService
+    from atlaspatch_amd.utils.h5 import h5
+    from oracle import coords_oracle
+
+    monkeypatch.setenv("ATLASPATCH_RANDOM_INIT", "4")
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, (3000, 4000, 3), dtype=np.uint8)
+    path = tmp_path / "slide.png"
+    Image.fromarray(img).save(path)
+    out = tmp_path / "out"
+    res = CliRunner().invoke(cli, ["segment-and-get-coords", str(path), "-o", str(out), "--patch-size", "256",
+                                   "--target-mag", "20", "--mpp-csv", str(_mpp_csv(tmp_path, "slide.png", 0.5))],
+                             catch_exceptions=False)
+    assert res.exit_code == 0 and "failures: 0" in res.output, res.output
+    with h5.File(out / "patches" / "slide.h5", "r") as f:
+        got = f["coords"][:]
+    seg = SAM2SegmentationService(SegmentationConfig(checkpoint_path=None, config_path=path, device="cuda"))
+    wsi = ImageWSI(path=str(path), mpp=0.5)
+    wsi._ensure_loaded()
+    mask = seg.segment_thumbnail(wsi).data
+    seg.close()
+    assert mask.shape == (188, 250) and set(np.unique(mask)) <= {0.0, 1.0}      # 4000 x 3000 at 20x -> 1.25x
+    want, _ = coords_oracle.coords_from_mask(mask, level0_wh=(4000, 3000), downsamples=[1.0], src_mag=wsi.mag,
+                                             tgt_mag=20, patch_size=256, step_size=None, tissue_thresh=0.0)
+    assert np.array_equal(got, want)
+
+
+def _mpp_csv(folder, name, mpp):
+    p = folder / "mpp.csv"
+    p.write_text(f"wsi,mpp\n{name},{mpp}\n")
+    return p

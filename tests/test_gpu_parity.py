@@ -275,3 +275,35 @@ def test_conch_registered_and_float32_rejected():
             reg.create("conch_v1")          # float32: 785 tokens exceed the f32 attention kernel / pooler is f16|bf16
     finally:
         os.environ.pop("ATLASPATCH_RANDOM_INIT", None)
+
+
+# ----------------------------------------------------------------------------- SAM2 Hiera-T image path (a4)
+def test_sam2_image_path_vs_oracle():
+    """Hiera-T trunk + FpnNeck + box-prompt mask decoder on the HIP float32 operator set vs the torch fp32
+    restatement (oracle/sam2_oracle.py), same seeded random weights.  Parity unpinned against the real package
+    (absent); tolerance: norm-wise 1e-4 on features / logits (float32, different summation order), masks equal
+    except where the upsampled logit is within rounding of the threshold."""
+    from atlaspatch_amd.services.sam2_hip import Sam2HipPredictor
+    from oracle import sam2_oracle as so
+    sd = so.random_state_dict(3)
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (1024, 1024, 3), dtype=np.uint8)
+    img[200:700, 300:800] = (img[200:700, 300:800] // 3 + 120).astype(np.uint8)        # some structure
+    pred = Sam2HipPredictor(sd, device=_dev())
+    embed_w, s0_w, s1_w = so.image_features(sd, img)
+    embed_w = embed_w + sd["sam_prompt_encoder.no_mask_embed.weight"].view(1, 256, 1, 1)
+    d_img = torch.from_numpy(img).to(_dev())
+    embed, s0, s1 = pred.image_features(d_img)
+    assert _rel(embed.cpu().numpy(), embed_w[0].flatten(1).t().numpy()) <= 1e-4
+    assert _rel(s0.cpu().numpy(), s0_w[0].flatten(1).t().numpy()) <= 1e-4
+    assert _rel(s1.cpu().numpy(), s1_w[0].flatten(1).t().numpy()) <= 1e-4
+    logits = pred.mask_logits(embed, s0, s1).cpu().numpy()
+    want = so.predict_logits(sd, img)
+    assert _rel(logits, want) <= 2e-4, _rel(logits, want)
+    # end to end through predict_image on a non-square thumbnail (BILINEAR in, NEAREST out)
+    thumb = rng.integers(0, 256, (733, 1024, 3), dtype=np.uint8)
+    got = pred.predict_image(thumb)
+    ref = so.predict_image(sd, thumb)
+    assert got.shape == ref.shape == (733, 1024) and set(np.unique(got)) <= {0.0, 1.0}
+    assert (got != ref).mean() <= 2e-4, (got != ref).mean()
+    pred.close()

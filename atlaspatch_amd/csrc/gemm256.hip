@@ -260,8 +260,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
     // fragment reads written before it may be hoisted by the compiler into the previous phase's
     // MFMA block (everything they read was published by the previous barrier); the wait may not.
 #ifdef AP_G256_ALT
-    // ablation twin (timing only, results are wrong when a flag is set): skew_ticks bit 28 = no counted wait,
-    // bit 29 = no barrier, bit 30 = no LDS-DMA after the prologue
+    // ablation twin (timing only, results are wrong when a flag is set; ap_gemm impl 257, variant bits 0-2):
+    // 1 = no counted wait, 2 = no barrier, 4 = no LDS-DMA after the prologue.  Measured (fc2, K = 3072):
+    // none 1.005 ms, no wait 1.013, no barrier 0.947, no DMA 0.940, all three 0.812 -> the fragment-read ->
+    // MFMA dependence inside a wave, not the synchronisation, bounds this structure at ~1.17 PF/s.
+    // A second barrier per phase with the two wave rows half a phase apart (+ s_setprio) was also measured: -1 %.
     const bool abl_nowait = (g.ablate & 1) != 0, abl_nobar = (g.ablate & 2) != 0;
 #define AP_PHASE_SYNC()                             \
     __builtin_amdgcn_sched_barrier(0);              \

@@ -112,6 +112,11 @@ int launch_layernorm(int dtype, const float* x, long stride, int rows, int dim,
 int launch_add_layernorm(int delta_dtype, int out_dtype, float* x, long stride, const void* delta,
                          long dstride, const float* ls, int rows, int dim, const float* gamma, const float* beta,
                          float eps, void* out, hipStream_t stream);
+// two pending branch outputs folded in one pass (delta0 first); store = 0: x itself is left untouched
+int launch_add2_layernorm(int delta_dtype, int out_dtype, float* x, long stride, const void* delta0, long dstride0,
+                          const float* ls0, const void* delta1, long dstride1, const float* ls1, int store,
+                          int rows, int dim, const float* gamma, const float* beta, float eps, void* out,
+                          hipStream_t stream);
 // f32 out variant used for the final norm on CLS rows
 int launch_layernorm_f32out(const float* x, long stride, int rows, int dim, const float* gamma,
                             const float* beta, float eps, float* out, hipStream_t stream);

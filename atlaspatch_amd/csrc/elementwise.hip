@@ -38,11 +38,21 @@ template <> __device__ __forceinline__ f32x4 load_vec4<bf16>(const bf16* p) {
 }
 
 // ---- (residual add +) LayerNorm.  x: f32 rows (the residual stream); when `delta` is given the
-// row is first updated in place, x += delta * ls (the branch output a GEMM stored in TD, times the
-// optional LayerScale vector ls), then
+// row is first updated, x += delta * ls (the branch output a GEMM stored in TD, times the optional
+// LayerScale vector ls; written back unless the launch says otherwise), then
 // normalised:  out = (x - mean) * rstd * gamma + beta  in TO.  Two-pass mean / variance on the
 // register-resident row, biased variance, eps inside the sqrt (nn.LayerNorm).
 //
+// Up to two pending branch outputs are folded in one pass (d[0] first, then d[1]: the same f32 operation order as
+// folding them in two launches); `store` = 0 leaves the stream untouched (the value is only needed for this
+// normalisation and will be folded again, together with the next branch, by the launch that does store).
+struct LnAdds {
+    const void* d[2];
+    long ds[2];
+    const float* ls[2];
+    int store;
+};
+
 // Main kernel: 16 lanes per row, 4 rows per wave: reductions stay inside a DPP row (no LDS
 // permutes) and four rows in flight per wave hide the HBM latency.  dim = 64 * NV.
 
@@ -58,8 +68,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 
 template <typename TD, typename TO, int NV>
 __global__ __launch_bounds__(256) void layernorm16_kernel(float* __restrict__ x, long stride,
-                                                          const TD* __restrict__ delta, long dstride,
-                                                          const float* __restrict__ ls, int rows, int dim,
+                                                          LnAdds add, int rows, int dim,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float eps,
                                                           TO* __restrict__ out) {
@@ -72,8 +81,11 @@ __global__ __launch_bounds__(256) void layernorm16_kernel(float* __restrict__ x,
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) v[i] = src[l16 + i * 16];
-    if (delta) {
-        const TD* dsrc = delta + (size_t)row * dstride;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        if (!add.d[a]) continue;
+        const TD* dsrc = (const TD*)add.d[a] + (size_t)row * add.ds[a];
+        const float* ls = add.ls[a];
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             f32x4 d = load_vec4<TD>(dsrc + (l16 + i * 16) * 4);
@@ -84,8 +96,11 @@ __global__ __launch_bounds__(256) void layernorm16_kernel(float* __restrict__ x,
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[i][e] += d[e];
-            if (live) src[l16 + i * 16] = v[i];
         }
+    }
+    if (add.store && live && (add.d[0] || add.d[1])) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) src[l16 + i * 16] = v[i];
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
@@ -118,8 +133,7 @@ constexpr int kMaxVec = 8;
 
 template <typename TD, typename TO>
 __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, long stride,
-                                                        const TD* __restrict__ delta, long dstride,
-                                                        const float* __restrict__ ls, int rows, int dim,
+                                                        LnAdds add, int rows, int dim,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps,
                                                         TO* __restrict__ out) {
@@ -135,17 +149,19 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, l
         const int idx = lane + i * 64;
         if (idx < nvec) {
             v[i] = src[idx];
-            if (delta) {
-                f32x4 d = load_vec4<TD>(delta + (size_t)row * dstride + idx * 4);
-                if (ls) {
-                    const f32x4 sc = ((const f32x4*)ls)[idx];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                if (!add.d[a]) continue;
+                f32x4 d = load_vec4<TD>((const TD*)add.d[a] + (size_t)row * add.ds[a] + idx * 4);
+                if (add.ls[a]) {
+                    const f32x4 sc = ((const f32x4*)add.ls[a])[idx];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) d[e] *= sc[e];
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[i][e] += d[e];
-                src[idx] = v[i];
             }
+            if (add.store && (add.d[0] || add.d[1])) src[idx] = v[i];
             s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
     }
@@ -179,17 +195,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, l
 }
 
 template <typename TD, typename TO>
-int launch_ln_typed(float* x, long stride, const void* delta, long dstride, const float* ls, int rows, int dim,
+int launch_ln_typed(float* x, long stride, const LnAdds& add, int rows, int dim,
                     const float* gamma, const float* beta, float eps, void* out, hipStream_t stream) {
-    const TD* d = (const TD*)delta;
     TO* o = (TO*)out;
     if (dim == 768 || dim == 1024) {      // same kernel for any row count: results never depend on the batch size
         dim3 g16((rows + 15) / 16), b16(256);
-        if (dim == 768) layernorm16_kernel<TD, TO, 12><<<g16, b16, 0, stream>>>(x, stride, d, dstride, ls, rows, dim, gamma, beta, eps, o);
-        else layernorm16_kernel<TD, TO, 16><<<g16, b16, 0, stream>>>(x, stride, d, dstride, ls, rows, dim, gamma, beta, eps, o);
+        if (dim == 768) layernorm16_kernel<TD, TO, 12><<<g16, b16, 0, stream>>>(x, stride, add, rows, dim, gamma, beta, eps, o);
+        else layernorm16_kernel<TD, TO, 16><<<g16, b16, 0, stream>>>(x, stride, add, rows, dim, gamma, beta, eps, o);
     } else {
         dim3 grid((rows + 3) / 4), block(256);
-        layernorm_kernel<TD, TO><<<grid, block, 0, stream>>>(x, stride, d, dstride, ls, rows, dim, gamma, beta, eps, o);
+        layernorm_kernel<TD, TO><<<grid, block, 0, stream>>>(x, stride, add, rows, dim, gamma, beta, eps, o);
     }
     AP_HIP_CHECK(hipGetLastError());
     return AP_OK;
@@ -232,14 +247,17 @@ __global__ void chw_to_patchrows_kernel(const TI* __restrict__ x, int n, int S, 
 
 }  // namespace
 
-int launch_add_layernorm(int delta_dtype, int out_dtype, float* x, long stride, const void* delta,
-                         long dstride, const float* ls, int rows, int dim, const float* gamma, const float* beta,
-                         float eps, void* out, hipStream_t stream) {
+int launch_add2_layernorm(int delta_dtype, int out_dtype, float* x, long stride, const void* delta0, long dstride0,
+                          const float* ls0, const void* delta1, long dstride1, const float* ls1, int store,
+                          int rows, int dim, const float* gamma, const float* beta, float eps, void* out,
+                          hipStream_t stream) {
     AP_REQUIRE(dim % 4 == 0 && dim <= 64 * 4 * kMaxVec, "layernorm: unsupported dim %d", dim);
-    AP_REQUIRE(stride % 4 == 0 && (!delta || dstride % 4 == 0), "layernorm: row strides must be multiples of 4");
+    AP_REQUIRE(stride % 4 == 0 && (!delta0 || dstride0 % 4 == 0) && (!delta1 || dstride1 % 4 == 0),
+               "layernorm: row strides must be multiples of 4");
     if (rows <= 0) return AP_OK;
-    if (!delta) delta_dtype = out_dtype;
-#define AP_LN(TD, TO) return launch_ln_typed<TD, TO>(x, stride, delta, dstride, ls, rows, dim, gamma, beta, eps, out, stream)
+    if (!delta0 && !delta1) delta_dtype = out_dtype;
+    const LnAdds add{{delta0, delta1}, {dstride0, dstride1}, {ls0, ls1}, store};
+#define AP_LN(TD, TO) return launch_ln_typed<TD, TO>(x, stride, add, rows, dim, gamma, beta, eps, out, stream)
     if (delta_dtype == AP_F16 && out_dtype == AP_F16) AP_LN(f16, f16);
     if (delta_dtype == AP_BF16 && out_dtype == AP_BF16) AP_LN(bf16, bf16);
     if (delta_dtype == AP_F32 && out_dtype == AP_F32) AP_LN(float, float);
@@ -248,6 +266,13 @@ int launch_add_layernorm(int delta_dtype, int out_dtype, float* x, long stride, 
 #undef AP_LN
     set_error("layernorm: unsupported dtype pair (delta %d, out %d)", delta_dtype, out_dtype);
     return AP_ERR_INVALID;
+}
+
+int launch_add_layernorm(int delta_dtype, int out_dtype, float* x, long stride, const void* delta,
+                         long dstride, const float* ls, int rows, int dim, const float* gamma, const float* beta,
+                         float eps, void* out, hipStream_t stream) {
+    return launch_add2_layernorm(delta_dtype, out_dtype, x, stride, delta, dstride, ls, nullptr, 0, nullptr, 1, rows, dim,
+                                 gamma, beta, eps, out, stream);
 }
 
 int launch_layernorm(int dtype, const float* x, long stride, int rows, int dim, const float* gamma,

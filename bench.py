@@ -35,7 +35,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=1024, help="tiles per step (device batch)")
+    ap.add_argument("--batch", type=int, default=2048, help="tiles per step (device batch)")
     ap.add_argument("--precision", default="float16", choices=["float16", "bfloat16", "float32"])
     ap.add_argument("--slide", type=int, default=40000, help="synthetic slide side in pixels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -177,7 +177,7 @@ def main():
     # summarised by tools/pmc_traffic.py into profiles/; FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md)
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if short != "f32" and B == 1024 and os.path.exists(tpath):
+    if short != "f32" and B == 2048 and os.path.exists(tpath):
         with open(tpath) as fh:
             for kname, rec in json.load(fh).items():
                 if "gemm256_kernel" in kname and ("Li1E" in kname or "EPI_BIAS_GELU" in kname or ", 1>" in kname) \

@@ -19,7 +19,7 @@ void set_error(const char* fmt, ...) {
 
 extern "C" {
 
-int ap_abi_version(void) { return 5; }
+int ap_abi_version(void) { return 6; }
 
 const char* ap_last_error(void) { return ap::g_error; }
 

@@ -61,51 +61,62 @@ class HipViTFeatureExtractor(FeatureExtractor):
     vit : atlaspatch_amd.encoders.vit.HipViT
         Device-resident encoder (weights already uploaded).
     mean, std : normalisation constants of the reference transform.
-    host_resize : optional ``(size, PIL resample)`` applied on the host with Pillow (the
-        reference's own resampler) when tiles are not already ``crop_from`` sized, e.g. timm's
-        ``Resize(224, bicubic)`` for 256-px tiles.  ``None`` = torchvision's
-        ``ImageClassification(crop 224, resize 256)`` on 256-px tiles, which is a pure
-        centre crop and runs on the device.
+    resize : optional ``(size, "bicubic" | "bilinear")`` -- the ``Resize(size)`` that opens the reference
+        transform (timm's ``Resize(224, bicubic)`` for uni_v1, open_clip's ``Resize(448, bicubic)`` for
+        conch_v1): shorter side -> size with the aspect kept, done on the device by ``ap_resample_u8``
+        bit-identically to Pillow (the reference's resampler); the centre crop that follows is part of
+        the preprocess kernel.  ``None`` = torchvision's ``ImageClassification(crop 224, resize 256)``
+        on 256-px tiles, which is a pure centre crop.
     """
 
     def __init__(self, *, name: str, vit, mean, std, max_batch: int = 1024,
-                 host_resize: Optional[tuple] = None, expect_size: Optional[int] = None) -> None:
+                 resize: Optional[tuple] = None, expect_size: Optional[int] = None) -> None:
         self.name = name
         self.vit = vit
         self.embedding_dim = int(vit.embed_dim)
         self.mean = tuple(float(v) for v in mean)
         self.std = tuple(float(v) for v in std)
         self.max_batch = int(max_batch)
-        self.host_resize = host_resize
+        self.resize = resize
         self.expect_size = expect_size
         self.device = vit.device
+        self._resamplers: dict = {}
 
     def _prepare(self, patches: Sequence) -> np.ndarray:
         arrs = [_as_uint8_hwc(p) for p in patches]
-        if self.host_resize is not None:
-            size, resample = self.host_resize
-            out = []
-            for a in arrs:
-                if min(a.shape[0], a.shape[1]) != size:
-                    img = Image.fromarray(a)
-                    w, h = img.size
-                    # torchvision/timm Resize(int): shorter side -> size, aspect kept
-                    if w <= h:
-                        nw, nh = size, int(size * h / w)
-                    else:
-                        nw, nh = int(size * w / h), size
-                    a = np.asarray(img.resize((nw, nh), resample))
-                out.append(a)
-            arrs = out
         shape0 = arrs[0].shape
         if any(a.shape != shape0 for a in arrs):
             raise ValueError("all patches of one batch must have the same shape")
-        if self.expect_size is not None and (shape0[0] != self.expect_size or shape0[1] != self.expect_size):
+        if self.resize is None and self.expect_size is not None and \
+                (shape0[0] != self.expect_size or shape0[1] != self.expect_size):
             raise ValueError(
                 f"{self.name}: the device preprocess implements the reference transform for "
-                f"{self.expect_size}x{self.expect_size} tiles only (got {shape0[1]}x{shape0[0]}); "
-                "resampling transforms are not part of this build")
+                f"{self.expect_size}x{self.expect_size} tiles only (got {shape0[1]}x{shape0[0]})")
         return np.stack(arrs, axis=0)
+
+    def resized(self, tiles_u8: torch.Tensor) -> torch.Tensor:
+        """The transform's leading ``Resize`` on a device batch uint8 [n, H, W, 3] (identity when absent)."""
+        if self.resize is None:
+            return tiles_u8
+        size, filt = self.resize
+        h, w = int(tiles_u8.shape[1]), int(tiles_u8.shape[2])
+        if min(h, w) == size:
+            return tiles_u8
+        rs = self._resamplers.get((h, w))
+        if rs is None:
+            from ..utils.resample import DeviceResampler
+            # torchvision/timm Resize(int): shorter side -> size, aspect kept
+            out_hw = (int(size * h / w), size) if w <= h else (size, int(size * w / h))
+            rs = self._resamplers[(h, w)] = DeviceResampler((h, w), out_hw, filt, self.device)
+        return rs(tiles_u8)
+
+    def forward_device(self, tiles_u8: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+        """One device chunk: resize (if the transform has one) + preprocess + encoder, all HIP kernels."""
+        n = int(tiles_u8.shape[0])
+        step = max(1, min(max(n, 1), self.max_batch))
+        for s in range(0, n, step):
+            self.vit.forward_u8(self.resized(tiles_u8[s:s + step]), self.mean, self.std, out[s:s + step])
+        return out
 
     @torch.inference_mode()
     def extract_batch(self, patches: Sequence[np.ndarray], *,
@@ -120,7 +131,7 @@ class HipViTFeatureExtractor(FeatureExtractor):
         out = torch.empty((n, self.embedding_dim), dtype=torch.float32, device=self.device)
         for s in range(0, n, step):
             dev = host[s:s + step].to(self.device, non_blocking=False)
-            self.vit.forward_u8(dev, self.mean, self.std, out[s:s + step])
+            self.forward_device(dev, out[s:s + step])
         return out.cpu().numpy()
 
     @torch.inference_mode()
@@ -129,10 +140,7 @@ class HipViTFeatureExtractor(FeatureExtractor):
         n = tiles_u8.shape[0]
         if out is None:
             out = torch.empty((n, self.embedding_dim), dtype=torch.float32, device=tiles_u8.device)
-        step = max(1, min(max(n, 1), self.max_batch))
-        for s in range(0, n, step):
-            self.vit.forward_u8(tiles_u8[s:s + step], self.mean, self.std, out[s:s + step])
-        return out
+        return self.forward_device(tiles_u8, out)
 
     def cleanup(self) -> None:
         self.vit.release()

@@ -324,7 +324,7 @@ def load_checkpoint(path: Path) -> dict:
 
 def build_hip_vit_extractor(*, name: str, arch, device, dtype, state_dict: Optional[dict] = None,
                             mean=None, std=None, source: str = "auto", max_batch: int = 1024,
-                            random_init_seed: Optional[int] = None, host_resize=None,
+                            random_init_seed: Optional[int] = None, resize=None,
                             expect_size: Optional[int] = 256, **arch_overrides) -> HipViTFeatureExtractor:
     spec = dict(ARCHS[arch]) if isinstance(arch, str) else dict(arch)
     spec.update(arch_overrides)
@@ -356,17 +356,16 @@ def build_hip_vit_extractor(*, name: str, arch, device, dtype, state_dict: Optio
         state.update({k: v.detach().to(torch.float32).cpu().contiguous() for k, v in pool_state.items()})
     vit = HipViT(spec, state, device=torch.device(device), dtype=dtype)
     return HipViTFeatureExtractor(name=name, vit=vit, mean=mean or IMAGENET_MEAN, std=std or IMAGENET_STD,
-                                  max_batch=max_batch, host_resize=host_resize, expect_size=expect_size)
+                                  max_batch=max_batch, resize=resize, expect_size=expect_size)
 
 
 def register_conch(registry, *, device, dtype=torch.float32, num_workers: int = 0) -> None:
     """conch_v1 (models/patch/conch.py:20-64): open_clip image transform = Resize(448, bicubic) + CenterCrop(448)
-    + ToTensor + Normalize(OpenAI CLIP mean / std) [3P]; the resize runs on the host with Pillow, the rest on
-    the device.  float16 / bfloat16 only (the reference's config 5 runs it in fp16)."""
-    from PIL import Image
+    + ToTensor + Normalize(OpenAI CLIP mean / std) [3P]; all of it on the device (the resize is Pillow-exact,
+    ap_resample_u8).  float16 / bfloat16 only (the reference's config 5 runs it in fp16)."""
     registry.register("conch_v1", lambda: build_hip_vit_extractor(
         name="conch_v1", arch="conch_v1", device=device, dtype=dtype, random_init_seed=_env_seed(),
-        mean=OPENAI_CLIP_MEAN, std=OPENAI_CLIP_STD, host_resize=(448, Image.Resampling.BICUBIC), expect_size=448,
+        mean=OPENAI_CLIP_MEAN, std=OPENAI_CLIP_STD, resize=(448, "bicubic"), expect_size=None,
         max_batch=256))
 
 
@@ -385,8 +384,7 @@ def register_vits(registry, *, device, dtype=torch.float32, num_workers: int = 0
 
 def register_uni(registry, *, device, dtype=torch.float32, num_workers: int = 0) -> None:
     """uni_v1: timm ViT-L/16 + LayerScale; timm transform Resize(224, bicubic) + CenterCrop(224):
-    the resize runs on the host with Pillow (the reference's own resampler), the rest on device."""
-    from PIL import Image
+    the resize runs on the device bit-identically to Pillow (ap_resample_u8), the crop in the preprocess kernel."""
     registry.register("uni_v1", lambda: build_hip_vit_extractor(
         name="uni_v1", arch="uni_v1", device=device, dtype=dtype, random_init_seed=_env_seed(),
-        host_resize=(224, Image.Resampling.BICUBIC), expect_size=224))
+        resize=(224, "bicubic"), expect_size=None))

@@ -174,7 +174,7 @@ class PatchFeatureEmbeddingService(FeatureEmbeddingService):
                 return self._stamp(result)
             attrs = {"name": extractor.name, "embedding_dim": extractor.embedding_dim}
             writer = self._writer(result, wsi)
-            if isinstance(extractor, HipViTFeatureExtractor) and extractor.host_resize is None:
+            if isinstance(extractor, HipViTFeatureExtractor):
                 feats = self.embed_matrix(result, wsi, extractor)
                 writer.append_feature_matrix(output_path=result.h5_path, feature_name=extractor.name,
                                              features=feats, feature_attrs=attrs,
@@ -210,7 +210,7 @@ class PatchFeatureEmbeddingService(FeatureEmbeddingService):
                                   slots=3, workers=max(1, self.feature_cfg.num_workers))
         with torch.cuda.device(extractor.device):
             return self._ring.run(coords, self._read_tile(wsi),
-                                  lambda tiles, out: extractor.vit.forward_u8(tiles, extractor.mean, extractor.std, out),
+                                  lambda tiles, out: extractor.forward_device(tiles, out),
                                   extractor.embedding_dim)
 
     def _embed_device_source(self, coords: np.ndarray, wsi: IWSI, extractor, batch: int):
@@ -226,7 +226,7 @@ class PatchFeatureEmbeddingService(FeatureEmbeddingService):
                 tiles = source(coords[lo:lo + batch], extractor.device, self.cfg.patch_size)
                 if tiles is None:
                     return None
-                extractor.vit.forward_u8(tiles, extractor.mean, extractor.std, out[lo:lo + tiles.shape[0]])
+                extractor.forward_device(tiles, out[lo:lo + tiles.shape[0]])
             return out.cpu().numpy()
 
     def embed_all(self, results: list[ExtractionResult], *, wsi_loader, progress=None) -> list[tuple]:

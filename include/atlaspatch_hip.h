@@ -63,6 +63,19 @@ int ap_preproc_u8hwc_to_patchrows(const uint8_t* src, int n, int h, int w,
                                   const float mean[3], const float stdv[3],
                                   void* dst, int ld, int dst_dtype, ap_stream_t stream);
 
+/* ---- Pillow-exact tile resampling ------------------------------------------------------
+ * Replaces the PIL resize inside the per-item transform of encoders whose transform starts with Resize:
+ * timm's Resize(224, bicubic) for uni_v1 (models/patch/uni.py:48-49) and open_clip's Resize(448, bicubic)
+ * for conch_v1 (models/patch/conch.py:35-38), applied by PatchDataset.__getitem__ (models/patch/base.py:42-45).
+ * Bit-identical to PIL.Image.resize for uint8 RGB: horizontal then vertical pass, 22-bit fixed-point weights.
+ * bounds_* : device int32 [out, 2] (first input index, tap count); coeffs_* : device int32 [out, ksize_*]
+ * (the tables of Pillow's precompute_coeffs + normalize_coeffs_8bpc, built by the host);
+ * src uint8 [n, h, w, 3] -> dst uint8 [n, oh, ow, 3]; tmp: device scratch of n*h*ow*3 bytes. */
+int ap_resample_u8(const uint8_t* src, int n, int h, int w, uint8_t* dst, int oh, int ow,
+                   const int32_t* bounds_x, const int32_t* coeffs_x, int ksize_x,
+                   const int32_t* bounds_y, const int32_t* coeffs_y, int ksize_y,
+                   uint8_t* tmp, ap_stream_t stream);
+
 /* ---- tile content statistics (--no-fast-mode filters) -------------------------------
  * Replaces utils/image.py:7-41 (is_black_patch / is_white_patch), which services/extraction.py:112-116
  * applies to every candidate tile: counts[i] = { #pixels with cv2 RGB2GRAY < black_thresh,

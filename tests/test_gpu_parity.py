@@ -236,6 +236,47 @@ def test_synth_tiles_bit_exact():
         assert np.array_equal(got[i], render_region(spec, int(x), int(y), 256, 256, 0)), i
 
 
+# ----------------------------------------------------------------------------- Pillow-exact device resize
+@pytest.mark.parametrize("filt", ["bicubic", "bilinear"])
+@pytest.mark.parametrize("in_hw,out_hw", [((256, 256), (224, 224)), ((256, 256), (448, 448)), ((300, 256), (262, 224)),
+                                          ((97, 131), (224, 302)), ((512, 512), (224, 224)), ((224, 224), (224, 224))])
+def test_device_resample_equals_pillow(filt, in_hw, out_hw):
+    """ap_resample_u8 == PIL.Image.resize bit for bit (the oracle here is Pillow itself: pinned)."""
+    from PIL import Image
+    from atlaspatch_amd.utils.resample import DeviceResampler
+    pf = {"bicubic": Image.Resampling.BICUBIC, "bilinear": Image.Resampling.BILINEAR}[filt]
+    rng = np.random.default_rng(in_hw[0] * 7 + out_hw[1])
+    tiles = rng.integers(0, 256, (5, *in_hw, 3), dtype=np.uint8)
+    tiles[1] = 255; tiles[2] = 0
+    tiles[3, ::2] = 255; tiles[3, 1::2] = 0                       # overshoot: exercises both clip8 branches
+    got = DeviceResampler(in_hw, out_hw, filt, _dev())(torch.from_numpy(tiles).to(_dev())).cpu().numpy()
+    for i in range(tiles.shape[0]):
+        want = np.asarray(Image.fromarray(tiles[i]).resize((out_hw[1], out_hw[0]), pf))
+        assert np.array_equal(got[i], want), (i, np.abs(got[i].astype(int) - want).max())
+
+
+def test_uni_transform_device_resize_matches_host_pillow():
+    """uni_v1's transform (Resize(224, bicubic) + CenterCrop + Normalize) through the device resize gives the
+    same features as resizing with Pillow on the host first (bit-identical inputs -> bit-identical outputs),
+    including non-square tiles (shorter side -> 224, centre crop)."""
+    from PIL import Image
+    from atlaspatch_amd.encoders.vit import ARCHS, build_hip_vit_extractor, random_canonical_state_dict
+    arch = dict(ARCHS["uni_v1"]); arch["depth"] = 2
+    state = random_canonical_state_dict(arch, seed=2)
+    ex = build_hip_vit_extractor(name="uni_test", arch=arch, state_dict=state, source="canonical", device=_dev(),
+                                 dtype=torch.float16, resize=(224, "bicubic"), expect_size=None)
+    rng = np.random.default_rng(9)
+    for hw in ((256, 256), (256, 300)):
+        tiles = [rng.integers(0, 256, (*hw, 3), dtype=np.uint8) for _ in range(4)]
+        got = ex.extract_batch(tiles)
+        h, w = hw
+        nw, nh = (224, int(224 * h / w)) if w <= h else (int(224 * w / h), 224)
+        pre = [np.asarray(Image.fromarray(t).resize((nw, nh), Image.Resampling.BICUBIC)) for t in tiles]
+        want = ex.extract_batch(pre)
+        assert np.array_equal(got, want)
+    ex.cleanup()
+
+
 # ----------------------------------------------------------------------------- CONCH v1 (a16)
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 5e-3), (torch.bfloat16, 3e-2)])
 def test_conch_visual_tower_vs_oracle(dtype, tol):
@@ -256,7 +297,7 @@ def test_conch_visual_tower_vs_oracle(dtype, tol):
     want = vit_oracle.conch_encode_image(trunk, pool, tiles, heads=12, depth=2, pool_heads=8)
     ex = build_hip_vit_extractor(name="conch_test", arch=arch, state_dict=state, source="canonical", device=_dev(),
                                  dtype=dtype, mean=OPENAI_CLIP_MEAN, std=OPENAI_CLIP_STD,
-                                 host_resize=(448, Image.Resampling.BICUBIC), expect_size=448)
+                                 resize=(448, "bicubic"), expect_size=None)
     got = ex.extract_batch(tiles, batch_size=32)
     ex.cleanup()
     assert got.shape == (3, 512) and got.dtype == np.float32

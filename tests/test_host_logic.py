@@ -257,7 +257,7 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/atlaspatch_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert _lib.load().ap_abi_version() == 5
+    assert _lib.load().ap_abi_version() == 6
 
 
 def test_product_has_no_cpu_fallback():
@@ -277,3 +277,36 @@ def test_product_never_imports_the_oracle():
     for path in glob.glob(os.path.join(ROOT, "atlaspatch_amd", "**", "*.py"), recursive=True):
         text = open(path).read()
         assert "import oracle" not in text and "from oracle" not in text, path
+
+
+def test_pillow_resample_tables_reproduce_pil():
+    """The host-built coefficient tables (product code feeding ap_resample_u8) applied in numpy equal
+    PIL.Image.resize bit for bit -- Pillow is the reference's resampler (timm / open_clip Resize on PIL images)."""
+    from PIL import Image
+    from atlaspatch_amd.utils.resample import pillow_resample_tables
+
+    def apply(img, oh, ow, f):
+        h, w, c = img.shape
+        bx, kx, _ = pillow_resample_tables(w, ow, f)
+        by, ky, _ = pillow_resample_tables(h, oh, f)
+        a = img.astype(np.int64)
+        tmp = np.zeros((h, ow, c), np.uint8)
+        for xx in range(ow):
+            s = np.full((h, c), 1 << 21, np.int64)
+            for x in range(bx[xx, 1]):
+                s += a[:, bx[xx, 0] + x, :] * int(kx[xx, x])
+            tmp[:, xx] = np.clip(s >> 22, 0, 255)
+        t = tmp.astype(np.int64)
+        out = np.zeros((oh, ow, c), np.uint8)
+        for yy in range(oh):
+            s = np.full((ow, c), 1 << 21, np.int64)
+            for y in range(by[yy, 1]):
+                s += t[by[yy, 0] + y] * int(ky[yy, y])
+            out[yy] = np.clip(s >> 22, 0, 255)
+        return out
+
+    rng = np.random.default_rng(1)
+    for (h, w), (oh, ow) in (((256, 256), (224, 224)), ((256, 256), (448, 448)), ((131, 97), (302, 224))):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        for f, pf in (("bicubic", Image.Resampling.BICUBIC), ("bilinear", Image.Resampling.BILINEAR)):
+            assert np.array_equal(apply(img, oh, ow, f), np.asarray(Image.fromarray(img).resize((ow, oh), pf))), (h, w, f)

@@ -86,6 +86,7 @@ struct GemmArgs {
     void* out; int ldo;      // T (STORE / GELU) or f32 (RESID / PATCH_EMBED)
     int P;                   // EPI_PATCH_EMBED: patches per image
     int ablate;              // gemm256 A/B twin only: timing ablation flags (results invalid when set)
+    int walk_cols;           // gemm256 only: tile-walk column-group width (0 = kernel default)
     int skew_ticks;          // gemm256 only: start-time spread across an XCD's workgroups (100 MHz ticks)
     long long* trace;        // gemm256 diagnostics: per (workgroup, tile) 8 x 100-MHz time stamps, or null
     int trace_tiles;         //   tiles recorded per workgroup

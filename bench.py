@@ -176,7 +176,7 @@ def main():
     # HBM bytes of that kernel from the PMC counters (separate rocprofv3 --pmc passes of this same command,
     # summarised by tools/pmc_traffic.py into profiles/; FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md)
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r01c_traffic.json")
     if short != "f32" and B == 2048 and os.path.exists(tpath):
         with open(tpath) as fh:
             for kname, rec in json.load(fh).items():
@@ -184,6 +184,20 @@ def main():
                         and ("DF16_" in kname) == (short == "f16"):
                     traffic = rec["hbm_bytes_per_launch"]
     kernel_ms = {k: round(v[0] / K, 4) for k, v in prof.items()}
+    # the HBM-bound kernels of the path, same HIP-event timers, algorithmic bytes:
+    #   preprocess: reads the 224x224x3 u8 centre crop, writes the [196, 768] patch matrix in the compute dtype
+    #   add+LayerNorm: per block LN1 (f32 stream + one pending branch in, normalised rows out; the first block has no
+    #   pending branch) and LN2 (stream + two branches in, stream + normalised rows out); the final LN touches CLS rows only
+    eb = 2.0 if short != "f32" else 4.0
+    pre_bytes = B * 150528.0 * (1.0 + eb)
+    ln_bytes = M * 768.0 * (12 * ((4 + eb + eb) + (4 + 2 * eb + 4 + eb)) - eb)
+    hbm_kernels = {}
+    for kind, nbytes in (("preproc", pre_bytes), ("layernorm", ln_bytes)):
+        ms = prof[kind][0] / K
+        if ms > 0:
+            hbm_kernels[kind] = {"algorithmic_bytes_per_step": nbytes, "ms_per_step": round(ms, 4),
+                                 "achieved_GBps": round(nbytes / (ms * 1e-3) / 1e9, 1), "peak_GBps": 8000.0,
+                                 "frac": round(nbytes / (ms * 1e-3) / 8e12, 4)}
     line = {
         "metric": "patches/sec embedded (256x256, ViT-B/16)", "value": round(value, 1), "unit": "patches/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 3),
@@ -200,7 +214,7 @@ def main():
                      "avg_launch_ms": round(fc1_avg_s * 1e3, 4), "launches": fc1_n,
                      "algorithmic_flop_per_launch": flop_launch},
         "end_to_end_model_tflops": round(value * FLOP_PER_PATCH_VIT_B16 / 1e12 / world, 1),
-        "kernel_ms_per_step": kernel_ms,
+        "kernel_ms_per_step": kernel_ms, "hbm_kernels": hbm_kernels,
         "coords": {"cells": cells, "rows": int(n_slide), "seconds": round(coords_s, 4),
                    "cells_per_s": round(cells / coords_s, 1)},
     }

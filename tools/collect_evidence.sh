@@ -1,0 +1,21 @@
+#!/bin/bash
+# Round evidence on one MI355X: bench line, rocprofv3 kernel trace of the same command, and the two PMC passes for
+# HBM traffic (each counter in its own run, kernel-trace only, as MI355X_MICROARCH.md prescribes).
+# usage: tools/collect_evidence.sh <tag>      (outputs under gpurun_out/<tag>/; copy the summaries into profiles/)
+set -u
+TAG=${1:-r01c}
+OUT=$PWD/gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+tail -1 "$OUT/bench.json"
+CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o kt -- $CMD > "$OUT/kt.log" 2>&1
+DB=$(find "$OUT/kt" -name '*_results.db' | head -1)
+if [ -n "$DB" ]; then python profiles/summarize_rocpd.py "$DB" > "$OUT/kernel_stats.txt"; else
+  find "$OUT/kt" -name '*kernel_stats.csv' | head -1 | xargs -r cp -t "$OUT"; fi
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o f -- $CMD > "$OUT/pmc_fetch.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o w -- $CMD > "$OUT/pmc_write.log" 2>&1
+python tools/pmc_traffic.py "$OUT/pmc_fetch" "$OUT/pmc_write" > "$OUT/traffic.json"
+rm -rf "$OUT/kt" "$OUT/pmc_fetch" "$OUT/pmc_write"
+head -30 "$OUT/kernel_stats.txt"

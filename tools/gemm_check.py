@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--impls", default="128:0,256:0,257:0")
+    ap.add_argument("--tiles", type=int, default=1024, help="device batch the timed shapes correspond to")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.load()
@@ -90,7 +91,7 @@ def main():
     if args.quick:
         return
     # ---- throughput on the ViT-B/16 shapes of a 1024-tile batch
-    M = 1024 * 197
+    M = args.tiles * 197
     res = []
     for name, N, K, epi in (("qkv", 2304, 768, "bias"), ("proj", 768, 768, "bias"), ("fc1", 3072, 768, "gelu"),
                             ("fc2", 768, 3072, "bias")):

@@ -239,16 +239,27 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
     // epilogue has no bias pass; the next tile's bias is fetched while the current epilogue runs.
     f32x16 acc[2][4];         // [n block of 32][m block of 32]
     f32x4 nbias[2][4];
-    auto load_bias = [&](int ti, int hi_) {
-        const int id = tw.first + ti * tw.stride;
+    // The bias loads are inline asm with hand-placed waits.  A load hipcc tracks that is still pending at the
+    // tile-loop header makes its waitcnt pass put static `s_waitcnt vmcnt(0..4)` in front of the first MFMAs of
+    // EVERY tile (the first-entry state is merged into the back edge), i.e. a drain of this workgroup's epilogue
+    // stores and of the DMA issued a moment earlier.  vmcnt retires in order, so "all but the N youngest" covers
+    // every older load.  (Timeline, tools/gemm_fine_trace.py: neutral within noise -- the first K-tile pair of a
+    // tile is dominated by wave 0 waiting at the first barrier for the waves that finish their epilogue later:
+    // the two waves of a SIMD share its VALU, 3.9 -> 4.0 us for the store epilogue, 6.4 us after the GELU one.)
+    auto bias_ptr = [&](int ti, int hi_) {
         int tr, tc;
-        tw.rc(id, tr, tc);
-        const float* bp = g.bias + tc * kBN + wc * 64 + hi_ * 4;
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) nbias[nb][g4] = *(const f32x4*)(bp + nb * 32 + g4 * 8);
+        tw.rc(tw.first + ti * tw.stride, tr, tc);
+        return g.bias + tc * kBN + wc * 64 + hi_ * 4;
     };
+#define AP_BIAS_LD(P, NB, G4) \
+    asm volatile("global_load_dwordx4 %0, %1, off offset:" #NB "*128+" #G4 "*32" : "=&v"(nbias[NB][G4]) : "v"(P) : "memory")
+#define AP_BIAS_LD8(P)                                                                  \
+    AP_BIAS_LD(P, 0, 0); AP_BIAS_LD(P, 0, 1); AP_BIAS_LD(P, 0, 2); AP_BIAS_LD(P, 0, 3); \
+    AP_BIAS_LD(P, 1, 0); AP_BIAS_LD(P, 1, 1); AP_BIAS_LD(P, 1, 2); AP_BIAS_LD(P, 1, 3)
+#define AP_BIAS_WAIT(N)                                                                                           \
+    asm volatile("s_waitcnt vmcnt(" #N ")"                                                                        \
+                 : "+v"(nbias[0][0]), "+v"(nbias[0][1]), "+v"(nbias[0][2]), "+v"(nbias[0][3]), "+v"(nbias[1][0]), \
+                   "+v"(nbias[1][1]), "+v"(nbias[1][2]), "+v"(nbias[1][3])::"memory")
     auto init_acc = [&]() {
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
@@ -257,8 +268,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[nb][mb][e] = nbias[nb][e >> 2][e & 3];
     };
-    load_bias(0, hi);
-    init_acc();
+    {
+        const float* bp0 = bias_ptr(0, hi);
+        AP_BIAS_LD8(bp0);
+    }
 
     Frag fa[2][4], fb0[4], fb1[4];
 
@@ -266,8 +279,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
     stage(ca, true, 0, U_X0); stage(ca, false, 0, U_Y0); advance(ca, 0);
     stage(cb, false, 0, U_Y1); stage(cb, true, 0, U_X1); advance(cb, 1);
     stage(ca, true, 1, U_X0); stage(ca, false, 1, U_Y0); advance(ca, 0);
-    AP_VMCNT(8);              // X0 / Y0 of K-tile 0 have landed (phase 0 reads them)
+    AP_BIAS_WAIT(8);          // X0 / Y0 of K-tile 0 (and the older bias loads) have landed (phase 0 reads them)
     __builtin_amdgcn_s_barrier();
+    init_acc();
 #ifdef AP_G256_ALT
     dma_off = true;
 #endif
@@ -364,13 +378,25 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
         if (g.trace && ti < g.trace_tiles && threadIdx.x == 0)
             g.trace[((size_t)blockIdx.x * g.trace_tiles + ti) * 8 + k] = (long long)__builtin_amdgcn_s_memrealtime();
     };
+    auto stamp_clk = [&](int ti, int k) {       // shader-clock counter: (slot 6 - slot 5) / (slot 1 - slot 0) = core clock in the main loop
+        if (g.trace && ti < g.trace_tiles && threadIdx.x == 0)
+            g.trace[((size_t)blockIdx.x * g.trace_tiles + ti) * 8 + k] = (long long)__builtin_amdgcn_s_memtime();
+    };
     for (int ti = 0; ti < tw.count; ++ti) {
         stamp(ti, 0);
+        stamp_clk(ti, 5);
         for (int kt = 0; kt < nk; kt += 2) {
+#ifdef AP_G256_ALT
+            // fine timeline (twin only): start of every K-tile pair, in a second [workgroups, tiles, 8] block of the buffer
+            if (g.trace && ti < g.trace_tiles && threadIdx.x == 0 && (kt >> 1) < 8)
+                g.trace[((size_t)(gridDim.x + blockIdx.x) * g.trace_tiles + ti) * 8 + (kt >> 1)] =
+                    (long long)__builtin_amdgcn_s_memrealtime();
+#endif
             ktile(std::integral_constant<int, 0>{}, ti == 0 || kt != 0);
             ktile(std::integral_constant<int, 1>{}, true);
         }
         // ---------------- epilogue
+        stamp_clk(ti, 6);
         stamp(ti, 1);
         AP_VMCNT(0);          // the stream staged so far (next tile's first K-tiles) has landed
         stamp(ti, 2);
@@ -383,7 +409,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
         int tr, tc;
         tw.rc(id, tr, tc);
         const int m0 = tr * kBM + wr * 128, n0 = tc * kBN + wc * 64;
-        load_bias(ti + 1 < tw.count ? ti + 1 : ti, hi);        // next tile's bias lands while this epilogue runs
+        // Next tile's bias (its accumulators start from it) has to be in flight BEFORE this epilogue's stores
+        // (in-order vmcnt: a younger load could only be awaited together with every store).  The store / GELU
+        // epilogues issue the loads once the first accumulator block has been consumed (its 32 registers are free)
+        // and wait with a count that leaves the last four stores in flight.
+        const int nti = ti + 1 < tw.count ? ti + 1 : ti;
+        const float* nbp = bias_ptr(nti, hi);
+        if constexpr (EPI == EPI_BIAS_RESID) { AP_BIAS_LD8(nbp); }
         const bool has_gamma = EPI != EPI_BIAS_GELU && g.gamma != nullptr;
         const float* gp = g.gamma + n0 + hi * 4;
         if (g.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(ti, 3); }
@@ -437,6 +469,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
                         }
                         *(u32x2*)(scr + l31 * 128 + (((nb * 4 + g4) ^ (l31 & 7)) << 4) + hi * 8) = pack4<T>(v);
                     }
+                if (mb == 0) { AP_BIAS_LD8(nbp); }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int row = i * 8 + rrow;
@@ -446,12 +479,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
                 }
             }
         }
+        // a full store / GELU wave tile issued exactly 16 stores after the bias loads, four of them in the last block
+        if (EPI != EPI_BIAS_RESID && m0 + 128 <= g.M) AP_BIAS_WAIT(4); else AP_BIAS_WAIT(0);
         stamp(ti, 4);
         init_acc();
     }
     AP_VMCNT(0);
 #undef AP_PHASE_SYNC
 #undef AP_MMA
+#undef AP_BIAS_LD
+#undef AP_BIAS_LD8
+#undef AP_BIAS_WAIT
 }
 
 template <typename T, int EPI>

@@ -7,7 +7,9 @@ from atlaspatch_amd import _lib
 dev = torch.device("cuda:0"); lib = _lib.load(); stream = _lib.current_stream_ptr(dev)
 g = torch.Generator(device=dev).manual_seed(0)
 M = 1024 * 197
-for name, N, K, epi, variant in (("qkv", 2304, 768, 0, 1), ("qkv", 2304, 768, 0, 0), ("fc1", 3072, 768, 1, 1), ("fc2", 768, 3072, 0, 1)):
+CASES = (("qkv", 2304, 768, 0, 0), ("fc1", 3072, 768, 1, 0), ("fc1-store-epilogue", 3072, 768, 0, 0), ("fc1-rowmajor-walk", 3072, 768, 1, 12 << 16),
+         ("fc1-N2304", 2304, 768, 1, 0), ("fc2", 768, 3072, 0, 0))
+for name, N, K, epi, variant in CASES:
     A = (torch.rand((M, K), device=dev, generator=g) * 2 - 1).half()
     W = ((torch.rand((N, K), device=dev, generator=g) * 2 - 1) * (2.0 / K ** 0.5)).half()
     bias = torch.rand(N, device=dev, generator=g) - 0.5
@@ -36,4 +38,6 @@ for name, N, K, epi, variant in (("qkv", 2304, 768, 0, 1), ("qkv", 2304, 768, 0,
     alld = np.concatenate([(t[w, :ntile[w], 2] - t[w, :ntile[w], 1]) for w in range(256)])
     allb = np.concatenate([(t[w, :ntile[w], 3] - t[w, :ntile[w], 2]) for w in range(256)])
     alle = np.concatenate([(t[w, :ntile[w], 4] - t[w, :ntile[w], 3]) for w in range(256)])
+    clk = np.concatenate([(t[w, 1:ntile[w], 6] - t[w, 1:ntile[w], 5]) / 0.01 / np.maximum(t[w, 1:ntile[w], 1] - t[w, 1:ntile[w], 0], 1e-9) for w in range(256)])
+    print(f" shader clock in the main loop (s_memtime ticks per us): mean {clk.mean():.0f}  p10 {np.percentile(clk,10):.0f}  p90 {np.percentile(clk,90):.0f}")
     print(f" all WGs: mainloop {allmain.mean():.2f} us/tile ({allmain.mean()/(K/64):.3f} us/K-tile)  drain {alld.mean():.2f}  bias {allb.mean():.2f}  epilogue {alle.mean():.2f}; kernel span {t[:,:,4].max()-start:.1f} us")

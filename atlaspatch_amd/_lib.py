@@ -12,7 +12,7 @@ import threading
 AP_F32, AP_F16, AP_BF16 = 0, 1, 2
 AP_OK = 0
 PROF_KINDS = ("preproc", "gemm_patch_embed", "gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2",
-              "attention", "layernorm")
+              "attention", "layernorm", "cls_tail")
 AP_ERR_CAPACITY = -6
 
 _LIB_NAME = "libatlaspatch_hip.so"

@@ -127,6 +127,9 @@ int launch_attention(int dtype, const void* qkv, void* out, int n, int tokens, i
 int launch_attention_flash(int dtype, const void* qkv, void* out, int n, int tokens, int heads,
                            hipStream_t stream);
 // attentional pooling (attn_pool.hip): kv T [n*tokens, 2*heads*64] (k | v), q f32 [heads*64] -> out T [n, heads*64]
+// one query row per (image, head) (CLS row of the last block); q packed [n, heads*64], k / v inside rows of `kv`
+int launch_attention_cls(int dtype, const void* q, const void* kv, int ld, int koff, int voff, void* out, int n,
+                         int tokens, int heads, int head_dim, hipStream_t stream);
 int launch_attn_pool(int dtype, const void* kv, const float* q, void* out, int n, int tokens, int heads,
                      hipStream_t stream);
 int launch_cls_init(float* tok, const float* cls, const float* pos, int n, int tokens, int dim,

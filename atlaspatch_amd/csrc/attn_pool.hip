@@ -82,6 +82,68 @@ __global__ __launch_bounds__(256) void attn_pool_kernel(const T* __restrict__ kv
     }
 }
 
+
+// One query per (image, head) taken from the data: the CLS row of the LAST encoder block.  Its output is the only
+// row of that block anything reads (the CLS readout), so the block's attention is this kernel instead of the full
+// [tokens x tokens] one.   q : T [n, heads * 64] (the CLS rows' projected queries, packed),
+// kv rows: T [n * tokens, ld] with k at column koff + head * 64 and v at voff + head * 64; out : T [n, heads * 64].
+// Same structure as the pooler above (scores in LDS, block softmax in f32, V rows streamed).
+template <typename T> struct RowVec { using v8 = typename PoolVec<T>::v8; };
+template <> struct RowVec<float> { typedef float v8 __attribute__((ext_vector_type(8))); };
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_cls_kernel(const T* __restrict__ q, const T* __restrict__ kv, int ld, int koff,
+                                                       int voff, T* __restrict__ out, int tokens, int heads) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];       // scores[tokens] | red[4] | part[4][64]
+    float* scores = sm;
+    float* red = sm + ((tokens + 3) & ~3);
+    float* part = red + 4;
+    using V8 = typename RowVec<T>::v8;
+    const int img = blockIdx.x / heads, head = blockIdx.x - img * heads;
+    const int P = heads * 64;
+    const T* kbase = kv + (size_t)img * tokens * ld + koff + head * 64;
+    const T* vbase = kv + (size_t)img * tokens * ld + voff + head * 64;
+    const T* qh = q + (size_t)img * P + head * 64;
+    float qr[64];
+#pragma unroll
+    for (int c8 = 0; c8 < 8; ++c8) {
+        const V8 qq = *(const V8*)(qh + c8 * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qr[c8 * 8 + e] = (float)qq[e];
+    }
+    float mx = -INFINITY;
+    for (int t = threadIdx.x; t < tokens; t += 256) {
+        const T* kp = kbase + (size_t)t * ld;
+        float s = 0.f;
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) {
+            const V8 kk = *(const V8*)(kp + c8 * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s = __builtin_fmaf((float)kk[e], qr[c8 * 8 + e], s);
+        }
+        s *= 0.125f;
+        scores[t] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = block_reduce(mx, red, true);
+    float sum = 0.f;
+    for (int t = threadIdx.x; t < tokens; t += 256) {
+        const float p = __expf(scores[t] - mx);
+        scores[t] = p;
+        sum += p;
+    }
+    sum = block_reduce(sum, red, false);          // its barriers also publish scores[]
+    const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    float acc = 0.f;
+    for (int t = grp; t < tokens; t += 4) acc = __builtin_fmaf(scores[t], (float)vbase[(size_t)t * ld + c], acc);
+    part[grp * 64 + c] = acc;
+    __syncthreads();
+    if (grp == 0) {
+        const float o = ((part[c] + part[64 + c]) + (part[128 + c] + part[192 + c])) / sum;
+        out[(size_t)img * P + head * 64 + c] = (T)o;
+    }
+}
+
 }  // namespace
 
 int launch_attn_pool(int dtype, const void* kv, const float* q, void* out, int n, int tokens, int heads,
@@ -93,6 +155,24 @@ int launch_attn_pool(int dtype, const void* kv, const float* q, void* out, int n
     dim3 grid(n * heads), block(256);
     if (dtype == AP_F16) attn_pool_kernel<f16><<<grid, block, lds, stream>>>((const f16*)kv, q, (f16*)out, tokens, heads);
     else attn_pool_kernel<bf16><<<grid, block, lds, stream>>>((const bf16*)kv, q, (bf16*)out, tokens, heads);
+    AP_HIP_CHECK(hipGetLastError());
+    return AP_OK;
+}
+
+int launch_attention_cls(int dtype, const void* q, const void* kv, int ld, int koff, int voff, void* out, int n,
+                         int tokens, int heads, int head_dim, hipStream_t stream) {
+    AP_REQUIRE(head_dim == 64, "attention_cls: head_dim %d unsupported (64 only)", head_dim);
+    AP_REQUIRE(tokens > 0 && tokens <= 12000, "attention_cls: %d tokens unsupported", tokens);
+    AP_REQUIRE(ld % 8 == 0 && koff % 8 == 0 && voff % 8 == 0, "attention_cls: misaligned layout");
+    if (n <= 0) return AP_OK;
+    const size_t lds = ((size_t)((tokens + 3) & ~3) + 4 + 256) * sizeof(float);
+    dim3 grid(n * heads), block(256);
+#define AP_CLS(T) attn_cls_kernel<T><<<grid, block, lds, stream>>>((const T*)q, (const T*)kv, ld, koff, voff, (T*)out, tokens, heads)
+    if (dtype == AP_F16) AP_CLS(f16);
+    else if (dtype == AP_BF16) AP_CLS(bf16);
+    else if (dtype == AP_F32) AP_CLS(float);
+    else { set_error("attention_cls: unsupported dtype %d", dtype); return AP_ERR_INVALID; }
+#undef AP_CLS
     AP_HIP_CHECK(hipGetLastError());
     return AP_OK;
 }

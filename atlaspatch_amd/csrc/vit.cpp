@@ -15,6 +15,7 @@
 #include <string>
 #include <vector>
 #include "ap_common.h"
+#include <cstdlib>
 
 namespace ap {
 
@@ -135,6 +136,10 @@ int run_blocks(ap_vit* m, int n, const Workspace& w, float* out, hipStream_t str
     // per block: ln1 normalises tok + fc2_prev WITHOUT storing it, ln2 folds fc2_prev and proj together
     // (same f32 operation order) and stores -> 620 MB less HBM traffic per block at n = 1024.
     const void* pending = nullptr;       // branch output not yet added to tok
+    long pending_stride = D;             // its row stride as seen from the final CLS LayerNorm
+    // AP_VIT_FULL_LAST_BLOCK=1 computes the last block for every token (A/B of the CLS-only tail; same features)
+    const bool full_last = getenv("AP_VIT_FULL_LAST_BLOCK") != nullptr;      // read per forward: tests toggle it
+    const bool cls_tail = c.pool == AP_POOL_CLS && !full_last && D / c.heads == 64;
     const float* pending_ls = nullptr;   // ... and its LayerScale vector (applied in f32 by the add)
     for (int i = 0; i < c.depth; ++i) {
         const std::string b = "blocks." + std::to_string(i) + ".";
@@ -144,6 +149,59 @@ int run_blocks(ap_vit* m, int n, const Workspace& w, float* out, hipStream_t str
           if ((rc = ap::launch_add2_layernorm(dt, dt, w.tok, D, pending, D, pending_ls, nullptr, 0, nullptr, /*store=*/0,
                                               M, D, vec("ln1.weight"), vec("ln1.bias"), c.ln_eps, w.xn,
                                               stream)) != AP_OK) return rc; }
+        if (i == c.depth - 1 && cls_tail) {
+            // ---- last block, CLS readout: nothing reads this block's output for the patch tokens, so only what the
+            // CLS row depends on is computed: K and V of every token, then the CLS row alone through q-projection,
+            // attention, proj, ln2, fc1, fc2.  Same operators, same operation order per row -> same features.
+            const size_t es = ap::dtype_size(dt);
+            const Param* wq = mat("qkv.weight");
+            const long cls_stride = (long)m->tokens * D;
+            char* q_cls = (char*)w.att;                                   // T [n, D]
+            char* a_cls = (char*)w.att + (size_t)n * D * es;              // T [n, D]
+            {
+                ap::GemmArgs g{};                                          // k | v for all rows
+                g.A = w.xn; g.lda = D; g.W = (const char*)wq->dev + (size_t)D * wq->ld * es; g.ldw = wq->ld;
+                g.M = M; g.N = 2 * D; g.K = D; g.bias = vec("qkv.bias") + D;
+                g.out = (char*)w.qkv + (size_t)D * es; g.ldo = 3 * D;
+                ScopedTimer t(m, AP_PROF_GEMM_QKV, stream);
+                if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_STORE, g, stream)) != AP_OK) return rc;
+            }
+            ScopedTimer t(m, AP_PROF_CLS_TAIL, stream);
+            {
+                ap::GemmArgs g{};                                          // q for the CLS rows
+                g.A = w.xn; g.lda = (int)cls_stride; g.W = wq->dev; g.ldw = wq->ld;
+                g.M = n; g.N = D; g.K = D; g.bias = vec("qkv.bias"); g.out = q_cls; g.ldo = D;
+                if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_STORE, g, stream)) != AP_OK) return rc;
+            }
+            if ((rc = ap::launch_attention_cls(dt, q_cls, w.qkv, 3 * D, D, 2 * D, a_cls, n, m->tokens, c.heads,
+                                               D / c.heads, stream)) != AP_OK) return rc;
+            {
+                ap::GemmArgs g{};
+                g.A = a_cls; g.lda = D; g.W = mat("proj.weight")->dev; g.ldw = mat("proj.weight")->ld;
+                g.M = n; g.N = D; g.K = D; g.bias = vec("proj.bias"); g.out = w.delta2; g.ldo = D;
+                if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_STORE, g, stream)) != AP_OK) return rc;
+            }
+            if ((rc = ap::launch_add2_layernorm(dt, dt, w.tok, cls_stride, pending, cls_stride, pending_ls, w.delta2, D,
+                                                c.layer_scale ? vec("ls1") : nullptr, /*store=*/1, n, D,
+                                                vec("ln2.weight"), vec("ln2.bias"), c.ln_eps, w.xn, stream)) != AP_OK)
+                return rc;
+            {
+                ap::GemmArgs g{};
+                g.A = w.xn; g.lda = D; g.W = mat("fc1.weight")->dev; g.ldw = mat("fc1.weight")->ld;
+                g.M = n; g.N = c.mlp_dim; g.K = D; g.bias = vec("fc1.bias"); g.out = w.hid; g.ldo = c.mlp_dim;
+                if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_GELU, g, stream)) != AP_OK) return rc;
+            }
+            {
+                ap::GemmArgs g{};
+                g.A = w.hid; g.lda = c.mlp_dim; g.W = mat("fc2.weight")->dev; g.ldw = mat("fc2.weight")->ld;
+                g.M = n; g.N = D; g.K = c.mlp_dim; g.bias = vec("fc2.bias"); g.out = w.delta; g.ldo = D;
+                if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_STORE, g, stream)) != AP_OK) return rc;
+            }
+            pending = w.delta;
+            pending_ls = c.layer_scale ? vec("ls2") : nullptr;
+            pending_stride = D;
+            break;
+        }
         {
             ap::GemmArgs g{};
             g.A = w.xn; g.lda = D; g.W = mat("qkv.weight")->dev; g.ldw = mat("qkv.weight")->ld;
@@ -186,7 +244,8 @@ int run_blocks(ap_vit* m, int n, const Workspace& w, float* out, hipStream_t str
     }
     if (c.pool == AP_POOL_CLS)
         // final LayerNorm on the CLS row of every image (last fc2 output folded in first) -> out f32 [n, D]
-        return ap::launch_add_layernorm(dt, AP_F32, w.tok, (long)m->tokens * D, pending, (long)m->tokens * D, pending_ls,
+        return ap::launch_add_layernorm(dt, AP_F32, w.tok, (long)m->tokens * D, pending,
+                                        cls_tail ? pending_stride : (long)m->tokens * D, pending_ls,
                                         n, D, (const float*)find(m, "norm.weight")->dev,
                                         (const float*)find(m, "norm.bias")->dev, c.ln_eps, out, stream);
 

@@ -27,6 +27,9 @@ import numpy as np
 import torch
 
 FLOP_PER_PATCH_VIT_B16 = 35.126e9      # 33.695 GEMM (incl. 0.231 patch-embed) + 1.431 attention
+# Executed by this build: the last block computes K / V for every token but everything after that for the CLS row only
+# (the only row the readout uses): 2.908 GFLOP of that block shrink to 0.477.
+FLOP_PER_PATCH_EXECUTED = FLOP_PER_PATCH_VIT_B16 - 2.908e9 + 0.477e9
 MFMA_PEAK = {"f16": 2.5e15, "bf16": 2.5e15, "f32": 157.3e12}   # dense, MI355X_MICROARCH.md
 
 
@@ -190,7 +193,9 @@ def main():
     #   pending branch) and LN2 (stream + two branches in, stream + normalised rows out); the final LN touches CLS rows only
     eb = 2.0 if short != "f32" else 4.0
     pre_bytes = B * 150528.0 * (1.0 + eb)
-    ln_bytes = M * 768.0 * (12 * ((4 + eb + eb) + (4 + 2 * eb + 4 + eb)) - eb)
+    full_last = bool(os.environ.get("AP_VIT_FULL_LAST_BLOCK"))
+    ln_blocks = 12 if full_last else 11          # the last block's LN2 runs on the CLS rows only (timed under cls_tail)
+    ln_bytes = M * 768.0 * (ln_blocks * ((4 + eb + eb) + (4 + 2 * eb + 4 + eb)) + (0 if full_last else 4 + eb + eb) - eb)
     hbm_kernels = {}
     for kind, nbytes in (("preproc", pre_bytes), ("layernorm", ln_bytes)):
         ms = prof[kind][0] / K
@@ -213,7 +218,10 @@ def main():
                      "algorithmic_bytes_per_launch": (M * 768 + 3072 * 768 + M * 3072) * 2.0,
                      "avg_launch_ms": round(fc1_avg_s * 1e3, 4), "launches": fc1_n,
                      "algorithmic_flop_per_launch": flop_launch},
-        "end_to_end_model_tflops": round(value * FLOP_PER_PATCH_VIT_B16 / 1e12 / world, 1),
+        "end_to_end_model_tflops": round(value * (FLOP_PER_PATCH_VIT_B16 if full_last else FLOP_PER_PATCH_EXECUTED) / 1e12 / world, 1),
+        "flop_per_patch": {"model": FLOP_PER_PATCH_VIT_B16, "executed": FLOP_PER_PATCH_VIT_B16 if full_last else FLOP_PER_PATCH_EXECUTED,
+                           "note": "last block: K/V for all tokens, the rest for the CLS row only (identical features); "
+                                   "AP_VIT_FULL_LAST_BLOCK=1 computes it for every token"},
         "kernel_ms_per_step": kernel_ms, "hbm_kernels": hbm_kernels,
         "coords": {"cells": cells, "rows": int(n_slide), "seconds": round(coords_s, 4),
                    "cells_per_s": round(cells / coords_s, 1)},

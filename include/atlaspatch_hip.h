@@ -149,7 +149,8 @@ int ap_vit_embed_dim(const ap_vit* m);   /* dim (AP_POOL_CLS) or pool_dim (AP_PO
 #define AP_PROF_GEMM_FC2 5
 #define AP_PROF_ATTENTION 6
 #define AP_PROF_LAYERNORM 7
-#define AP_PROF_KINDS 8
+#define AP_PROF_CLS_TAIL 8      /* last block after its K/V projection, CLS rows only (see ap_vit_forward_u8) */
+#define AP_PROF_KINDS 9
 int ap_vit_profile_enable(ap_vit* m, int on);
 int ap_vit_profile_read(ap_vit* m, double* ms_by_kind, long long* launches_by_kind, int kinds);
 

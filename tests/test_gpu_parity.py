@@ -236,6 +236,32 @@ def test_synth_tiles_bit_exact():
         assert np.array_equal(got[i], render_region(spec, int(x), int(y), 256, 256, 0)), i
 
 
+# ----------------------------------------------------------------------------- CLS-only tail of the last block
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.float16, 1e-3), (torch.bfloat16, 8e-3)])
+@pytest.mark.parametrize("arch_name", ["vit_b_16", "uni_v1"])
+def test_cls_tail_equals_full_last_block(dtype, tol, arch_name):
+    """The default forward computes the last block's K / V for every token and everything after for the CLS row only;
+    AP_VIT_FULL_LAST_BLOCK=1 runs the block for all tokens like the reference module does.  Same features (the CLS
+    row never depends on the other rows' outputs of that block); tolerance = rounding differences of the one-row
+    attention kernel (f32 softmax weights) vs the tiled one (weights rounded to T before the PV MFMA)."""
+    import os
+    from atlaspatch_amd.encoders.vit import ARCHS, build_hip_vit_extractor, random_canonical_state_dict
+    arch = dict(ARCHS[arch_name]); arch["depth"] = 3
+    state = random_canonical_state_dict(arch, seed=4)
+    ex = build_hip_vit_extractor(name="t", arch=arch, state_dict=state, source="canonical", device=_dev(), dtype=dtype,
+                                 expect_size=256)
+    rng = np.random.default_rng(3)
+    tiles = [rng.integers(0, 256, (256, 256, 3), dtype=np.uint8) for _ in range(5)]
+    got = ex.extract_batch(tiles)
+    os.environ["AP_VIT_FULL_LAST_BLOCK"] = "1"
+    try:
+        want = ex.extract_batch(tiles)
+    finally:
+        os.environ.pop("AP_VIT_FULL_LAST_BLOCK", None)
+    ex.cleanup()
+    assert _rel(got, want) <= tol, _rel(got, want)
+
+
 # ----------------------------------------------------------------------------- Pillow-exact device resize
 @pytest.mark.parametrize("filt", ["bicubic", "bilinear"])
 @pytest.mark.parametrize("in_hw,out_hw", [((256, 256), (224, 224)), ((256, 256), (448, 448)), ((300, 256), (262, 224)),

@@ -94,53 +94,61 @@ template <> struct RowVec<float> { typedef float v8 __attribute__((ext_vector_ty
 template <typename T>
 __global__ __launch_bounds__(256) void attn_cls_kernel(const T* __restrict__ q, const T* __restrict__ kv, int ld, int koff,
                                                        int voff, T* __restrict__ out, int tokens, int heads) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];       // scores[tokens] | red[4] | part[4][64]
+    // thread = (row slot r of 32, channel octet sub of 8): every K / V access is a 16-byte load and a wave covers eight
+    // whole 128-byte rows per step
+    extern __shared__ __attribute__((aligned(16))) float sm[];       // scores[tokens] | red[4] | part[32][64]
     float* scores = sm;
     float* red = sm + ((tokens + 3) & ~3);
     float* part = red + 4;
     using V8 = typename RowVec<T>::v8;
     const int img = blockIdx.x / heads, head = blockIdx.x - img * heads;
     const int P = heads * 64;
-    const T* kbase = kv + (size_t)img * tokens * ld + koff + head * 64;
-    const T* vbase = kv + (size_t)img * tokens * ld + voff + head * 64;
-    const T* qh = q + (size_t)img * P + head * 64;
-    float qr[64];
+    const int sub = threadIdx.x & 7, r = threadIdx.x >> 3;
+    const T* kbase = kv + (size_t)img * tokens * ld + koff + head * 64 + sub * 8;
+    const T* vbase = kv + (size_t)img * tokens * ld + voff + head * 64 + sub * 8;
+    float qr[8];
+    {
+        const V8 qq = *(const V8*)(q + (size_t)img * P + head * 64 + sub * 8);
 #pragma unroll
-    for (int c8 = 0; c8 < 8; ++c8) {
-        const V8 qq = *(const V8*)(qh + c8 * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) qr[c8 * 8 + e] = (float)qq[e];
+        for (int e = 0; e < 8; ++e) qr[e] = (float)qq[e];
     }
     float mx = -INFINITY;
-    for (int t = threadIdx.x; t < tokens; t += 256) {
-        const T* kp = kbase + (size_t)t * ld;
+    for (int t = r; t < tokens; t += 32) {
+        const V8 kk = *(const V8*)(kbase + (size_t)t * ld);
         float s = 0.f;
 #pragma unroll
-        for (int c8 = 0; c8 < 8; ++c8) {
-            const V8 kk = *(const V8*)(kp + c8 * 8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s = __builtin_fmaf((float)kk[e], qr[c8 * 8 + e], s);
-        }
+        for (int e = 0; e < 8; ++e) s = __builtin_fmaf((float)kk[e], qr[e], s);
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
         s *= 0.125f;
-        scores[t] = s;
+        if (sub == 0) scores[t] = s;
         mx = fmaxf(mx, s);
     }
-    mx = block_reduce(mx, red, true);
+    mx = block_reduce(mx, red, true);              // its barriers also publish scores[]
     float sum = 0.f;
     for (int t = threadIdx.x; t < tokens; t += 256) {
         const float p = __expf(scores[t] - mx);
         scores[t] = p;
         sum += p;
     }
-    sum = block_reduce(sum, red, false);          // its barriers also publish scores[]
-    const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    float acc = 0.f;
-    for (int t = grp; t < tokens; t += 4) acc = __builtin_fmaf(scores[t], (float)vbase[(size_t)t * ld + c], acc);
-    part[grp * 64 + c] = acc;
+    sum = block_reduce(sum, red, false);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int t = r; t < tokens; t += 32) {
+        const float p = scores[t];
+        const V8 vv = *(const V8*)(vbase + (size_t)t * ld);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = __builtin_fmaf(p, (float)vv[e], acc[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) part[r * 64 + sub * 8 + e] = acc[e];
     __syncthreads();
-    if (grp == 0) {
-        const float o = ((part[c] + part[64 + c]) + (part[128 + c] + part[192 + c])) / sum;
-        out[(size_t)img * P + head * 64 + c] = (T)o;
+    if (threadIdx.x < 64) {
+        const int c = threadIdx.x;
+        float o = 0.f;
+#pragma unroll
+        for (int g = 0; g < 32; ++g) o += part[g * 64 + c];
+        out[(size_t)img * P + head * 64 + c] = (T)(o / sum);
     }
 }
 
@@ -165,7 +173,7 @@ int launch_attention_cls(int dtype, const void* q, const void* kv, int ld, int k
     AP_REQUIRE(tokens > 0 && tokens <= 12000, "attention_cls: %d tokens unsupported", tokens);
     AP_REQUIRE(ld % 8 == 0 && koff % 8 == 0 && voff % 8 == 0, "attention_cls: misaligned layout");
     if (n <= 0) return AP_OK;
-    const size_t lds = ((size_t)((tokens + 3) & ~3) + 4 + 256) * sizeof(float);
+    const size_t lds = ((size_t)((tokens + 3) & ~3) + 4 + 32 * 64) * sizeof(float);
     dim3 grid(n * heads), block(256);
 #define AP_CLS(T) attn_cls_kernel<T><<<grid, block, lds, stream>>>((const T*)q, (const T*)kv, ld, koff, voff, (T*)out, tokens, heads)
     if (dtype == AP_F16) AP_CLS(f16);

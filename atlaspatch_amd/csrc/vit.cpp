@@ -166,12 +166,13 @@ int run_blocks(ap_vit* m, int n, const Workspace& w, float* out, hipStream_t str
                 ScopedTimer t(m, AP_PROF_GEMM_QKV, stream);
                 if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_STORE, g, stream)) != AP_OK) return rc;
             }
+            // n-row GEMMs on the 128x128 kernel: more workgroups than 256x256 tiles would give, bit-identical results
             ScopedTimer t(m, AP_PROF_CLS_TAIL, stream);
             {
                 ap::GemmArgs g{};                                          // q for the CLS rows
                 g.A = w.xn; g.lda = (int)cls_stride; g.W = wq->dev; g.ldw = wq->ld;
                 g.M = n; g.N = D; g.K = D; g.bias = vec("qkv.bias"); g.out = q_cls; g.ldo = D;
-                if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_STORE, g, stream)) != AP_OK) return rc;
+                if ((rc = ap::launch_gemm_impl(dt, ap::EPI_BIAS_STORE, g, 128, 0, stream)) != AP_OK) return rc;
             }
             if ((rc = ap::launch_attention_cls(dt, q_cls, w.qkv, 3 * D, D, 2 * D, a_cls, n, m->tokens, c.heads,
                                                D / c.heads, stream)) != AP_OK) return rc;
@@ -179,7 +180,7 @@ int run_blocks(ap_vit* m, int n, const Workspace& w, float* out, hipStream_t str
                 ap::GemmArgs g{};
                 g.A = a_cls; g.lda = D; g.W = mat("proj.weight")->dev; g.ldw = mat("proj.weight")->ld;
                 g.M = n; g.N = D; g.K = D; g.bias = vec("proj.bias"); g.out = w.delta2; g.ldo = D;
-                if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_STORE, g, stream)) != AP_OK) return rc;
+                if ((rc = ap::launch_gemm_impl(dt, ap::EPI_BIAS_STORE, g, 128, 0, stream)) != AP_OK) return rc;
             }
             if ((rc = ap::launch_add2_layernorm(dt, dt, w.tok, cls_stride, pending, cls_stride, pending_ls, w.delta2, D,
                                                 c.layer_scale ? vec("ls1") : nullptr, /*store=*/1, n, D,
@@ -189,13 +190,13 @@ int run_blocks(ap_vit* m, int n, const Workspace& w, float* out, hipStream_t str
                 ap::GemmArgs g{};
                 g.A = w.xn; g.lda = D; g.W = mat("fc1.weight")->dev; g.ldw = mat("fc1.weight")->ld;
                 g.M = n; g.N = c.mlp_dim; g.K = D; g.bias = vec("fc1.bias"); g.out = w.hid; g.ldo = c.mlp_dim;
-                if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_GELU, g, stream)) != AP_OK) return rc;
+                if ((rc = ap::launch_gemm_impl(dt, ap::EPI_BIAS_GELU, g, 128, 0, stream)) != AP_OK) return rc;
             }
             {
                 ap::GemmArgs g{};
                 g.A = w.hid; g.lda = c.mlp_dim; g.W = mat("fc2.weight")->dev; g.ldw = mat("fc2.weight")->ld;
                 g.M = n; g.N = D; g.K = c.mlp_dim; g.bias = vec("fc2.bias"); g.out = w.delta; g.ldo = D;
-                if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_STORE, g, stream)) != AP_OK) return rc;
+                if ((rc = ap::launch_gemm_impl(dt, ap::EPI_BIAS_STORE, g, 128, 0, stream)) != AP_OK) return rc;
             }
             pending = w.delta;
             pending_ls = c.layer_scale ? vec("ls2") : nullptr;

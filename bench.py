@@ -179,7 +179,7 @@ def main():
     # HBM bytes of that kernel from the PMC counters (separate rocprofv3 --pmc passes of this same command,
     # summarised by tools/pmc_traffic.py into profiles/; FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md)
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01c_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r01d_traffic.json")
     if short != "f32" and B == 2048 and os.path.exists(tpath):
         with open(tpath) as fh:
             for kname, rec in json.load(fh).items():

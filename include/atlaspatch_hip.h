@@ -155,7 +155,9 @@ int ap_vit_profile_enable(ap_vit* m, int on);
 int ap_vit_profile_read(ap_vit* m, double* ms_by_kind, long long* launches_by_kind, int kinds);
 
 /* patches: device uint8 [n, h, w, 3]; centre-cropped to image_size, normalised with
- * mean/std, embedded.  out: device float32 [n, dim].  Asynchronous on `stream`. */
+ * mean/std, embedded.  out: device float32 [n, dim].  Asynchronous on `stream`.
+ * For the CLS readout the last block computes K / V for every token and everything after that for the CLS row
+ * only (nothing reads the other rows; identical features; AP_VIT_FULL_LAST_BLOCK=1 disables it). */
 int ap_vit_forward_u8(ap_vit* m, const uint8_t* patches, int n, int h, int w,
                       const float mean[3], const float stdv[3],
                       float* out, void* workspace, size_t workspace_bytes, ap_stream_t stream);

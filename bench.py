@@ -242,11 +242,13 @@ def main():
                                f"resident in HBM, ViT-B/16 (random-init), device batch {B}",
                    "tiles_per_step": B, "slide_tissue_tiles": int(n_slide), "grid_cells": cells,
                    "parallelism": f"slide-per-rank x{world}" + (" + RCCL all-gather of features" if world > 1 else "")},
-        "roofline": {"bound": "mfma", "kernel": "gemm256_kernel<T,EPI_BIAS_GELU> (fc1: [B*197,768]x[768,3072], "
-                                                        "persistent 256x256-tile MFMA GEMM)",
+        "roofline": {"bound": "mfma", "kernel": ("gemm256_kernel<T,EPI_BIAS_GELU> (fc1: [B*197,768]x[768,3072], "
+                                                         "persistent 256x256-tile MFMA GEMM)") if short != "f32" else
+                                                        ("gemm_kernel<float,EPI_BIAS_GELU> (fc1: [B*197,768]x[768,3072], "
+                                                         "128x128-tile v_mfma_f32_32x32x2_f32 GEMM)"),
                      "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "TFLOP/s",
                      "frac": round(achieved / peak, 4), "traffic": traffic,
-                     "algorithmic_bytes_per_launch": (M * 768 + 3072 * 768 + M * 3072) * 2.0,
+                     "algorithmic_bytes_per_launch": (M * 768 + 3072 * 768 + M * 3072) * (4.0 if short == "f32" else 2.0),
                      "avg_launch_ms": round(fc1_avg_s * 1e3, 4), "launches": fc1_n,
                      "algorithmic_flop_per_launch": flop_launch},
         "end_to_end_model_tflops": round(value * (FLOP_PER_PATCH_VIT_B16 if full_last else FLOP_PER_PATCH_EXECUTED) / 1e12 / world, 1),

@@ -66,6 +66,20 @@ __device__ __forceinline__ float gelu_sigmoid_poly(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// The same function on four values with the full-rate operations packed two per instruction (v_pk_mul_f32 /
+// v_pk_fma_f32 / v_pk_add_f32: IEEE-identical to the scalar forms, so results are bit-identical to
+// gelu_sigmoid_poly); min, exp and rcp have no packed form.  The fc1 epilogue is VALU-bound on this.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t gelu_sigmoid_poly2(f32x2_t x) {
+    f32x2_t t = x * x;
+    t = f32x2_t{fminf(t[0], 50.0f), fminf(t[1], 50.0f)};
+    f32x2_t p = __builtin_elementwise_fma(t, f32x2_t{1.0148166e-3f, 1.0148166e-3f}, f32x2_t{-1.0677913e-1f, -1.0677913e-1f});
+    p = __builtin_elementwise_fma(t, p, f32x2_t{-2.3011176f, -2.3011176f});
+    const f32x2_t z = x * p;
+    const f32x2_t d = f32x2_t{1.0f, 1.0f} + f32x2_t{__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])};
+    return x * f32x2_t{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+}
+
 // ---- GEMM ------------------------------------------------------------------------------
 // C[m][n] = sum_k A[m][k] * W[n][k]  (+ epilogue); A: activations [M, lda], W: weights [N, ldw],
 // both K-contiguous in the compute dtype.

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
                     store4<T>((T*)g.out + orow + n, v);
                 } else if constexpr (EPI == EPI_BIAS_GELU) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = sizeof(T) == 2 ? gelu_sigmoid_poly(v[e]) : gelu_erf(v[e]);
+                    for (int e = 0; e < 4; ++e) v[e] = sizeof(T) == 2 ? gelu_sigmoid_poly(v[e]) : gelu_erf(v[e]);   // == gelu_sigmoid_poly2 bitwise
                     store4<T>((T*)g.out + orow + n, v);
                 } else if constexpr (EPI == EPI_BIAS_RESID) {
                     float* dst = (float*)g.out + orow + n;

@@ -458,9 +458,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
                     for (int g4 = 0; g4 < 4; ++g4) {
                         f32x4 v;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            v[e] = acc[nb][mb][g4 * 4 + e];
-                            if constexpr (EPI == EPI_BIAS_GELU) v[e] = gelu_sigmoid_poly(v[e]);
+                        for (int e = 0; e < 4; ++e) v[e] = acc[nb][mb][g4 * 4 + e];
+                        if constexpr (EPI == EPI_BIAS_GELU) {
+                            const f32x2_t lo = gelu_sigmoid_poly2(f32x2_t{v[0], v[1]}), hi2 = gelu_sigmoid_poly2(f32x2_t{v[2], v[3]});
+                            v = f32x4{lo[0], lo[1], hi2[0], hi2[1]};
                         }
                         if (has_gamma) {
                             const f32x4 ga = *(const f32x4*)(gp + nb * 32 + g4 * 8);

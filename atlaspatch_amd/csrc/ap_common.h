@@ -57,18 +57,11 @@ template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf
 // (coefficients: minimax fit against 0.5 x (1 + erf(x / sqrt 2)) on [-9, 9], max |error| 2.6e-5,
 // below f16's half-ulp for |gelu| >= 0.06; the clamp keeps the odd polynomial monotone so the
 // sigmoid saturates correctly for any |x|).  -log2(e) is folded into the coefficients:
-// 7 VALU + v_exp_f32 + v_rcp_f32.  The f32 mode uses libm erff instead.
-__device__ __forceinline__ float gelu_sigmoid_poly(float x) {
-    const float t = fminf(x * x, 50.0f);
-    float p = __builtin_fmaf(t, 1.0148166e-3f, -1.0677913e-1f);      // -log2e * (c2 t + c1)
-    p = __builtin_fmaf(t, p, -2.3011176f);                           // -log2e * c0
-    const float e = __builtin_amdgcn_exp2f(x * p);
-    return x * __builtin_amdgcn_rcpf(1.0f + e);
-}
-
-// The same function on four values with the full-rate operations packed two per instruction (v_pk_mul_f32 /
-// v_pk_fma_f32 / v_pk_add_f32: IEEE-identical to the scalar forms, so results are bit-identical to
-// gelu_sigmoid_poly); min, exp and rcp have no packed form.  The fc1 epilogue is VALU-bound on this.
+// per value 1 min + 3 packed (mul, 2 fma, mul, add, mul over two values) + v_exp_f32 + v_rcp_f32.  The f32 mode uses libm erff.
+// Evaluated two values at a time with the full-rate operations packed two per instruction (v_pk_mul_f32 /
+// v_pk_fma_f32 / v_pk_add_f32); min, exp and rcp have no packed form.  The fc1 epilogue is VALU-bound on this.
+// Both GEMM kernels call THIS routine (hipcc contracts the scalar form differently: 1-ulp differences), so the
+// 128x128 and the 256x256 kernel stay bit-identical.
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2_t gelu_sigmoid_poly2(f32x2_t x) {
     f32x2_t t = x * x;

@@ -195,7 +195,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
                     store4<T>((T*)g.out + orow + n, v);
                 } else if constexpr (EPI == EPI_BIAS_GELU) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = sizeof(T) == 2 ? gelu_sigmoid_poly(v[e]) : gelu_erf(v[e]);   // == gelu_sigmoid_poly2 bitwise
+                    for (int e = 0; e < 4; ++e) if (sizeof(T) != 2) v[e] = gelu_erf(v[e]);
+                    if constexpr (sizeof(T) == 2) {      // the same packed routine as gemm256: the two kernels stay bit-identical
+                        const f32x2_t lo = gelu_sigmoid_poly2(f32x2_t{v[0], v[1]}), hi2 = gelu_sigmoid_poly2(f32x2_t{v[2], v[3]});
+                        v = f32x4{lo[0], lo[1], hi2[0], hi2[1]};
+                    }
                     store4<T>((T*)g.out + orow + n, v);
                 } else if constexpr (EPI == EPI_BIAS_RESID) {
                     float* dst = (float*)g.out + orow + n;

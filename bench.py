@@ -210,8 +210,10 @@ def main():
     # HBM bytes of that kernel from the PMC counters (separate rocprofv3 --pmc passes of this same command,
     # summarised by tools/pmc_traffic.py into profiles/; FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md)
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01d_traffic.json")
-    if short != "f32" and B == 2048 and os.path.exists(tpath):
+    import glob
+    tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))      # the latest round's PMC summary
+    tpath = tfiles[-1] if tfiles else ""
+    if short != "f32" and B == 2048 and tpath and os.path.exists(tpath):
         with open(tpath) as fh:
             for kname, rec in json.load(fh).items():
                 if "gemm256_kernel" in kname and ("Li1E" in kname or "EPI_BIAS_GELU" in kname or ", 1>" in kname) \

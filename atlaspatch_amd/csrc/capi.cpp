@@ -19,7 +19,7 @@ void set_error(const char* fmt, ...) {
 
 extern "C" {
 
-int ap_abi_version(void) { return 6; }
+int ap_abi_version(void) { return 7; }
 
 const char* ap_last_error(void) { return ap::g_error; }
 
@@ -47,6 +47,16 @@ int ap_preproc_u8hwc_to_patchrows(const uint8_t* src, int n, int h, int w, int c
                                   ap_stream_t stream) {
     return ap::preproc_patchrows(src, n, h, w, crop_top, crop_left, oh, ow, ps, mean, stdv, dst, ld,
                                  dst_dtype, (hipStream_t)stream);
+}
+
+int ap_host_gather_tiles(void* dst, const void* const* src, int n, size_t bytes_each) {
+    AP_REQUIRE(dst && (src || n == 0) && n >= 0, "ap_host_gather_tiles: bad arguments");
+    char* d = (char*)dst;
+    for (int i = 0; i < n; ++i) {
+        AP_REQUIRE(src[i], "ap_host_gather_tiles: null tile %d", i);
+        memcpy(d + (size_t)i * bytes_each, src[i], bytes_each);
+    }
+    return AP_OK;
 }
 
 int ap_tile_content_counts(const uint8_t* tiles, int n, int h, int w, int black_thresh, int white_sat_thresh,

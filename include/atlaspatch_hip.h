@@ -63,6 +63,13 @@ int ap_preproc_u8hwc_to_patchrows(const uint8_t* src, int n, int h, int w,
                                   const float mean[3], const float stdv[3],
                                   void* dst, int ld, int dst_dtype, ap_stream_t stream);
 
+/* ---- host side of the tile ring ----------------------------------------------------------
+ * Copies n decoded tiles (host pointers, bytes_each bytes each) into consecutive slots of a pinned staging buffer.
+ * Plain memcpy outside the interpreter lock: the decode threads of the ring that replaces the serial tile loop of
+ * services/feature_embedding.py:81-96 call it once per chunk, so an in-memory tile source is not serialised by
+ * per-tile NumPy slice assignments.  Host only, no device work. */
+int ap_host_gather_tiles(void* dst, const void* const* src, int n, size_t bytes_each);
+
 /* ---- Pillow-exact tile resampling ------------------------------------------------------
  * Replaces the PIL resize inside the per-item transform of encoders whose transform starts with Resize:
  * timm's Resize(224, bicubic) for uni_v1 (models/patch/uni.py:48-49) and open_clip's Resize(448, bicubic)

@@ -257,7 +257,7 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/atlaspatch_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert _lib.load().ap_abi_version() == 6
+    assert _lib.load().ap_abi_version() == 7
 
 
 def test_product_has_no_cpu_fallback():
@@ -310,3 +310,17 @@ def test_pillow_resample_tables_reproduce_pil():
         img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
         for f, pf in (("bicubic", Image.Resampling.BICUBIC), ("bilinear", Image.Resampling.BILINEAR)):
             assert np.array_equal(apply(img, oh, ow, f), np.asarray(Image.fromarray(img).resize((ow, oh), pf))), (h, w, f)
+
+
+def test_host_gather_tiles_copies_in_order():
+    """ap_host_gather_tiles (host-only entry of the C ABI): n scattered tiles -> consecutive slots."""
+    import ctypes as C
+    from atlaspatch_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    tiles = [rng.integers(0, 256, (8, 8, 3), dtype=np.uint8) for _ in range(5)]
+    dst = np.zeros((5, 8, 8, 3), np.uint8)
+    ptrs = (C.c_void_p * 5)(*[t.ctypes.data for t in tiles])
+    assert lib.ap_host_gather_tiles(dst.ctypes.data, ptrs, 5, 8 * 8 * 3) == 0
+    assert all(np.array_equal(dst[i], tiles[i]) for i in range(5))
+    assert lib.ap_host_gather_tiles(dst.ctypes.data, ptrs, 0, 8 * 8 * 3) == 0

@@ -219,6 +219,17 @@ def main():
                 if "gemm256_kernel" in kname and ("Li1E" in kname or "EPI_BIAS_GELU" in kname or ", 1>" in kname) \
                         and ("DF16_" in kname) == (short == "f16"):
                     traffic = rec["hbm_bytes_per_launch"]
+    # MFMA-pipe utilisation and effective shader clock of the same kernel from the PMC pass of the same command
+    # (SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE; tools/pmc_mfma.py -> profiles/): frac ~= mfma_util * clock / 2.4 GHz
+    pmc_mfma = None
+    mfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mfma_util.json")))
+    if short != "f32" and B == 2048 and mfiles:
+        with open(mfiles[-1]) as fh:
+            for kname, rec in json.load(fh).items():
+                if "gemm256_kernel" in kname and "Li1E" in kname and ("DF16_" in kname) == (short == "f16"):
+                    pmc_mfma = {"mfma_util": round(rec["mfma_util"], 4),
+                                "effective_clock_GHz": round(rec.get("effective_clock_GHz", 0.0), 3),
+                                "source": os.path.basename(mfiles[-1])}
     kernel_ms = {k: round(v[0] / K, 4) for k, v in prof.items()}
     # the HBM-bound kernels of the path, same HIP-event timers, algorithmic bytes:
     #   preprocess: reads the 224x224x3 u8 centre crop, writes the [196, 768] patch matrix in the compute dtype
@@ -249,7 +260,7 @@ def main():
                                                         ("gemm_kernel<float,EPI_BIAS_GELU> (fc1: [B*197,768]x[768,3072], "
                                                          "128x128-tile v_mfma_f32_32x32x2_f32 GEMM)"),
                      "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "TFLOP/s",
-                     "frac": round(achieved / peak, 4), "traffic": traffic,
+                     "frac": round(achieved / peak, 4), "traffic": traffic, "pmc": pmc_mfma,
                      "algorithmic_bytes_per_launch": (M * 768 + 3072 * 768 + M * 3072) * (4.0 if short == "f32" else 2.0),
                      "avg_launch_ms": round(fc1_avg_s * 1e3, 4), "launches": fc1_n,
                      "algorithmic_flop_per_launch": flop_launch},

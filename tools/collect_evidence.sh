@@ -17,5 +17,8 @@ if [ -n "$DB" ]; then python profiles/summarize_rocpd.py "$DB" > "$OUT/kernel_st
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o f -- $CMD > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o w -- $CMD > "$OUT/pmc_write.log" 2>&1
 python tools/pmc_traffic.py "$OUT/pmc_fetch" "$OUT/pmc_write" > "$OUT/traffic.json"
-rm -rf "$OUT/kt" "$OUT/pmc_fetch" "$OUT/pmc_write"
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_mfma" -o m -- $CMD > "$OUT/pmc_mfma.log" 2>&1
+head -1 $(find "$OUT/pmc_mfma" -name "*counter_collection.csv" | head -1) > "$OUT/pmc_mfma_columns.txt" 2>/dev/null
+python tools/pmc_mfma.py "$OUT/pmc_mfma" > "$OUT/mfma_util.json"
+rm -rf "$OUT/kt" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_mfma"
 head -30 "$OUT/kernel_stats.txt"

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""usage: e2e_profile.py [encoder=vit_b_16] [slide_side=100000] [host_tiles=0]
+"""usage: e2e_profile.py [encoder=vit_b_16] [slide_side=100000] [host_tiles=0] [weights=random|file]
+weights=file: the seeded weights are first written to <tmp>/<encoder>.safetensors (untimed) and the run loads them through
+ATLASPATCH_WEIGHTS_DIR like a real checkpoint, instead of generating 86-303 M random parameters on the host inside the run.
 Where the wall time of one `process` CLI run goes (cProfile, cumulative, top functions of this package)."""
 import cProfile, io, json, os, pstats, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,6 +15,12 @@ from click.testing import CliRunner
 from atlaspatch_amd.cli import cli
 torch.zeros(1, device="cuda")            # context creation is not the pipeline's cost
 with tempfile.TemporaryDirectory() as tmp:
+    if len(sys.argv) > 4 and sys.argv[4] == "file":
+        from safetensors.torch import save_file
+        from atlaspatch_amd.encoders.vit import ARCHS, random_canonical_state_dict
+        save_file(random_canonical_state_dict(ARCHS[arch], 0), os.path.join(tmp, f"{arch}.safetensors"))
+        os.environ["ATLASPATCH_WEIGHTS_DIR"] = tmp
+        os.environ.pop("ATLASPATCH_RANDOM_INIT", None)
     slide = os.path.join(tmp, "big.synth")
     json.dump({"width": side, "height": side, "seed": 1234, "mag": 20, "mpp": 0.5, "downsamples": [1, 4, 16]}, open(slide, "w"))
     args = ["process", slide, "-o", os.path.join(tmp, "out"), "--patch-size", "256", "--target-mag", "20",

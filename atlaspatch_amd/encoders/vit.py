@@ -379,7 +379,7 @@ def register_vits(registry, *, device, dtype=torch.float32, num_workers: int = 0
     resize 256) -- for the 256-px tiles this pipeline produces that is a centre crop."""
     for name in ("vit_b_16", "vit_l_16"):
         registry.register(name, lambda n=name: build_hip_vit_extractor(
-            name=n, arch=n, device=device, dtype=dtype, random_init_seed=_env_seed(), expect_size=256))
+            name=n, arch=n, device=device, dtype=dtype, random_init_seed=_env_seed(), expect_size=256, max_batch=2048))
 
 
 def register_uni(registry, *, device, dtype=torch.float32, num_workers: int = 0) -> None:
@@ -387,4 +387,4 @@ def register_uni(registry, *, device, dtype=torch.float32, num_workers: int = 0)
     the resize runs on the device bit-identically to Pillow (ap_resample_u8), the crop in the preprocess kernel."""
     registry.register("uni_v1", lambda: build_hip_vit_extractor(
         name="uni_v1", arch="uni_v1", device=device, dtype=dtype, random_init_seed=_env_seed(),
-        resize=(224, "bicubic"), expect_size=None))
+        resize=(224, "bicubic"), expect_size=None, max_batch=2048))

@@ -199,7 +199,10 @@ class PatchFeatureEmbeddingService(FeatureEmbeddingService):
         """float32 [N, D] for one slide through the pinned tile ring (device pipeline)."""
         from .tile_ring import TileRing
         coords = read_coords(result.h5_path)
-        batch = max(self.feature_cfg.batch_size, min(1024, max(1, coords.shape[0])))
+        # device batch: 2048 tiles quantise best onto the 256 persistent GEMM workgroups (DESIGN.md section 5); never above
+        # what the encoder accepts in one forward, never below the CLI's --feature-batch-size
+        cap = min(2048, max(1, int(getattr(extractor, "max_batch", 1024))))
+        batch = max(self.feature_cfg.batch_size, min(cap, max(1, coords.shape[0])))
         feats = self._embed_device_source(coords, wsi, extractor, batch)
         if feats is not None:
             return feats

@@ -375,11 +375,14 @@ def _env_seed() -> Optional[int]:
 
 
 def register_vits(registry, *, device, dtype=torch.float32, num_workers: int = 0) -> None:
-    """vit_b_16 / vit_l_16 with torchvision's transform semantics: ImageClassification(crop 224,
-    resize 256) -- for the 256-px tiles this pipeline produces that is a centre crop."""
+    """vit_b_16 / vit_l_16 with torchvision's transform semantics: ImageClassification(crop 224, resize 256,
+    bilinear) on the PIL tile (models/patch/base.py:42-45 hands the transform a PIL image, so the resize is
+    Pillow's BILINEAR): for the 256-px tiles this pipeline produces by default it is a pure centre crop; other
+    --patch-size values go through the Pillow-exact device resize (shorter side -> 256) first."""
     for name in ("vit_b_16", "vit_l_16"):
         registry.register(name, lambda n=name: build_hip_vit_extractor(
-            name=n, arch=n, device=device, dtype=dtype, random_init_seed=_env_seed(), expect_size=256, max_batch=2048))
+            name=n, arch=n, device=device, dtype=dtype, random_init_seed=_env_seed(), resize=(256, "bilinear"),
+            expect_size=None, max_batch=2048))
 
 
 def register_uni(registry, *, device, dtype=torch.float32, num_workers: int = 0) -> None:

@@ -303,6 +303,28 @@ def test_uni_transform_device_resize_matches_host_pillow():
     ex.cleanup()
 
 
+def test_vit_b16_other_tile_sizes_resize_like_torchvision_on_pil():
+    """--patch-size 512 (or any size != 256): torchvision's ImageClassification resizes the PIL tile to shorter side
+    256 with Pillow's BILINEAR before the centre crop; the registered vit_b_16 does that on the device, bit-identically
+    to resizing with Pillow on the host first."""
+    import os
+    from PIL import Image
+    from atlaspatch_amd.encoders import build_default_registry
+    os.environ["ATLASPATCH_RANDOM_INIT"] = "5"
+    try:
+        ex = build_default_registry(device="cuda", dtype=torch.float16).create("vit_b_16")
+    finally:
+        os.environ.pop("ATLASPATCH_RANDOM_INIT", None)
+    rng = np.random.default_rng(12)
+    for hw in ((512, 512), (384, 320)):
+        tiles = [rng.integers(0, 256, (*hw, 3), dtype=np.uint8) for _ in range(3)]
+        h, w = hw
+        nw, nh = (256, int(256 * h / w)) if w <= h else (int(256 * w / h), 256)
+        pre = [np.asarray(Image.fromarray(t).resize((nw, nh), Image.Resampling.BILINEAR)) for t in tiles]
+        assert np.array_equal(ex.extract_batch(tiles), ex.extract_batch(pre))
+    ex.cleanup()
+
+
 # ----------------------------------------------------------------------------- CONCH v1 (a16)
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 5e-3), (torch.bfloat16, 3e-2)])
 def test_conch_visual_tower_vs_oracle(dtype, tol):

@@ -194,6 +194,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # Secondary, untimed-for-`value` measurement: the same K steps with the last block computed for every token
+    # (AP_VIT_FULL_LAST_BLOCK=1, read per forward), so the line shows what the CLS-only tail is worth.
+    full_value = None
+    if world == 1 and not os.environ.get("AP_VIT_FULL_LAST_BLOCK"):
+        os.environ["AP_VIT_FULL_LAST_BLOCK"] = "1"
+        try:
+            step(0, feats[:B])
+            torch.cuda.synchronize(device)
+            t1 = time.perf_counter()
+            for i in range(K):
+                step(i, feats[i * B:(i + 1) * B])
+            torch.cuda.synchronize(device)
+            full_value = K * B / (time.perf_counter() - t1)
+        finally:
+            os.environ.pop("AP_VIT_FULL_LAST_BLOCK", None)
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -267,7 +283,8 @@ def main():
         "end_to_end_model_tflops": round(value * (FLOP_PER_PATCH_VIT_B16 if full_last else FLOP_PER_PATCH_EXECUTED) / 1e12 / world, 1),
         "flop_per_patch": {"model": FLOP_PER_PATCH_VIT_B16, "executed": FLOP_PER_PATCH_VIT_B16 if full_last else FLOP_PER_PATCH_EXECUTED,
                            "note": "last block: K/V for all tokens, the rest for the CLS row only (identical features); "
-                                   "AP_VIT_FULL_LAST_BLOCK=1 computes it for every token"},
+                                   "AP_VIT_FULL_LAST_BLOCK=1 computes it for every token",
+                           "value_with_full_last_block": None if full_value is None else round(full_value, 1)},
         "kernel_ms_per_step": kernel_ms, "hbm_kernels": hbm_kernels,
         "coords": {"cells": cells, "rows": int(n_slide), "seconds": round(coords_s, 4),
                    "cells_per_s": round(cells / coords_s, 1)},

@@ -91,75 +91,93 @@ template <typename T> __device__ __forceinline__ void store_vec8(T* p, f32x4 a, 
     }
 }
 
+// The per-column parameters (gamma, beta and the LayerScale vectors) are staged once per workgroup in LDS (one
+// coalesced 16-byte load per thread and vector): read from global memory per row they cost 2-4 extra 16-byte loads
+// per lane and vector (uni_v1's two LayerScale vectors made add+LN 26 % slower than vit_l_16's: 50.0 -> 39.7 ms).
 template <typename TD, typename TO, int NV, bool WIDE>
 __global__ __launch_bounds__(256) void layernorm16_kernel(float* __restrict__ x, long stride,
                                                           LnAdds add, int rows, int dim,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float eps,
-                                                          TO* __restrict__ out) {
+                                                          TO* __restrict__ out, int groups) {
+    extern __shared__ __attribute__((aligned(16))) float prm[];      // gamma | beta | ls0 | ls1, dim floats each
+    float* sg = prm;
+    float* sb = prm + dim;
+    const float* sls[2] = {add.ls[0] ? prm + 2 * dim : nullptr, add.ls[1] ? prm + 3 * dim : nullptr};
+    for (int i = threadIdx.x * 4; i < dim; i += 1024) {
+        *(f32x4*)(sg + i) = *(const f32x4*)(gamma + i);
+        *(f32x4*)(sb + i) = *(const f32x4*)(beta + i);
+        if (add.ls[0]) *(f32x4*)(prm + 2 * dim + i) = *(const f32x4*)(add.ls[0] + i);
+        if (add.ls[1]) *(f32x4*)(prm + 3 * dim + i) = *(const f32x4*)(add.ls[1] + i);
+    }
+    __syncthreads();
     const int l16 = threadIdx.x & 15;
-    int row = blockIdx.x * 16 + (threadIdx.x >> 4);
-    const bool live = row < rows;
-    if (!live) row = rows - 1;                       // keep all lanes in the DPP reductions
-    float* src = x + (size_t)row * stride;
     // element offset of the lane's i-th f32x4
     auto off = [&](int i) { return WIDE ? (((i >> 1) * 16 + l16) * 8 + (i & 1) * 4) : ((l16 + i * 16) * 4); };
-    f32x4 v[NV];
-    float s = 0.f;
+    for (int rg = 0; rg < groups; ++rg) {
+        const int row0 = (blockIdx.x * groups + rg) * 16;
+        if (row0 >= rows) break;
+        int row = row0 + (threadIdx.x >> 4);
+        const bool live = row < rows;
+        if (!live) row = rows - 1;                       // keep all lanes in the DPP reductions
+        float* src = x + (size_t)row * stride;
+        f32x4 v[NV];
+        float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) v[i] = *(const f32x4*)(src + off(i));
+        for (int i = 0; i < NV; ++i) v[i] = *(const f32x4*)(src + off(i));
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        if (!add.d[a]) continue;
-        const TD* dsrc = (const TD*)add.d[a] + (size_t)row * add.ds[a];
-        const float* ls = add.ls[a];
+        for (int a = 0; a < 2; ++a) {
+            if (!add.d[a]) continue;
+            const TD* dsrc = (const TD*)add.d[a] + (size_t)row * add.ds[a];
+            const float* ls = sls[a];
 #pragma unroll
-        for (int i = 0; i < NV; i += (WIDE ? 2 : 1)) {
-            f32x4 d[2];
-            if constexpr (WIDE) load_vec8<TD>(dsrc + off(i), d[0], d[1]);
-            else d[0] = load_vec4<TD>(dsrc + off(i));
+            for (int i = 0; i < NV; i += (WIDE ? 2 : 1)) {
+                f32x4 d[2];
+                if constexpr (WIDE) load_vec8<TD>(dsrc + off(i), d[0], d[1]);
+                else d[0] = load_vec4<TD>(dsrc + off(i));
 #pragma unroll
-            for (int h = 0; h < (WIDE ? 2 : 1); ++h) {
-                if (ls) {
-                    const f32x4 sc = *(const f32x4*)(ls + off(i + h));
+                for (int h = 0; h < (WIDE ? 2 : 1); ++h) {
+                    if (ls) {
+                        const f32x4 sc = *(const f32x4*)(ls + off(i + h));
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) d[h][e] *= sc[e];
+                        for (int e = 0; e < 4; ++e) d[h][e] *= sc[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[i + h][e] += d[h][e];
                 }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[i + h][e] += d[h][e];
             }
         }
-    }
-    if (add.store && live && (add.d[0] || add.d[1])) {
+        if (add.store && live && (add.d[0] || add.d[1])) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) *(f32x4*)(src + off(i)) = v[i];
-    }
-#pragma unroll
-    for (int i = 0; i < NV; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-    const float mean = row16_sum(s) / (float)dim;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float d = v[i][e] - mean;
-            q += d * d;
+            for (int i = 0; i < NV; ++i) *(f32x4*)(src + off(i)) = v[i];
         }
-    const float rstd = 1.0f / sqrtf(row16_sum(q) / (float)dim + eps);
-    if (!live) return;
-    TO* dst = out + (size_t)row * dim;
 #pragma unroll
-    for (int i = 0; i < NV; i += (WIDE ? 2 : 1)) {
-        f32x4 y[2];
+        for (int i = 0; i < NV; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        const float mean = row16_sum(s) / (float)dim;
+        float q = 0.f;
 #pragma unroll
-        for (int h = 0; h < (WIDE ? 2 : 1); ++h) {
-            const f32x4 ga = *(const f32x4*)(gamma + off(i + h));
-            const f32x4 be = *(const f32x4*)(beta + off(i + h));
+        for (int i = 0; i < NV; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) y[h][e] = (v[i + h][e] - mean) * rstd * ga[e] + be[e];
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[i][e] - mean;
+                q += d * d;
+            }
+        const float rstd = 1.0f / sqrtf(row16_sum(q) / (float)dim + eps);
+        if (!live) continue;
+        TO* dst = out + (size_t)row * dim;
+#pragma unroll
+        for (int i = 0; i < NV; i += (WIDE ? 2 : 1)) {
+            f32x4 y[2];
+#pragma unroll
+            for (int h = 0; h < (WIDE ? 2 : 1); ++h) {
+                const f32x4 ga = *(const f32x4*)(sg + off(i + h));
+                const f32x4 be = *(const f32x4*)(sb + off(i + h));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[h][e] = (v[i + h][e] - mean) * rstd * ga[e] + be[e];
+            }
+            if constexpr (WIDE) store_vec8<TO>(dst + off(i), y[0], y[1]);
+            else store_vec4<TO>(dst + off(i), y[0]);
         }
-        if constexpr (WIDE) store_vec8<TO>(dst + off(i), y[0], y[1]);
-        else store_vec4<TO>(dst + off(i), y[0]);
     }
 }
 
@@ -234,11 +252,15 @@ int launch_ln_typed(float* x, long stride, const LnAdds& add, int rows, int dim,
                     const float* gamma, const float* beta, float eps, void* out, hipStream_t stream) {
     TO* o = (TO*)out;
     if (dim == 768 || dim == 1024) {      // same kernel for any row count: results never depend on the batch size
-        dim3 g16((rows + 15) / 16), b16(256);
+        // 16 rows per workgroup: more row groups per workgroup were measured slower (2: +4 %, 8: +13 % add+LN time) --
+        // the gain is the cooperative, coalesced parameter load, not its amortisation
+        const int groups = 1;
+        dim3 g16((rows + 16 * groups - 1) / (16 * groups)), b16(256);
+        const size_t lds = (size_t)4 * dim * sizeof(float);
         // WIDE measured against the 4-element layout inside bench.py: add+LayerNorm 5.38 -> 5.64 TB/s; nontemporal
         // loads / stores of the stream were also tried: slower (5.25 TB/s)
-        if (dim == 768) layernorm16_kernel<TD, TO, 12, true><<<g16, b16, 0, stream>>>(x, stride, add, rows, dim, gamma, beta, eps, o);
-        else layernorm16_kernel<TD, TO, 16, true><<<g16, b16, 0, stream>>>(x, stride, add, rows, dim, gamma, beta, eps, o);
+        if (dim == 768) layernorm16_kernel<TD, TO, 12, true><<<g16, b16, lds, stream>>>(x, stride, add, rows, dim, gamma, beta, eps, o, groups);
+        else layernorm16_kernel<TD, TO, 16, true><<<g16, b16, lds, stream>>>(x, stride, add, rows, dim, gamma, beta, eps, o, groups);
     } else {
         dim3 grid((rows + 3) / 4), block(256);
         layernorm_kernel<TD, TO><<<grid, block, 0, stream>>>(x, stride, add, rows, dim, gamma, beta, eps, o);

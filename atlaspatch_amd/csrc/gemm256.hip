@@ -241,11 +241,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
     f32x4 nbias[2][4];
     // The bias loads are inline asm with hand-placed waits.  A load hipcc tracks that is still pending at the
     // tile-loop header makes its waitcnt pass put static `s_waitcnt vmcnt(0..4)` in front of the first MFMAs of
-    // EVERY tile (the first-entry state is merged into the back edge), i.e. a drain of this workgroup's epilogue
-    // stores and of the DMA issued a moment earlier.  vmcnt retires in order, so "all but the N youngest" covers
-    // every older load.  (Timeline, tools/gemm_fine_trace.py: neutral within noise -- the first K-tile pair of a
-    // tile is dominated by wave 0 waiting at the first barrier for the waves that finish their epilogue later:
-    // the two waves of a SIMD share its VALU, 3.9 -> 4.0 us for the store epilogue, 6.4 us after the GELU one.)
+    // EVERY tile (the first-entry state is merged into the back edge).  The waits are FULL drains placed where only
+    // loads are outstanding: vmcnt retires loads in order among themselves, but a store may retire before an older
+    // load, so "all but the N youngest" proves nothing once stores are in the queue (a counted wait behind the
+    // epilogue's stores let a late bias load slip through about once in 10^5 tiles: one or two wrong images per
+    // few hundred forwards).  The next tile's bias is therefore requested just before the drain that opens the
+    // epilogue (the main loop's 64 fragment registers are free by then) and is complete when the drain returns.
     auto bias_ptr = [&](int ti, int hi_) {
         int tr, tc;
         tw.rc(tw.first + ti * tw.stride, tr, tc);
@@ -271,6 +272,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
     {
         const float* bp0 = bias_ptr(0, hi);
         AP_BIAS_LD8(bp0);
+        AP_BIAS_WAIT(0);
     }
 
     Frag fa[2][4], fb0[4], fb1[4];
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
     stage(ca, true, 0, U_X0); stage(ca, false, 0, U_Y0); advance(ca, 0);
     stage(cb, false, 0, U_Y1); stage(cb, true, 0, U_X1); advance(cb, 1);
     stage(ca, true, 1, U_X0); stage(ca, false, 1, U_Y0); advance(ca, 0);
-    AP_BIAS_WAIT(8);          // X0 / Y0 of K-tile 0 (and the older bias loads) have landed (phase 0 reads them)
+    AP_VMCNT(8);              // X0 / Y0 of K-tile 0 have landed (phase 0 reads them)
     __builtin_amdgcn_s_barrier();
     init_acc();
 #ifdef AP_G256_ALT
@@ -398,24 +400,23 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
         // ---------------- epilogue
         stamp_clk(ti, 6);
         stamp(ti, 1);
-        AP_VMCNT(0);          // the stream staged so far (next tile's first K-tiles) has landed
-        stamp(ti, 2);
         // lane-derived epilogue constants are recomputed per tile from an opaque copy of the lane id:
         // hoisted out of the tile loop they would live (spilled) across the whole K loop
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
         const int hi = lane_e >> 5, l31 = lane_e & 31;
+        {
+            // next tile's bias (its accumulators start from it), then ONE drain: the stream staged so far (next
+            // tile's first K-tiles) and the bias have landed; only loads are outstanding here
+            const float* nbp = bias_ptr(ti + 1 < tw.count ? ti + 1 : ti, hi);
+            AP_BIAS_LD8(nbp);
+            AP_BIAS_WAIT(0);
+        }
+        stamp(ti, 2);
         const int id = tw.first + ti * tw.stride;
         int tr, tc;
         tw.rc(id, tr, tc);
         const int m0 = tr * kBM + wr * 128, n0 = tc * kBN + wc * 64;
-        // Next tile's bias (its accumulators start from it) has to be in flight BEFORE this epilogue's stores
-        // (in-order vmcnt: a younger load could only be awaited together with every store).  The store / GELU
-        // epilogues issue the loads once the first accumulator block has been consumed (its 32 registers are free)
-        // and wait with a count that leaves the last four stores in flight.
-        const int nti = ti + 1 < tw.count ? ti + 1 : ti;
-        const float* nbp = bias_ptr(nti, hi);
-        if constexpr (EPI == EPI_BIAS_RESID) { AP_BIAS_LD8(nbp); }
         const bool has_gamma = EPI != EPI_BIAS_GELU && g.gamma != nullptr;
         const float* gp = g.gamma + n0 + hi * 4;
         if (g.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(ti, 3); }
@@ -470,7 +471,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
                         }
                         *(u32x2*)(scr + l31 * 128 + (((nb * 4 + g4) ^ (l31 & 7)) << 4) + hi * 8) = pack4<T>(v);
                     }
-                if (mb == 0) { AP_BIAS_LD8(nbp); }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int row = i * 8 + rrow;
@@ -480,8 +480,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
                 }
             }
         }
-        // a full store / GELU wave tile issued exactly 16 stores after the bias loads, four of them in the last block
-        if (EPI != EPI_BIAS_RESID && m0 + 128 <= g.M) AP_BIAS_WAIT(4); else AP_BIAS_WAIT(0);
         stamp(ti, 4);
         init_acc();
     }

@@ -61,6 +61,31 @@ def test_gemm_persistent_kernel_vs_torch(env, dt, epi, shape):
     assert torch.equal(outs[256], outs[128])
 
 
+@pytest.mark.parametrize("shape", [(2304, 768, "bias"), (768, 768, "bias"), (3072, 768, "gelu"), (768, 3072, "bias")])
+def test_gemm_tile_seam_with_cold_bias(env, shape):
+    """Regression screen for the tile seam of the persistent kernel: the next tile's bias is fetched while a tile ends.
+    The four ViT-B/16 GEMM shapes at the row count of a 348-tile slide (several tiles per workgroup, ragged last row
+    tile), many launches each with a DIFFERENT, cache-cold bias vector (vectors 1 MiB apart in a 256 MiB pool, so the
+    load misses L2 and comes back late); every result must equal the 128x128 kernel's bit for bit.  (A counted wait
+    behind the epilogue's stores once let a late bias load slip through: a store may retire before an older load;
+    seen as one or two wrong images in about one forward of ten.)"""
+    _lib, lib, dev, stream = env
+    dt = torch.float16
+    N, K, epi = shape
+    M = 348 * 197
+    g = torch.Generator(device=dev).manual_seed(9)
+    A = (torch.rand((M, K), device=dev, generator=g) * 2 - 1).to(dt)
+    W = ((torch.rand((N, K), device=dev, generator=g) * 2 - 1) * (2.0 / K ** 0.5)).to(dt)
+    pool = torch.rand((256, 262144), device=dev, generator=g) - 0.5          # row stride 1 MiB
+    out256 = torch.empty((M, N), device=dev, dtype=dt)
+    out128 = torch.empty((M, N), device=dev, dtype=dt)
+    for it in range(48):
+        bias = pool[(it * 37) % 256, :N]
+        _gemm(env, dt, epi, A, W, bias, None, out256, 256)
+        _gemm(env, dt, epi, A, W, bias, None, out128, 128)
+        assert torch.equal(out256, out128), f"launch {it}"
+
+
 def test_gemm_f32_exact_mfma(env):
     _lib, lib, dev, stream = env
     g = torch.Generator(device=dev).manual_seed(3)

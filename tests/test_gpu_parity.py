@@ -236,6 +236,34 @@ def test_synth_tiles_bit_exact():
         assert np.array_equal(got[i], render_region(spec, int(x), int(y), 256, 256, 0)), i
 
 
+# ----------------------------------------------------------------------------- whole-forward race screen
+@pytest.mark.parametrize("name,n,iters", [("vit_b_16", 348, 160), ("uni_v1", 96, 40), ("conch_v1", 24, 40)])
+def test_forward_is_repeatable(name, n, iters):
+    """The same batch through the full-depth encoder many times: every output equals the first bit for bit.  This is
+    the screen that exposed a seam race in the persistent GEMM (a late bias load behind the epilogue's stores: one or
+    two wrong images in 4.6 % of the forwards at exactly this size, 348 tiles = 68 556 token rows, ragged last tile)."""
+    import os
+    from atlaspatch_amd.encoders import build_default_registry
+    os.environ["ATLASPATCH_RANDOM_INIT"] = "2"
+    try:
+        ex = build_default_registry(device="cuda", dtype=torch.float16).create(name)
+    finally:
+        os.environ.pop("ATLASPATCH_RANDOM_INIT", None)
+    tiles = torch.from_numpy(np.random.default_rng(0).integers(0, 256, (n, 256, 256, 3), dtype=np.uint8)).to(_dev())
+    ref = torch.empty((n, ex.embedding_dim), dtype=torch.float32, device=_dev())
+    out = torch.empty_like(ref)
+    ex.forward_device(tiles, ref)
+    torch.cuda.synchronize()
+    bad = []
+    for it in range(iters):
+        ex.forward_device(tiles, out)
+        torch.cuda.synchronize()
+        if not torch.equal(out, ref):
+            bad.append((it, torch.nonzero((out != ref).any(dim=1)).flatten().tolist()[:6]))
+    ex.cleanup()
+    assert not bad, f"{len(bad)} of {iters} forwards differ from the first: {bad[:5]}"
+
+
 # ----------------------------------------------------------------------------- CLS-only tail of the last block
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.float16, 1e-3), (torch.bfloat16, 8e-3)])
 @pytest.mark.parametrize("arch_name", ["vit_b_16", "uni_v1"])

@@ -264,6 +264,36 @@ def test_forward_is_repeatable(name, n, iters):
     assert not bad, f"{len(bad)} of {iters} forwards differ from the first: {bad[:5]}"
 
 
+@pytest.mark.parametrize("arch_name,n", [("vit_b_16", 300), ("uni_v1", 270), ("conch_v1", 12)])
+def test_features_do_not_depend_on_batch_cut(arch_name, n):
+    """The same tiles cut into device batches of 1 / 7 / 255 / 257 tiles or sent as one batch: bit-identical features
+    (the 128x128 and 256x256 GEMM kernels agree bitwise, every other kernel works per image or per row).  The reference
+    chunks by --feature-batch-size (base.py:83); a drop-in must not make results depend on that knob."""
+    from atlaspatch_amd.encoders.vit import (ARCHS, OPENAI_CLIP_MEAN, OPENAI_CLIP_STD, attn_pool_canonical,
+                                             build_hip_vit_extractor, random_attn_pool, random_canonical_state_dict)
+    arch = dict(ARCHS[arch_name]); arch["depth"] = 2
+    if arch_name == "conch_v1":
+        trunk_arch = {k: v for k, v in arch.items() if not k.startswith("pool")}
+        state = dict(random_canonical_state_dict(trunk_arch, seed=6)); state.update(attn_pool_canonical(random_attn_pool(arch, seed=6)))
+        ex = build_hip_vit_extractor(name="t", arch=arch, state_dict=state, source="canonical", device=_dev(),
+                                     dtype=torch.float16, mean=OPENAI_CLIP_MEAN, std=OPENAI_CLIP_STD,
+                                     resize=(448, "bicubic"), expect_size=None)
+    else:
+        ex = build_hip_vit_extractor(name="t", arch=arch, state_dict=random_canonical_state_dict(arch, seed=6),
+                                     source="canonical", device=_dev(), dtype=torch.float16, expect_size=256)
+    tiles = torch.from_numpy(np.random.default_rng(2).integers(0, 256, (n, 256, 256, 3), dtype=np.uint8)).to(_dev())
+    ref = torch.empty((n, ex.embedding_dim), dtype=torch.float32, device=_dev())
+    ex.forward_device(tiles, ref)
+    for chunk in (1, 7, 255, 257):
+        if chunk >= n and chunk != 257:
+            continue
+        out = torch.empty_like(ref)
+        for lo in range(0, n, chunk):
+            ex.forward_device(tiles[lo:lo + chunk], out[lo:lo + chunk])
+        assert torch.equal(out, ref), chunk
+    ex.cleanup()
+
+
 # ----------------------------------------------------------------------------- CLS-only tail of the last block
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.float16, 1e-3), (torch.bfloat16, 8e-3)])
 @pytest.mark.parametrize("arch_name", ["vit_b_16", "uni_v1"])

@@ -294,6 +294,33 @@ def test_features_do_not_depend_on_batch_cut(arch_name, n):
     ex.cleanup()
 
 
+def test_full_size_batch_properties():
+    """BASELINE's device batch (2048 tiles, full-depth ViT-B/16, f16): size-independent properties instead of an oracle
+    run -- (1) the batch equals its four 512-tile quarters forwarded separately, (2) permuting the tiles permutes the
+    features, both bit for bit (every image is independent of its batch neighbours), (3) no NaN / Inf."""
+    import os
+    from atlaspatch_amd.encoders import build_default_registry
+    os.environ["ATLASPATCH_RANDOM_INIT"] = "0"
+    try:
+        ex = build_default_registry(device="cuda", dtype=torch.float16).create("vit_b_16")
+    finally:
+        os.environ.pop("ATLASPATCH_RANDOM_INIT", None)
+    n = 2048
+    g = torch.Generator(device=_dev()).manual_seed(4)
+    tiles = torch.randint(0, 256, (n, 256, 256, 3), device=_dev(), dtype=torch.uint8, generator=g)
+    ref = torch.empty((n, ex.embedding_dim), dtype=torch.float32, device=_dev())
+    ex.forward_device(tiles, ref)
+    assert torch.isfinite(ref).all()
+    out = torch.empty_like(ref)
+    for lo in range(0, n, 512):
+        ex.forward_device(tiles[lo:lo + 512], out[lo:lo + 512])
+    assert torch.equal(out, ref)
+    perm = torch.randperm(n, device=_dev(), generator=g)
+    ex.forward_device(tiles[perm].contiguous(), out)
+    assert torch.equal(out, ref[perm])
+    ex.cleanup()
+
+
 # ----------------------------------------------------------------------------- CLS-only tail of the last block
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.float16, 1e-3), (torch.bfloat16, 8e-3)])
 @pytest.mark.parametrize("arch_name", ["vit_b_16", "uni_v1"])

@@ -40,6 +40,9 @@ struct ap_vit {
     std::vector<hipEvent_t> ev_pool;
     std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> ev_used;
     size_t ev_next = 0;
+    // experimental two-half overlap (AP_VIT_OVERLAP=1): second stream + hand-off events
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 namespace {
@@ -367,6 +370,9 @@ void ap_vit_destroy(ap_vit* m) {
     for (auto& kv : m->params)
         if (kv.second.dev) (void)hipFree(kv.second.dev);
     for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
+    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+    if (m->ev_join) (void)hipEventDestroy(m->ev_join);
+    if (m->side) (void)hipStreamDestroy(m->side);
     delete m;
 }
 
@@ -406,7 +412,10 @@ int ap_vit_finalize(ap_vit* m) {
 
 size_t ap_vit_workspace_bytes(const ap_vit* m, int n) {
     if (!m || n <= 0) return 0;
-    return carve(m, n, nullptr).total;
+    const size_t whole = carve(m, n, nullptr).total;
+    const int na = (n + 1) / 2;                       // the two-half mode carves two independent workspaces
+    const size_t halves = carve(m, na, nullptr).total + (n - na > 0 ? carve(m, n - na, nullptr).total : 0);
+    return whole > halves ? whole : halves;
 }
 
 int ap_vit_embed_dim(const ap_vit* m) { return !m ? 0 : (m->cfg.pool == AP_POOL_ATTN ? m->cfg.pool_dim : m->cfg.dim); }
@@ -444,15 +453,39 @@ int ap_vit_forward_u8(ap_vit* m, const uint8_t* patches, int n, int h, int w, co
                "(resampling preprocess not in this build)", h, w, S);
     // torchvision CenterCrop: top = int(round((h - S) / 2.0)) (banker's rounding)
     auto crop_off = [](int full, int size) { int d = full - size; return (d / 2) + ((d & 1) && ((d / 2) & 1) ? 1 : 0); };
-    const Workspace ws = carve(m, n, (char*)workspace);
     hipStream_t s = (hipStream_t)stream;
-    if (m->kpe != 3 * m->cfg.patch_size * m->cfg.patch_size)
-        AP_HIP_CHECK(hipMemsetAsync(ws.hid, 0, (size_t)n * m->patches * m->kpe * ap::dtype_size(m->cfg.compute_dtype), s));
-    { ScopedTimer t(m, AP_PROF_PREPROC, s);
-      rc = ap::preproc_patchrows(patches, n, h, w, crop_off(h, S), crop_off(w, S), S, S, m->cfg.patch_size,
-                                 mean, stdv, ws.hid, m->kpe, m->cfg.compute_dtype, s); }
-    if (rc != AP_OK) return rc;
-    return run_blocks(m, n, ws, out, s);
+    auto forward_part = [&](const uint8_t* tiles, int cnt, float* dst, char* base, hipStream_t st) -> int {
+        const Workspace ws = carve(m, cnt, base);
+        if (m->kpe != 3 * m->cfg.patch_size * m->cfg.patch_size)
+            AP_HIP_CHECK(hipMemsetAsync(ws.hid, 0, (size_t)cnt * m->patches * m->kpe * ap::dtype_size(m->cfg.compute_dtype), st));
+        int r;
+        { ScopedTimer t(m, AP_PROF_PREPROC, st);
+          r = ap::preproc_patchrows(tiles, cnt, h, w, crop_off(h, S), crop_off(w, S), S, S, m->cfg.patch_size,
+                                    mean, stdv, ws.hid, m->kpe, m->cfg.compute_dtype, st); }
+        if (r != AP_OK) return r;
+        return run_blocks(m, cnt, ws, dst, st);
+    };
+    // Experimental (AP_VIT_OVERLAP=1): the batch as two independent halves on two streams, so that the HBM-bound
+    // add+LayerNorm launches of one half can run beside the VALU-bound attention of the other.  Same features (every
+    // image is independent of its batch neighbours, tested bit for bit).
+    const bool overlap = getenv("AP_VIT_OVERLAP") != nullptr && n >= 512;
+    if (!overlap) return forward_part(patches, n, out, (char*)workspace, s);
+    if (!m->side) {
+        AP_HIP_CHECK(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+        AP_HIP_CHECK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+        AP_HIP_CHECK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+    }
+    const int na = (n + 1) / 2, nb = n - na;
+    const size_t bytes_a = carve(m, na, nullptr).total;
+    const int D = ap_vit_embed_dim(m);
+    AP_HIP_CHECK(hipEventRecord(m->ev_fork, s));
+    AP_HIP_CHECK(hipStreamWaitEvent(m->side, m->ev_fork, 0));
+    if ((rc = forward_part(patches, na, out, (char*)workspace, s)) != AP_OK) return rc;
+    if ((rc = forward_part(patches + (size_t)na * h * w * 3, nb, out + (size_t)na * D, (char*)workspace + bytes_a, m->side)) != AP_OK)
+        return rc;
+    AP_HIP_CHECK(hipEventRecord(m->ev_join, m->side));
+    AP_HIP_CHECK(hipStreamWaitEvent(s, m->ev_join, 0));
+    return AP_OK;
 }
 
 int ap_vit_forward_chw(ap_vit* m, const void* x, int x_dtype, int n, float* out, void* workspace,

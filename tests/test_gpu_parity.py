@@ -321,6 +321,30 @@ def test_full_size_batch_properties():
     ex.cleanup()
 
 
+def test_two_half_overlap_mode_is_bit_identical():
+    """AP_VIT_OVERLAP=1 (opt-in): the batch runs as two halves on two streams; features are the same bits."""
+    import os
+    from atlaspatch_amd.encoders.vit import ARCHS, build_hip_vit_extractor, random_canonical_state_dict
+    arch = dict(ARCHS["vit_b_16"]); arch["depth"] = 3
+    ex = build_hip_vit_extractor(name="t", arch=arch, state_dict=random_canonical_state_dict(arch, seed=8),
+                                 source="canonical", device=_dev(), dtype=torch.float16, expect_size=256)
+    n = 700
+    tiles = torch.from_numpy(np.random.default_rng(3).integers(0, 256, (n, 256, 256, 3), dtype=np.uint8)).to(_dev())
+    ref = torch.empty((n, ex.embedding_dim), dtype=torch.float32, device=_dev())
+    out = torch.empty_like(ref)
+    ex.forward_device(tiles, ref)
+    os.environ["AP_VIT_OVERLAP"] = "1"
+    try:
+        for _ in range(5):
+            out.zero_()
+            ex.forward_device(tiles, out)
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref)
+    finally:
+        os.environ.pop("AP_VIT_OVERLAP", None)
+    ex.cleanup()
+
+
 # ----------------------------------------------------------------------------- CLS-only tail of the last block
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.float16, 1e-3), (torch.bfloat16, 8e-3)])
 @pytest.mark.parametrize("arch_name", ["vit_b_16", "uni_v1"])

@@ -222,7 +222,7 @@ void attention_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int 
             if (kb == 1 && !full) break;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(st[kb][r] * c - mb);
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][r], c, -mb));    // one VALU op (the build uses -ffp-contract=off)
                 st[kb][r] = p;
                 psum += p;
             }

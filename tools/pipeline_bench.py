@@ -17,7 +17,7 @@ dev = torch.device("cuda:0")
 arch = sys.argv[1] if len(sys.argv) > 1 else "vit_b_16"
 side = int(sys.argv[2]) if len(sys.argv) > 2 else 40000
 ex = build_default_registry(device=dev, dtype=torch.float16).create(arch)
-B = min(1024, ex.max_batch)
+B = min(2048, ex.max_batch)
 rng = np.random.default_rng(0)
 N = 8 * B
 host = rng.integers(0, 256, (N, 256, 256, 3), dtype=np.uint8)

@@ -22,9 +22,12 @@
 //    staged between them: 2 x global_load_lds_dwordx4 per lane].  vmcnt(6) = "everything staged four
 //    phases ago has landed"; data is read no earlier than one phase after the wait that retires it
 //    and a unit is restaged no earlier than one barrier after its reading phase (raw s_barrier,
-//    never vmcnt(0) in the loop).  vmcnt retires in order and also counts the epilogue's global
-//    stores, so the first K-tile after an epilogue skips the counted wait (the epilogue drained
-//    the stream) and the stores drain under the next tile's MFMAs.
+//    never vmcnt(0) in the loop).  Loads retire in issue order among themselves, which is all the counted
+//    wait relies on; vmcnt also counts the epilogue's global stores, and a store may retire before OR after a
+//    load issued around it: older stores still in the queue only make vmcnt(6) stricter (safe), but nothing may
+//    be concluded about a load from a count once YOUNGER stores are outstanding -- there the wait is a full
+//    drain.  The epilogue opens with such a drain, so the first K-tile after it skips the counted wait and the
+//    epilogue's stores drain under the next tile's MFMAs.
 //  * the LDS-DMA is issued from inline asm (SGPR base + 32-bit lane offset, M0 = LDS address): the
 //    compiler treats the builtin as a FLAT access and then turns every later LDS / VMEM wait into a
 //    full drain; hidden from it, the fragment reads get counted lgkmcnt(N) waits, so the first

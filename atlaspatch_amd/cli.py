@@ -13,6 +13,7 @@ for real slides.  When launched under ``torch.distributed.run`` slides are shard
 from __future__ import annotations
 
 import logging
+import os
 import sys
 from pathlib import Path
 
@@ -142,6 +143,14 @@ def _run_pipeline(*, wsi_path, output, patch_size, step_size, target_mag, device
             failures.extend(service.embed_all(results, wsi_loader=loader, progress=bar))
         finally:
             bar.close()
+        if world > 1 and os.environ.get("ATLASPATCH_GATHER_FEATURES"):
+            # MI355X addition (north star): one RCCL all-gather-v reassembles the rank-sharded feature matrices
+            from .orchestration.dispatch import gather_run_features, init_process_group
+            dev = torch.device("cuda", local_rank) if torch.cuda.is_available() else None
+            init_process_group(device=dev)
+            failed = {str(s.path) for s, _ in failures}
+            mine = [r.h5_path for r in results if str(r.slide.path) not in failed]
+            gather_run_features(mine, [e.lower() for e in app_cfg.features.extractors], app_cfg.output.output_root, device=dev)
     return results, failures
 
 

@@ -72,3 +72,50 @@ def gather_feature_matrix(local: torch.Tensor, group=None) -> list[torch.Tensor]
         dist.all_gather(parts, padded, group=group)
         out = torch.cat(parts, dim=0)
     return [out[r * width: r * width + rows[r]] for r in range(world)]
+
+
+def gather_run_features(h5_paths: Sequence, extractor_names: Sequence[str], out_root, *, device=None) -> dict:
+    """Reassemble the feature matrices of a rank-sharded run on every rank (the one exchange step of the north star).
+
+    ``h5_paths``: this rank's ``<stem>.h5`` outputs, in processing order.  Per extractor: the rank's ``[sum N_i, D]``
+    block (its slides concatenated) goes through ONE all-gather-v (``gather_feature_matrix``); rank 0 writes
+    ``<out_root>/features_all/<extractor>.npy`` ([total, D] float32, ranks in order, slides in each rank's order) and
+    ``<extractor>.index.json`` (slide stem, rank, first row, rows).  Returns ``{extractor: [total, D] tensor}`` on every
+    rank.  A reference run has no such file: this is the MI355X multi-GPU addition, enabled by
+    ``ATLASPATCH_GATHER_FEATURES=1`` under ``torch.distributed.run``."""
+    import json
+    from pathlib import Path
+    import numpy as np
+    import torch.distributed as dist
+    from ..utils.h5 import h5
+    rank, world, _ = env_rank_world()
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    merged: dict = {}
+    for name in extractor_names:
+        blocks, index = [], []
+        for path in h5_paths:
+            with h5.File(str(path), "r") as fh:
+                feats = np.asarray(fh["features"][name][:], dtype=np.float32)
+            index.append({"slide": Path(str(path)).stem, "rank": rank, "rows": int(feats.shape[0])})
+            blocks.append(torch.from_numpy(feats))
+        dim = blocks[0].shape[1] if blocks else 0
+        local = (torch.cat(blocks, 0) if blocks else torch.zeros((0, dim), dtype=torch.float32)).to(dev)
+        parts = gather_feature_matrix(local)
+        width = max((p.shape[1] for p in parts if p.dim() == 2 and p.shape[0]), default=dim)
+        whole = torch.cat([p if p.shape[0] else p.reshape(0, width) for p in parts], 0) if parts else local
+        merged[name] = whole
+        all_index = [index]
+        if dist.is_available() and dist.is_initialized() and world > 1:
+            all_index = [None] * world
+            dist.all_gather_object(all_index, index)
+        if rank == 0:
+            out_dir = Path(out_root) / "features_all"
+            out_dir.mkdir(parents=True, exist_ok=True)
+            np.save(out_dir / f"{name}.npy", whole.cpu().numpy())
+            rows, first = [], 0
+            for per_rank in all_index:
+                for item in per_rank:
+                    rows.append({**item, "first_row": first})
+                    first += item["rows"]
+            (out_dir / f"{name}.index.json").write_text(json.dumps(rows, indent=1))
+    return merged

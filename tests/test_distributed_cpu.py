@@ -63,3 +63,43 @@ def test_runner_shards_slides_one_per_rank(tmp_path):
         seen.append([s.path.name for s in runner.discover_slides()])
     assert seen[0] == ["slide0.synth", "slide2.synth", "slide4.synth"]
     assert seen[1] == ["slide1.synth", "slide3.synth"]
+
+
+def _gather_worker(rank, world, port, tmp):
+    import json
+    import torch.distributed as dist
+    from atlaspatch_amd.orchestration.dispatch import gather_run_features
+    from atlaspatch_amd.utils.h5 import h5
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # rank 0 owns slides a (3 rows) and c (2 rows), rank 1 owns b (4 rows): features = slide id + row / 10
+        mine = {0: [("a", 3, 1.0), ("c", 2, 3.0)], 1: [("b", 4, 2.0)]}[rank]
+        paths = []
+        for stem, rows, base in mine:
+            p = os.path.join(tmp, f"{stem}.h5")
+            with h5.File(p, "w") as fh:
+                grp = fh.create_group("features")
+                grp.create_dataset("enc", data=(base + np.arange(rows)[:, None] / 10 + np.zeros((rows, 5))).astype(np.float32))
+            paths.append(p)
+        merged = gather_run_features(paths, ["enc"], os.path.join(tmp, "out"))
+        assert merged["enc"].shape == (9, 5)
+        assert torch.allclose(merged["enc"][:, 0], torch.tensor([1.0, 1.1, 1.2, 3.0, 3.1, 2.0, 2.1, 2.2, 2.3]))
+        dist.barrier()
+        if rank == 0:
+            whole = np.load(os.path.join(tmp, "out", "features_all", "enc.npy"))
+            index = json.load(open(os.path.join(tmp, "out", "features_all", "enc.index.json")))
+            assert whole.shape == (9, 5) and whole.dtype == np.float32
+            assert [(r["slide"], r["rank"], r["first_row"], r["rows"]) for r in index] == \
+                [("a", 0, 0, 3), ("c", 0, 3, 2), ("b", 1, 5, 4)]
+        np.save(os.path.join(tmp, f"gok{rank}.npy"), np.array([1]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_run_features_world2(tmp_path):
+    """The run-level reassembly (ATLASPATCH_GATHER_FEATURES): per-rank H5 feature sets -> one [total, D] matrix + index."""
+    port = _free_port()
+    mp.spawn(_gather_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "gok0.npy").exists() and (tmp_path / "gok1.npy").exists()

@@ -85,35 +85,48 @@ class TileRing:
             return [self.pool.submit(some, s) for s in range(0, count, chunk)], count
 
         pending = {}
-        for b in range(min(nb, self.slots)):         # prime the ring
-            if self.free_events[b % self.slots] is not None:
-                self.free_events[b % self.slots].synchronize()
-                self.free_events[b % self.slots] = None
-            pending[b] = fill(b % self.slots, b)
-        for b in range(nb):
-            slot = b % self.slots
-            tasks, count = pending.pop(b)
-            for t in tasks:
-                t.result()
-            with torch.cuda.stream(self.copy_stream):
-                if self.free_events[slot] is not None:           # device slot: the forward that read it is done
-                    self.copy_stream.wait_event(self.free_events[slot])
-                self.dev[slot][:count].copy_(self.host[slot][:count], non_blocking=True)
-                copied = torch.cuda.Event()
-                copied.record(self.copy_stream)
-            compute.wait_event(copied)
-            forward(self.dev[slot][:count], out_dev[slot][:count])
-            lo = b * self.batch
-            out_host[lo:lo + count].copy_(out_dev[slot][:count], non_blocking=True)
-            done = torch.cuda.Event()
-            done.record(compute)
-            self.free_events[slot] = done
-            nxt = b + self.slots
-            if nxt < nb:
-                # the pinned host slot may be refilled as soon as its H2D copy has completed; the device slot is
-                # protected by the copy stream waiting on `done` above, so the CPU never waits for a forward
-                copied.synchronize()
-                pending[nxt] = fill(slot, nxt)
+        try:
+            for b in range(min(nb, self.slots)):         # prime the ring
+                if self.free_events[b % self.slots] is not None:
+                    self.free_events[b % self.slots].synchronize()
+                    self.free_events[b % self.slots] = None
+                pending[b] = fill(b % self.slots, b)
+            for b in range(nb):
+                slot = b % self.slots
+                tasks, count = pending[b]
+                for t in tasks:
+                    t.result()
+                del pending[b]
+                with torch.cuda.stream(self.copy_stream):
+                    if self.free_events[slot] is not None:           # device slot: the forward that read it is done
+                        self.copy_stream.wait_event(self.free_events[slot])
+                    self.dev[slot][:count].copy_(self.host[slot][:count], non_blocking=True)
+                    copied = torch.cuda.Event()
+                    copied.record(self.copy_stream)
+                compute.wait_event(copied)
+                forward(self.dev[slot][:count], out_dev[slot][:count])
+                lo = b * self.batch
+                out_host[lo:lo + count].copy_(out_dev[slot][:count], non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(compute)
+                self.free_events[slot] = done
+                nxt = b + self.slots
+                if nxt < nb:
+                    # the pinned host slot may be refilled as soon as its H2D copy has completed; the device slot is
+                    # protected by the copy stream waiting on `done` above, so the CPU never waits for a forward
+                    copied.synchronize()
+                    pending[nxt] = fill(slot, nxt)
+        except BaseException:
+            # a tile source failed (or the forward did): let the decode tasks that are still filling pinned slots
+            # finish before the ring is reused for the next slide, then drain the device
+            for tasks, _ in pending.values():
+                for t in tasks:
+                    try:
+                        t.result()
+                    except Exception:  # noqa: BLE001
+                        pass
+            torch.cuda.synchronize(self.device)
+            raise
         torch.cuda.synchronize(self.device)
         return out_host.numpy()
 

@@ -98,6 +98,36 @@ def test_tile_ring_matches_direct_forward():
     ex.cleanup()
 
 
+def test_tile_ring_survives_a_failing_tile_source():
+    """A tile source that raises makes ``run`` raise (the slide is recorded as failed by the caller) after every decode
+    task still filling pinned slots has finished; the same ring then serves the next slide correctly."""
+    import os
+    from atlaspatch_amd.encoders.vit import ARCHS, build_hip_vit_extractor, random_canonical_state_dict
+    from atlaspatch_amd.services.tile_ring import TileRing
+    arch = dict(ARCHS["vit_b_16"]); arch["depth"] = 1
+    ex = build_hip_vit_extractor(name="t", arch=arch, state_dict=random_canonical_state_dict(arch, seed=1),
+                                 source="canonical", device=torch.device("cuda:0"), dtype=torch.float16, expect_size=256)
+    n = 300
+    host = np.random.default_rng(0).integers(0, 256, (n, 256, 256, 3), dtype=np.uint8)
+    coords = np.stack([np.arange(n), np.zeros(n), np.full(n, 256), np.full(n, 256), np.zeros(n)], 1).astype(np.int32)
+    ring = TileRing(device=ex.device, batch=64, patch_size=256, slots=3, workers=4)
+
+    def bad(x, y, rw, rh, lv):
+        if x == 150:
+            raise OSError("decode failed")
+        return host[x]
+
+    fwd = lambda t, o: ex.forward_device(t, o)
+    with pytest.raises(OSError):
+        ring.run(coords, bad, fwd, ex.embedding_dim)
+    got = ring.run(coords, lambda x, y, rw, rh, lv: host[x], fwd, ex.embedding_dim)
+    want = torch.empty((n, ex.embedding_dim), dtype=torch.float32, device=ex.device)
+    ex.forward_device(torch.from_numpy(host).to(ex.device), want)
+    assert np.array_equal(got, want.cpu().numpy())
+    ring.close()
+    ex.cleanup()
+
+
 def test_cli_process_conch_and_uni_fp16(tmp_path, monkeypatch):
     """BASELINE configs 3 / 5 in miniature: `process` with uni_v1 (ViT-L/16 + LayerScale, host bicubic 224) and
     conch_v1 (448-px trunk + attentional pooler) in float16 on one small synthetic slide -> both feature sets in

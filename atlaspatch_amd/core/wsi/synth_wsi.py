@@ -6,10 +6,16 @@ A ``.synth`` file is a small JSON object ``{"width", "height", "seed", "n_ellips
 store and any tile can be produced on the host (this class) or directly in HBM
 (csrc/synth.hip, bit-identical).  Registered with ``WSIFactory`` under backend
 name ``synth``, the same seam the reference offers (wsi_factory.py:41-53).
+
+Optional key ``"jpeg_tiles": "<directory>"``: level-0 tiles found there as ``<x>_<y>_<size>.jpg`` are DECODED with
+Pillow instead of rendered -- a stand-in for a real slide's compressed tiles (SURVEY 8d "optional JPEG-tile store"),
+so the tile ring can be measured against a realistic host decoder (libjpeg releases the interpreter lock); such a
+slide never serves tiles from the device.  ``tools/jpeg_slide_bench.py`` builds a store.
 """
 from __future__ import annotations
 
 import json
+import os
 from typing import Literal, Optional, Tuple, Union
 
 import numpy as np
@@ -40,10 +46,15 @@ class SynthWSI(IWSI):
     def __init__(self, path: str, mpp: Optional[float] = None, **_: object) -> None:
         super().__init__(path=path, mpp=mpp)
         self.spec: Optional[SynthSpec] = None
+        self.jpeg_dir: Optional[str] = None
 
     def _setup(self) -> None:
         spec = load_spec(self.path)
         self.spec = spec
+        with open(self.path, "r", encoding="utf-8") as handle:
+            jd = json.load(handle).get("jpeg_tiles")
+        if jd:
+            self.jpeg_dir = jd if os.path.isabs(jd) else os.path.join(os.path.dirname(os.path.abspath(self.path)), jd)
         self.w, self.h = spec.width, spec.height
         self.ds = [float(d) for d in spec.downsamples]
         self.nlvl = len(self.ds)
@@ -65,7 +76,14 @@ class SynthWSI(IWSI):
         self._ensure_loaded()
         if not 0 <= lv < (self.nlvl or 0):
             raise ValueError(f"Invalid level {lv}")
-        region = render_region(self.spec, int(xy[0]), int(xy[1]), int(wh[0]), int(wh[1]), int(lv))
+        region = None
+        if self.jpeg_dir is not None and lv == 0 and wh[0] == wh[1]:
+            tile = os.path.join(self.jpeg_dir, f"{int(xy[0])}_{int(xy[1])}_{int(wh[0])}.jpg")
+            if os.path.exists(tile):
+                with Image.open(tile) as img:
+                    region = np.asarray(img.convert("RGB"))
+        if region is None:
+            region = render_region(self.spec, int(xy[0]), int(xy[1]), int(wh[0]), int(wh[1]), int(lv))
         if mode == "array":
             return region
         if mode == "image":
@@ -80,6 +98,8 @@ class SynthWSI(IWSI):
         import torch
         from ... import _lib
         self._ensure_loaded()
+        if self.jpeg_dir is not None:
+            return None                      # compressed tiles are decoded on the host and cross the ring
         rows = np.asarray(rows)
         if rows.size == 0:
             return torch.empty((0, patch_size, patch_size, 3), dtype=torch.uint8, device=device)

@@ -324,3 +324,24 @@ def test_host_gather_tiles_copies_in_order():
     assert lib.ap_host_gather_tiles(dst.ctypes.data, ptrs, 5, 8 * 8 * 3) == 0
     assert all(np.array_equal(dst[i], tiles[i]) for i in range(5))
     assert lib.ap_host_gather_tiles(dst.ctypes.data, ptrs, 0, 8 * 8 * 3) == 0
+
+
+def test_synth_slide_with_jpeg_tile_store(tmp_path):
+    """``"jpeg_tiles"`` in a .synth descriptor: level-0 tiles present in the store are decoded with Pillow (others are
+    rendered), and such a slide never offers a device tile source (its tiles cross the ring)."""
+    import json
+    from PIL import Image
+    from atlaspatch_amd.core.wsi.synth_pixels import SynthSpec, render_region
+    from atlaspatch_amd.core.wsi.wsi_factory import WSIFactory
+    store = tmp_path / "tiles"
+    store.mkdir()
+    spec = SynthSpec(width=4096, height=4096, seed=3)
+    marked = np.full((256, 256, 3), 77, np.uint8)
+    Image.fromarray(marked).save(store / "512_768_256.jpg", quality=95)
+    path = tmp_path / "s.synth"
+    path.write_text(json.dumps({"width": 4096, "height": 4096, "seed": 3, "jpeg_tiles": "tiles"}))
+    wsi = WSIFactory.load(str(path))
+    got = wsi.extract((512, 768), 0, (256, 256))
+    assert got.shape == (256, 256, 3) and abs(int(got.mean()) - 77) <= 1            # decoded, not rendered
+    assert np.array_equal(wsi.extract((0, 0), 0, (256, 256)), render_region(spec, 0, 0, 256, 256, 0))   # not in the store
+    assert wsi.extract_batch_device(np.array([[0, 0, 256, 256, 0]]), "cpu", 256) is None

@@ -42,6 +42,7 @@ SIGNATURES = {
     "ap_preproc_u8hwc_to_patchrows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                                 C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
                                                 C.POINTER(C.c_float), C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "ap_host_inflate_tiles": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.c_int, C.c_size_t]),
     "ap_host_gather_tiles": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_size_t]),
     "ap_resample_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

@@ -8,7 +8,7 @@ store and any tile can be produced on the host (this class) or directly in HBM
 name ``synth``, the same seam the reference offers (wsi_factory.py:41-53).
 
 Optional key ``"jpeg_tiles": "<directory>"``: level-0 tiles found there as ``<x>_<y>_<size>.jpg`` are DECODED with
-Pillow instead of rendered -- a stand-in for a real slide's compressed tiles (SURVEY 8d "optional JPEG-tile store"),
+Pillow (or, as ``<x>_<y>_<size>.z``, inflated with zlib: raw RGB) instead of rendered -- a stand-in for a real slide's compressed tiles (SURVEY 8d "optional JPEG-tile store"),
 so the tile ring can be measured against a realistic host decoder (libjpeg releases the interpreter lock); such a
 slide never serves tiles from the device.  ``tools/jpeg_slide_bench.py`` builds a store.
 """
@@ -78,9 +78,13 @@ class SynthWSI(IWSI):
             raise ValueError(f"Invalid level {lv}")
         region = None
         if self.jpeg_dir is not None and lv == 0 and wh[0] == wh[1]:
-            tile = os.path.join(self.jpeg_dir, f"{int(xy[0])}_{int(xy[1])}_{int(wh[0])}.jpg")
-            if os.path.exists(tile):
-                with Image.open(tile) as img:
+            stem = os.path.join(self.jpeg_dir, f"{int(xy[0])}_{int(xy[1])}_{int(wh[0])}")
+            if os.path.exists(stem + ".z"):          # raw RGB, deflate: zlib.decompress runs without the interpreter lock
+                import zlib
+                with open(stem + ".z", "rb") as fh:
+                    region = np.frombuffer(zlib.decompress(fh.read()), dtype=np.uint8).reshape(int(wh[1]), int(wh[0]), 3)
+            elif os.path.exists(stem + ".jpg"):
+                with Image.open(stem + ".jpg") as img:
                     region = np.asarray(img.convert("RGB"))
         if region is None:
             region = render_region(self.spec, int(xy[0]), int(xy[1]), int(wh[0]), int(wh[1]), int(lv))
@@ -119,6 +123,26 @@ class SynthWSI(IWSI):
                                           cache.shape[0], tiles.data_ptr(), _lib.current_stream_ptr(device)),
                        "ap_synth_tiles")
         return tiles
+
+    def read_tiles_into(self, rows, dst_ptr: int, patch_size: int) -> bool:
+        """Optional IWSI capability (native batched host decode): decode the tiles of ``rows`` (x, y, rw, rh, lv) into
+        consecutive ``patch_size^2 * 3``-byte slots at ``dst_ptr`` in ONE call outside the interpreter lock, or return
+        False when this backend cannot (the caller then reads tile by tile).  Here: the deflate tile store."""
+        import ctypes as C
+        from ... import _lib
+        self._ensure_loaded()
+        if self.jpeg_dir is None:
+            return False
+        paths = []
+        for x, y, rw, rh, lv in rows:
+            p = os.path.join(self.jpeg_dir, f"{int(x)}_{int(y)}_{int(rw)}.z")
+            if lv != 0 or rw != patch_size or rh != patch_size or not os.path.exists(p):
+                return False
+            paths.append(p.encode())
+        arr = (C.c_char_p * len(paths))(*paths)
+        _lib.check(_lib.load().ap_host_inflate_tiles(dst_ptr, arr, len(paths), patch_size * patch_size * 3),
+                   "ap_host_inflate_tiles")
+        return True
 
     def get_size(self, lv: int = 0) -> Tuple[int, int]:
         self._ensure_loaded()

@@ -1,7 +1,10 @@
 // Library-level entry points of the C ABI: error text, device info, K1 wrappers.
 #include <cstdarg>
 #include <cstdio>
+#include <cstdio>
 #include <cstring>
+#include <vector>
+#include <zlib.h>
 #include "ap_common.h"
 
 namespace ap {
@@ -19,7 +22,7 @@ void set_error(const char* fmt, ...) {
 
 extern "C" {
 
-int ap_abi_version(void) { return 7; }
+int ap_abi_version(void) { return 8; }
 
 const char* ap_last_error(void) { return ap::g_error; }
 
@@ -55,6 +58,28 @@ int ap_host_gather_tiles(void* dst, const void* const* src, int n, size_t bytes_
     for (int i = 0; i < n; ++i) {
         AP_REQUIRE(src[i], "ap_host_gather_tiles: null tile %d", i);
         memcpy(d + (size_t)i * bytes_each, src[i], bytes_each);
+    }
+    return AP_OK;
+}
+
+int ap_host_inflate_tiles(void* dst, const char* const* paths, int n, size_t bytes_each) {
+    AP_REQUIRE(dst && (paths || n == 0) && n >= 0 && bytes_each > 0, "ap_host_inflate_tiles: bad arguments");
+    std::vector<unsigned char> buf;
+    for (int i = 0; i < n; ++i) {
+        AP_REQUIRE(paths[i], "ap_host_inflate_tiles: null path %d", i);
+        FILE* f = fopen(paths[i], "rb");
+        AP_REQUIRE(f, "ap_host_inflate_tiles: cannot open %s", paths[i]);
+        fseek(f, 0, SEEK_END);
+        const long size = ftell(f);
+        fseek(f, 0, SEEK_SET);
+        buf.resize(size > 0 ? (size_t)size : 1);
+        const size_t got = size > 0 ? fread(buf.data(), 1, (size_t)size, f) : 0;
+        fclose(f);
+        AP_REQUIRE(size > 0 && got == (size_t)size, "ap_host_inflate_tiles: short read of %s", paths[i]);
+        uLongf len = (uLongf)bytes_each;
+        const int zr = uncompress((Bytef*)dst + (size_t)i * bytes_each, &len, buf.data(), (uLong)size);
+        AP_REQUIRE(zr == Z_OK && len == bytes_each, "ap_host_inflate_tiles: %s does not inflate to %zu bytes (zlib %d)",
+                   paths[i], bytes_each, zr);
     }
     return AP_OK;
 }

@@ -214,7 +214,7 @@ class PatchFeatureEmbeddingService(FeatureEmbeddingService):
         with torch.cuda.device(extractor.device):
             return self._ring.run(coords, self._read_tile(wsi),
                                   lambda tiles, out: extractor.forward_device(tiles, out),
-                                  extractor.embedding_dim)
+                                  extractor.embedding_dim, read_chunk=getattr(wsi, "read_tiles_into", None))
 
     def _embed_device_source(self, coords: np.ndarray, wsi: IWSI, extractor, batch: int):
         """Backends that can materialise tiles in HBM themselves (``extract_batch_device``, e.g. the synthetic

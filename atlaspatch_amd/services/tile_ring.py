@@ -45,10 +45,12 @@ class TileRing:
         self.pool = futures.ThreadPoolExecutor(max_workers=self.workers, thread_name_prefix="tile")
 
     def run(self, coords: np.ndarray, read_tile: Callable[[int, int, int, int, int], np.ndarray],
-            forward: Callable[[torch.Tensor, torch.Tensor], None], out_dim: int) -> np.ndarray:
+            forward: Callable[[torch.Tensor, torch.Tensor], None], out_dim: int, *,
+            read_chunk: Callable | None = None) -> np.ndarray:
         """coords int32 [N, 5]; ``read_tile(x, y, rw, rh, lv)`` -> uint8 [ps, ps, 3];
         ``forward(tiles_dev [n,ps,ps,3], out_dev [n,D])`` enqueues on the current stream.
-        Returns float32 [N, D] (host)."""
+        ``read_chunk(rows, dst_ptr, patch_size) -> bool`` (optional): a backend's native batched decoder; when it
+        returns True the chunk's tiles are already in the pinned slot.  Returns float32 [N, D] (host)."""
         n_total = int(coords.shape[0])
         out_host = torch.empty((n_total, out_dim), dtype=torch.float32).pin_memory() if n_total else \
             torch.empty((0, out_dim), dtype=torch.float32)
@@ -71,6 +73,8 @@ class TileRing:
                 # decode the chunk, then ONE ap_host_gather_tiles call copies it into the pinned slot with the
                 # interpreter lock released (a NumPy slice assignment per tile would hold it for every 196 KB memcpy)
                 stop = min(count, start + chunk)
+                if read_chunk is not None and read_chunk(rows[start:stop], base + start * tile_bytes, self.ps):
+                    return
                 tiles = []
                 for i in range(start, stop):
                     x, y, rw, rh, lv = rows[i]

@@ -69,6 +69,10 @@ int ap_preproc_u8hwc_to_patchrows(const uint8_t* src, int n, int h, int w,
  * services/feature_embedding.py:81-96 call it once per chunk, so an in-memory tile source is not serialised by
  * per-tile NumPy slice assignments.  Host only, no device work. */
 int ap_host_gather_tiles(void* dst, const void* const* src, int n, size_t bytes_each);
+/* The same for tiles stored as zlib-deflated raw RGB files (the synthetic slide's compressed tile store): reads and
+ * inflates n files straight into consecutive slots, one call per chunk -- the shape a native reader for a real slide
+ * format takes (the reference's per-tile Python read, services/feature_embedding.py:86-95, cannot leave the interpreter). */
+int ap_host_inflate_tiles(void* dst, const char* const* paths, int n, size_t bytes_each);
 
 /* ---- Pillow-exact tile resampling ------------------------------------------------------
  * Replaces the PIL resize inside the per-item transform of encoders whose transform starts with Resize:

@@ -257,7 +257,7 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/atlaspatch_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert _lib.load().ap_abi_version() == 7
+    assert _lib.load().ap_abi_version() == 8
 
 
 def test_product_has_no_cpu_fallback():
@@ -345,3 +345,27 @@ def test_synth_slide_with_jpeg_tile_store(tmp_path):
     assert got.shape == (256, 256, 3) and abs(int(got.mean()) - 77) <= 1            # decoded, not rendered
     assert np.array_equal(wsi.extract((0, 0), 0, (256, 256)), render_region(spec, 0, 0, 256, 256, 0))   # not in the store
     assert wsi.extract_batch_device(np.array([[0, 0, 256, 256, 0]]), "cpu", 256) is None
+
+
+def test_native_batched_decode_of_the_deflate_tile_store(tmp_path):
+    """ap_host_inflate_tiles through SynthWSI.read_tiles_into: the chunk lands in consecutive slots, bit-equal to the
+    stored pixels; a missing tile or a wrong size makes the capability decline (False) instead of guessing."""
+    import json, zlib
+    from atlaspatch_amd.core.wsi.wsi_factory import WSIFactory
+    store = tmp_path / "tiles"
+    store.mkdir()
+    rng = np.random.default_rng(0)
+    tiles = {(256 * i, 512): rng.integers(0, 256, (256, 256, 3), dtype=np.uint8) for i in range(4)}
+    for (x, y), t in tiles.items():
+        (store / f"{x}_{y}_256.z").write_bytes(zlib.compress(t.tobytes(), 1))
+    path = tmp_path / "s.synth"
+    path.write_text(json.dumps({"width": 4096, "height": 4096, "seed": 3, "jpeg_tiles": "tiles"}))
+    wsi = WSIFactory.load(str(path))
+    rows = [[x, y, 256, 256, 0] for (x, y) in tiles]
+    dst = np.zeros((4, 256, 256, 3), np.uint8)
+    assert wsi.read_tiles_into(rows, dst.ctypes.data, 256) is True
+    for i, key in enumerate(tiles):
+        assert np.array_equal(dst[i], tiles[key])
+        assert np.array_equal(wsi.extract(key, 0, (256, 256)), tiles[key])          # the per-tile path reads the same store
+    assert wsi.read_tiles_into(rows + [[0, 0, 256, 256, 0]], dst.ctypes.data, 256) is False
+    assert wsi.read_tiles_into([[0, 512, 512, 512, 0]], dst.ctypes.data, 256) is False

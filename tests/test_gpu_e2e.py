@@ -218,6 +218,38 @@ def test_device_tile_source_equals_host_ring(tmp_path, monkeypatch):
                              f"NaNs device {int(np.isnan(d).sum())} host {int(np.isnan(h).sum())}")
 
 
+def test_compressed_tile_store_through_the_native_decode_hook(tmp_path, monkeypatch):
+    """A slide whose tiles sit in a (lossless) deflate tile store: the ring's workers fill the pinned slots through
+    ``IWSI.read_tiles_into`` -> ``ap_host_inflate_tiles``; the features must equal those of the same slide served from
+    the device tile source bit for bit."""
+    import zlib
+    from click.testing import CliRunner
+    from atlaspatch_amd.cli import cli
+    from atlaspatch_amd.core.wsi.synth_pixels import SynthSpec, render_region
+    from atlaspatch_amd.utils.h5 import h5
+
+    monkeypatch.setenv("ATLASPATCH_RANDOM_INIT", "2")
+    spec_kw = dict(width=7000, height=5000, seed=8)
+    args = ["--patch-size", "256", "--target-mag", "20", "--feature-extractors", "vit_b_16", "--feature-precision", "float16",
+            "--feature-num-workers", "4"]
+    plain = tmp_path / "plain"; plain.mkdir()
+    (plain / "s5.synth").write_text(json.dumps({**spec_kw, "mag": 20, "mpp": 0.5, "downsamples": [1, 4, 16]}))
+    res = CliRunner().invoke(cli, ["process", str(plain / "s5.synth"), "-o", str(tmp_path / "o1"), *args], catch_exceptions=False)
+    assert res.exit_code == 0 and "failures: 0" in res.output, res.output
+    with h5.File(tmp_path / "o1" / "patches" / "s5.h5", "r") as f:
+        coords, want = f["coords"][:], f["features"]["vit_b_16"][:]
+    stored = tmp_path / "stored"; (stored / "tiles").mkdir(parents=True)
+    spec = SynthSpec(**spec_kw)
+    for x, y in coords[:, :2].tolist():
+        (stored / "tiles" / f"{x}_{y}_256.z").write_bytes(zlib.compress(render_region(spec, x, y, 256, 256, 0).tobytes(), 1))
+    (stored / "s5.synth").write_text(json.dumps({**spec_kw, "mag": 20, "mpp": 0.5, "downsamples": [1, 4, 16], "jpeg_tiles": "tiles"}))
+    res = CliRunner().invoke(cli, ["process", str(stored / "s5.synth"), "-o", str(tmp_path / "o2"), *args], catch_exceptions=False)
+    assert res.exit_code == 0 and "failures: 0" in res.output, res.output
+    with h5.File(tmp_path / "o2" / "patches" / "s5.h5", "r") as f:
+        got = f["features"]["vit_b_16"][:]
+    assert got.shape[0] > 0 and np.array_equal(got, want)
+
+
 def test_segment_and_get_coords_with_sam2_on_an_image_slide(tmp_path, monkeypatch):
     """Real (non-synthetic) slide path: a PNG through the Pillow backend, SAM2 Hiera-T segmenter on the HIP
     operator set (seeded random weights: the mask is arbitrary, the plumbing is what is checked), device coords,

@@ -160,9 +160,9 @@ class IWSI(abc.ABC):
         """Whole-slide RGB image at objective ``power`` (iwsi.py:246-323).
 
         Reads the pyramid level chosen by ``optimal_level(mag / power)`` in full and, when
-        that level is not already the exact ``(W0/ds, H0/ds)`` size, resamples it.  The
-        reference resamples with ``cv2.resize`` (AREA down / CUBIC up); here that step is
-        done by ``utils.resample.resize_area_or_cubic`` (restated, parity unpinned).
+        that level is not already the exact ``(W0/ds, H0/ds)`` size, resamples it with
+        ``cv2.resize`` semantics (AREA when shrinking / CUBIC when enlarging, iwsi.py:305-321)
+        on the device (``ap_cv2_resize_u8``).
         """
         self._ensure_loaded()
         if self.mag is None:
@@ -183,8 +183,9 @@ class IWSI(abc.ABC):
         out_w = max(1, int(round(width0 / ds_target)))
         out_h = max(1, int(round(height0 / ds_target)))
         if region.shape[1] != out_w or region.shape[0] != out_h:
-            from atlaspatch_amd.utils.resample import resize_area_or_cubic
-            region = resize_area_or_cubic(region, (out_w, out_h), interpolation)
+            from atlaspatch_amd.utils.resample import cv2_resize_array, thumbnail_interpolation
+            region = cv2_resize_array(region, (out_w, out_h),
+                                      thumbnail_interpolation(region.shape[:2], (out_w, out_h), interpolation))
         return Image.fromarray(region)
 
     def __enter__(self):

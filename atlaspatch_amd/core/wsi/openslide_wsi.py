@@ -19,10 +19,76 @@ try:  # pragma: no cover - optional dependency
 except Exception:  # noqa: BLE001
     openslide = None
 
-_MPP_KEYS = ("openslide.mpp-x", "aperio.MPP", "hamamatsu.XResolution", "mirax.DICOM.PIXEL_SPACING")
+# key tables and their priority order as the reference holds them (openslide_wsi.py:19-32)
+_MPP_KEYS = ("openslide.mpp-x", "openslide.mpp-y", "openslide.mirax.MPP", "aperio.MPP", "hamamatsu.XResolution")
 _MPP_TEXT_KEYS = ("openslide.comment", "tiff.ImageDescription")
-_MAG_KEYS = ("openslide.objective-power", "aperio.AppMag")
+_MAG_KEYS = ("aperio.AppMag", "openslide.objective-power", "hamamatsu.SourceLens")
 _MPP_PATTERNS = (r"mpp\s*[:=]\s*([0-9]*\.?[0-9]+)", r"microns?\s+per\s+pixel[^0-9]*([0-9]*\.?[0-9]+)")
+
+
+def _mpp_from_text(text) -> Optional[float]:
+    """openslide_wsi.py:149-182: first pattern that matches AND parses."""
+    if not text:
+        return None
+    for pattern in _MPP_PATTERNS:
+        match = re.search(pattern, text, flags=re.IGNORECASE)
+        if match:
+            try:
+                return float(match.group(1))
+            except ValueError:
+                continue
+    return None
+
+
+def mpp_from_properties(meta: dict) -> Optional[float]:
+    """MPP lookup of the reference (openslide_wsi.py:71-128), on a plain property dict: direct keys in priority
+    order -> free-text fields -> TIFF resolution -> 10 / magnification; rounded to 4 decimals."""
+    for key in _MPP_KEYS:
+        if key in meta:
+            try:
+                return round(float(meta[key]), 4)
+            except (TypeError, ValueError):
+                continue
+    for key in _MPP_TEXT_KEYS:
+        parsed = _mpp_from_text(meta.get(key))
+        if parsed is not None:
+            return round(parsed, 4)
+    try:
+        res, unit = meta.get("tiff.XResolution"), meta.get("tiff.ResolutionUnit")
+        if res and unit:
+            res_f = float(res)
+            if unit.lower() == "centimeter":
+                return round(10000 / res_f, 4)
+            elif unit.lower() == "inch":
+                return round(25400 / res_f, 4)
+    except (TypeError, ValueError):
+        pass
+    for key in _MAG_KEYS:
+        value = meta.get(key)
+        if value is not None:
+            try:
+                mag = float(value)
+                if mag > 0:
+                    return round(10.0 / mag, 4)
+            except (TypeError, ValueError):
+                continue
+    return None
+
+
+def mag_from_properties(meta: dict, mpp: Optional[float], infer_mag) -> Optional[int]:
+    """Magnification (openslide_wsi.py:130-147): the objective-power property, else inferred from MPP."""
+    power = meta.get("openslide.objective-power")
+    if power:
+        try:
+            return int(float(power))
+        except (TypeError, ValueError):
+            pass
+    if mpp is not None:
+        try:
+            return infer_mag(mpp)
+        except ValueError:
+            pass
+    return None
 
 
 class OpenSlideWSI(IWSI):
@@ -43,53 +109,14 @@ class OpenSlideWSI(IWSI):
             self.mpp = self.validate_mpp(float(self._mpp_manual), source="user-provided mpp")
         else:
             found = self._extract_mpp()
-            self.mpp = self.validate_mpp(found) if found is not None else None
+            self.mpp = self.validate_mpp(found, source="slide metadata") if found is not None else None
         self.mag = self._extract_mag()
 
     def _extract_mpp(self) -> Optional[float]:
-        meta = self.meta or {}
-        for key in _MPP_KEYS:
-            try:
-                if key in meta:
-                    return round(float(meta[key]), 4)
-            except (TypeError, ValueError):
-                continue
-        for key in _MPP_TEXT_KEYS:
-            text = meta.get(key)
-            for pattern in _MPP_PATTERNS if text else ():
-                match = re.search(pattern, text, flags=re.IGNORECASE)
-                if match:
-                    return round(float(match.group(1)), 4)
-        try:
-            res, unit = meta.get("tiff.XResolution"), meta.get("tiff.ResolutionUnit")
-            if res and unit:
-                scale = {"centimeter": 10000.0, "inch": 25400.0}.get(unit.lower())
-                if scale:
-                    return round(scale / float(res), 4)
-        except (TypeError, ValueError):
-            pass
-        for key in _MAG_KEYS:
-            try:
-                mag = float(meta.get(key))
-                if mag > 0:
-                    return round(10.0 / mag, 4)
-            except (TypeError, ValueError):
-                continue
-        return None
+        return mpp_from_properties(self.meta or {})
 
     def _extract_mag(self) -> Optional[int]:
-        power = (self.meta or {}).get("openslide.objective-power")
-        if power:
-            try:
-                return int(float(power))
-            except (TypeError, ValueError):
-                pass
-        if self.mpp is not None:
-            try:
-                return self._infer_mag(self.mpp)
-            except ValueError:
-                pass
-        return None
+        return mag_from_properties(self.meta or {}, self.mpp, self._infer_mag)
 
     def extract(self, xy: Tuple[int, int], lv: int, wh: Tuple[int, int], *,
                 mode: Literal["array", "image"] = "array") -> Union[np.ndarray, Image.Image]:

@@ -95,10 +95,12 @@ class SynthWSI(IWSI):
         raise ValueError(f"Invalid mode: {mode}")
 
     def extract_batch_device(self, rows: np.ndarray, device, patch_size: int):
-        """Optional IWSI capability (device tile source): uint8 [n, ps, ps, 3] in HBM for coords rows
-        (x, y, read_w, read_h, level), or None when the backend cannot serve them on the device.  The synthetic
-        slide's pixel function runs as ``ap_synth_tiles`` (bit-identical to ``render_region``, tested), which
-        stands in for a GPU tile decoder; real backends decode on the host and go through the tile ring."""
+        """Optional IWSI capability (device tile source): uint8 [n, read_h, read_w, 3] in HBM for coords rows
+        (x, y, read_w, read_h, level) -- tiles at their READ size, like ``extract``; the caller applies the
+        reference's ``cv2.resize`` to ``patch_size`` on the device when the two differ -- or None when the backend
+        cannot serve them on the device.  The synthetic slide's pixel function runs as ``ap_synth_tiles``
+        (bit-identical to ``render_region``, tested), which stands in for a GPU tile decoder; real backends decode
+        on the host and go through the tile ring."""
         import torch
         from ... import _lib
         self._ensure_loaded()
@@ -107,40 +109,57 @@ class SynthWSI(IWSI):
         rows = np.asarray(rows)
         if rows.size == 0:
             return torch.empty((0, patch_size, patch_size, 3), dtype=torch.uint8, device=device)
-        lv = int(rows[0, 4])
-        if np.any(rows[:, 4] != lv) or np.any(rows[:, 2] != patch_size) or np.any(rows[:, 3] != patch_size):
+        lv, side = int(rows[0, 4]), int(rows[0, 2])
+        if np.any(rows[:, 4] != lv) or np.any(rows[:, 2] != side) or np.any(rows[:, 3] != side):
             return None
         lib = _lib.load()
+        device = torch.device(device)
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
         cache = getattr(self, "_dev_ellipses", None)
-        if cache is None or cache.device != torch.device(device):
+        if cache is None or cache.device != device:
             cache = torch.from_numpy(self.spec.ellipses()).to(device)
             self._dev_ellipses = cache
         xy = torch.from_numpy(np.ascontiguousarray(rows[:, :2], dtype=np.int32)).to(device)
-        tiles = torch.empty((rows.shape[0], patch_size, patch_size, 3), dtype=torch.uint8, device=device)
+        tiles = torch.empty((rows.shape[0], side, side, 3), dtype=torch.uint8, device=device)
         with torch.cuda.device(device):
-            _lib.check(lib.ap_synth_tiles(xy.data_ptr(), rows.shape[0], patch_size, int(round(self.ds[lv])), lv,
+            _lib.check(lib.ap_synth_tiles(xy.data_ptr(), rows.shape[0], side, int(round(self.ds[lv])), lv,
                                           self.spec.width, self.spec.height, self.spec.seed, cache.data_ptr(),
                                           cache.shape[0], tiles.data_ptr(), _lib.current_stream_ptr(device)),
                        "ap_synth_tiles")
         return tiles
 
-    def read_tiles_into(self, rows, dst_ptr: int, patch_size: int) -> bool:
+    def read_tiles_into(self, rows, dst_ptr: int, tile_side: int) -> bool:
         """Optional IWSI capability (native batched host decode): decode the tiles of ``rows`` (x, y, rw, rh, lv) into
-        consecutive ``patch_size^2 * 3``-byte slots at ``dst_ptr`` in ONE call outside the interpreter lock, or return
-        False when this backend cannot (the caller then reads tile by tile).  Here: the deflate tile store."""
+        consecutive ``tile_side^2 * 3``-byte slots at ``dst_ptr`` in ONE call outside the interpreter lock, or return
+        False when this backend cannot (the caller then reads tile by tile).  The deflate tile store is inflated by
+        ``ap_host_inflate_tiles``; a plain synthetic slide is rendered by ``ap_host_synth_tiles`` (the C twin of
+        ``render_region``) -- both stand in for a real format's native tile decoder."""
         import ctypes as C
         from ... import _lib
         self._ensure_loaded()
-        if self.jpeg_dir is None:
+        if not rows:
+            return True
+        lv0 = int(rows[0][4])
+        if any(int(r[2]) != tile_side or int(r[3]) != tile_side or int(r[4]) != lv0 for r in rows):
             return False
+        if self.jpeg_dir is None:
+            xy = np.ascontiguousarray([[r[0], r[1]] for r in rows], dtype=np.int32)
+            ell = getattr(self, "_host_ellipses", None)
+            if ell is None:
+                ell = self._host_ellipses = np.ascontiguousarray(self.spec.ellipses(), dtype=np.int64)
+            _lib.check(_lib.load().ap_host_synth_tiles(dst_ptr, xy.ctypes.data, len(rows), tile_side, int(round(self.ds[lv0])),
+                                                       lv0, self.spec.width, self.spec.height, self.spec.seed,
+                                                       ell.ctypes.data, ell.shape[0]), "ap_host_synth_tiles")
+            return True
         paths = []
         for x, y, rw, rh, lv in rows:
             p = os.path.join(self.jpeg_dir, f"{int(x)}_{int(y)}_{int(rw)}.z")
-            if lv != 0 or rw != patch_size or rh != patch_size or not os.path.exists(p):
+            if lv != 0 or not os.path.exists(p):
                 return False
             paths.append(p.encode())
         arr = (C.c_char_p * len(paths))(*paths)
-        _lib.check(_lib.load().ap_host_inflate_tiles(dst_ptr, arr, len(paths), patch_size * patch_size * 3),
+        _lib.check(_lib.load().ap_host_inflate_tiles(dst_ptr, arr, len(paths), tile_side * tile_side * 3),
                    "ap_host_inflate_tiles")
         return True
 

@@ -2,6 +2,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdio>
+#include <climits>
 #include <cstring>
 #include <vector>
 #include <zlib.h>
@@ -22,7 +23,7 @@ void set_error(const char* fmt, ...) {
 
 extern "C" {
 
-int ap_abi_version(void) { return 8; }
+int ap_abi_version(void) { return 9; }
 
 const char* ap_last_error(void) { return ap::g_error; }
 
@@ -80,6 +81,40 @@ int ap_host_inflate_tiles(void* dst, const char* const* paths, int n, size_t byt
         const int zr = uncompress((Bytef*)dst + (size_t)i * bytes_each, &len, buf.data(), (uLong)size);
         AP_REQUIRE(zr == Z_OK && len == bytes_each, "ap_host_inflate_tiles: %s does not inflate to %zu bytes (zlib %d)",
                    paths[i], bytes_each, zr);
+    }
+    return AP_OK;
+}
+
+int ap_host_synth_tiles(void* dst, const int32_t* xy, int n, int side, int level_ds, int level, int64_t width,
+                        int64_t height, uint32_t seed, const int64_t* ellipses, int k) {
+    AP_REQUIRE(dst && (xy || n == 0) && (ellipses || k == 0) && n >= 0 && side > 0 && level_ds > 0 && k >= 0,
+               "ap_host_synth_tiles: bad arguments");
+    auto mix = [](uint32_t a) { a ^= a >> 16; a *= 0x7FEB352Du; a ^= a >> 15; a *= 0x846CA68Bu; a ^= a >> 16; return a; };
+    uint8_t* o = (uint8_t*)dst;
+    for (int t = 0; t < n; ++t) {
+        for (int py = 0; py < side; ++py) {
+            const long long gy = (long long)xy[2 * t + 1] + (long long)py * level_ds, uy = gy >> 4;
+            long long last_ux = INT64_MIN;
+            bool tissue = false;
+            for (int px = 0; px < side; ++px, o += 3) {
+                const long long gx = (long long)xy[2 * t] + (long long)px * level_ds, ux = gx >> 4;
+                if (gx < 0 || gy < 0 || gx >= width || gy >= height) { o[0] = o[1] = o[2] = 0; continue; }
+                if (ux != last_ux) {           // the ellipse test lives on a 16-pixel lattice: once per lattice cell
+                    last_ux = ux;
+                    tissue = false;
+                    for (int e = 0; e < k && !tissue; ++e) {
+                        const long long a = ellipses[4 * e + 2], b = ellipses[4 * e + 3];
+                        const long long dx = (ux - ellipses[4 * e]) * b, dy = (uy - ellipses[4 * e + 1]) * a, ab = a * b;
+                        tissue = dx * dx + dy * dy <= ab * ab;
+                    }
+                }
+                const uint32_t h = mix((uint32_t)gx * 0x9E3779B1u + (uint32_t)gy * 0x85EBCA77u + seed + (uint32_t)level * 0xC2B2AE3Du);
+                const int n0 = h & 0xFF, n1 = (h >> 8) & 0xFF, n2 = (h >> 16) & 0xFF, bg = 236 + (n0 & 7);
+                o[0] = (uint8_t)(tissue ? 168 + (n0 >> 2) : bg);
+                o[1] = (uint8_t)(tissue ? 72 + (n1 >> 1) : bg);
+                o[2] = (uint8_t)(tissue ? 136 + (n2 >> 2) : bg);
+            }
+        }
     }
     return AP_OK;
 }

@@ -29,6 +29,18 @@ IMAGENET_STD = (0.229, 0.224, 0.225)
 OPENAI_CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 OPENAI_CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
 
+# Leading Resize of the reference transform per registered name: (shorter side, Pillow filter).
+# torchvision (models/patch/base.py:126-145 prefers <enum>.IMAGENET1K_V1, base.py:170 takes weights.transforms()) [3P]:
+#   ViT_B_16_Weights.IMAGENET1K_V1 = ImageClassification(crop_size=224)                  -> resize_size 256 (default), bilinear
+#   ViT_L_16_Weights.IMAGENET1K_V1 = ImageClassification(crop_size=224, resize_size=242) -> 256-px tiles ARE resampled to 242
+# timm / open_clip: uni_v1 Resize(224, bicubic), conch_v1 Resize(448, bicubic).
+TRANSFORM_RESIZE = {
+    "vit_b_16": (256, "bilinear"),
+    "vit_l_16": (242, "bilinear"),
+    "uni_v1": (224, "bicubic"),
+    "conch_v1": (448, "bicubic"),
+}
+
 ARCHS = {
     # name: image, patch, dim, depth, heads, mlp, eps, layer_scale
     "vit_b_16": dict(image_size=224, patch_size=16, dim=768, depth=12, heads=12, mlp_dim=3072,
@@ -365,7 +377,7 @@ def register_conch(registry, *, device, dtype=torch.float32, num_workers: int = 
     ap_resample_u8).  float16 / bfloat16 only (the reference's config 5 runs it in fp16)."""
     registry.register("conch_v1", lambda: build_hip_vit_extractor(
         name="conch_v1", arch="conch_v1", device=device, dtype=dtype, random_init_seed=_env_seed(),
-        mean=OPENAI_CLIP_MEAN, std=OPENAI_CLIP_STD, resize=(448, "bicubic"), expect_size=None,
+        mean=OPENAI_CLIP_MEAN, std=OPENAI_CLIP_STD, resize=TRANSFORM_RESIZE["conch_v1"], expect_size=None,
         max_batch=256))
 
 
@@ -375,13 +387,14 @@ def _env_seed() -> Optional[int]:
 
 
 def register_vits(registry, *, device, dtype=torch.float32, num_workers: int = 0) -> None:
-    """vit_b_16 / vit_l_16 with torchvision's transform semantics: ImageClassification(crop 224, resize 256,
-    bilinear) on the PIL tile (models/patch/base.py:42-45 hands the transform a PIL image, so the resize is
-    Pillow's BILINEAR): for the 256-px tiles this pipeline produces by default it is a pure centre crop; other
-    --patch-size values go through the Pillow-exact device resize (shorter side -> 256) first."""
+    """vit_b_16 / vit_l_16 with torchvision's transform semantics: ImageClassification(crop 224, resize R, bilinear)
+    on the PIL tile (models/patch/base.py:42-45 hands the transform a PIL image, so the resize is Pillow's BILINEAR),
+    R = 256 for vit_b_16 and 242 for vit_l_16 (``TRANSFORM_RESIZE``).  vit_b_16 on the default 256-px tiles is a pure
+    centre crop; vit_l_16 resamples every 256-px tile to 242 first; any other --patch-size goes through the same
+    Pillow-exact device resize (shorter side -> R)."""
     for name in ("vit_b_16", "vit_l_16"):
         registry.register(name, lambda n=name: build_hip_vit_extractor(
-            name=n, arch=n, device=device, dtype=dtype, random_init_seed=_env_seed(), resize=(256, "bilinear"),
+            name=n, arch=n, device=device, dtype=dtype, random_init_seed=_env_seed(), resize=TRANSFORM_RESIZE[n],
             expect_size=None, max_batch=2048))
 
 
@@ -390,4 +403,4 @@ def register_uni(registry, *, device, dtype=torch.float32, num_workers: int = 0)
     the resize runs on the device bit-identically to Pillow (ap_resample_u8), the crop in the preprocess kernel."""
     registry.register("uni_v1", lambda: build_hip_vit_extractor(
         name="uni_v1", arch="uni_v1", device=device, dtype=dtype, random_init_seed=_env_seed(),
-        resize=(224, "bicubic"), expect_size=None, max_batch=2048))
+        resize=TRANSFORM_RESIZE["uni_v1"], expect_size=None, max_batch=2048))

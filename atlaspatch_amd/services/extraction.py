@@ -135,7 +135,12 @@ class PatchExtractionService(ExtractionService):
         ps = int(self.cfg.patch_size)
         n = int(coords.shape[0])
         keep = np.ones(n, dtype=bool)
-        host = torch.empty((batch, ps, ps, 3), dtype=torch.uint8).pin_memory()
+        if n == 0:
+            return np.ascontiguousarray(coords)
+        # tiles are read at their level size; cv2.resize(patch, (ps, ps)) (extraction.py:112-113) runs on the device
+        rw, rh = int(coords[0, 2]), int(coords[0, 3])
+        resized = (rw, rh) != (ps, ps)
+        host = torch.empty((batch, rh, rw, 3), dtype=torch.uint8).pin_memory()
         view = host.numpy()
         writers = futures.ThreadPoolExecutor(max_workers=max(2, min(8, __import__("os").cpu_count() or 4)),
                                              thread_name_prefix="patch-img") if img_dir is not None else None
@@ -143,27 +148,33 @@ class PatchExtractionService(ExtractionService):
         pending = []
 
         def read(i, row):
-            x, y, rw, rh, lv = (int(v) for v in row)
-            tile = wsi.extract((x, y), lv=lv, wh=(rw, rh), mode="array")
-            if tile.shape[0] != ps or tile.shape[1] != ps:
-                raise NotImplementedError("tiles that need cv2.resize to patch_size are not part of this build")
+            x, y, w_, h_, lv = (int(v) for v in row)
+            tile = wsi.extract((x, y), lv=lv, wh=(w_, h_), mode="array")
+            if tile.shape[:2] != (rh, rw):
+                raise ValueError(f"tile source returned shape {tile.shape}, expected {(rh, rw, 3)}")
             view[i] = tile
 
         try:
             for lo in range(0, n, batch):
                 hi = min(n, lo + batch)
                 list(readers.map(lambda i: read(i - lo, coords[i]), range(lo, hi)))
-                if not self.cfg.fast_mode:
+                patches = view
+                if resized or not self.cfg.fast_mode:
                     tiles = host[:hi - lo].to(device, non_blocking=False)
-                    black, white = tile_content_flags(tiles, black_thresh=self.cfg.black_threshold,
-                                                      white_thresh=self.cfg.white_threshold)
-                    keep[lo:hi] = ~(black | white)          # is_black first, then is_white (extraction.py:113-116)
+                    if resized:
+                        from ..utils.resample import INTER_LINEAR, cv2_resize_device
+                        tiles = cv2_resize_device(tiles, (ps, ps), INTER_LINEAR)
+                        patches = tiles.cpu().numpy() if writers is not None else None
+                    if not self.cfg.fast_mode:
+                        black, white = tile_content_flags(tiles, black_thresh=self.cfg.black_threshold,
+                                                          white_thresh=self.cfg.white_threshold)
+                        keep[lo:hi] = ~(black | white)          # is_black first, then is_white (extraction.py:113-116)
                 if writers is not None:
                     for i in range(lo, hi):
                         if keep[i]:
                             x, y = int(coords[i, 0]), int(coords[i, 1])
                             pending.append(writers.submit(
-                                lambda arr, path: Image.fromarray(arr).save(str(path)), view[i - lo].copy(),
+                                lambda arr, path: Image.fromarray(arr).save(str(path)), patches[i - lo].copy(),
                                 img_dir / f"{slide.stem}_x{x}_y{y}.png"))
             for f in pending:
                 f.result()

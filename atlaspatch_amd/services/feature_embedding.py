@@ -45,10 +45,19 @@ def resolve_feature_dtype(device: torch.device, precision: str) -> torch.dtype:
 
 
 def _resize_tile(tile: np.ndarray, size: int) -> np.ndarray:
-    """cv2.resize(tile, (size, size)) stand-in (INTER_LINEAR) for level reads that are not already
-    ``patch_size`` (feature_embedding.py:94-95) -- Pillow bilinear, parity unpinned."""
-    from PIL import Image
-    return np.asarray(Image.fromarray(tile).resize((size, size), Image.Resampling.BILINEAR))
+    """``cv2.resize(tile, (size, size))`` (INTER_LINEAR) for a level read that is not already ``patch_size``
+    (feature_embedding.py:94-95), one tile through the device kernel: only the generic (plugin-encoder) loop uses
+    this; the native path resizes whole ring batches on the device."""
+    from ..utils.resample import INTER_LINEAR, cv2_resize_array
+    return cv2_resize_array(tile, (size, size), INTER_LINEAR)
+
+
+def _to_patch_size(tiles: torch.Tensor, ps: int) -> torch.Tensor:
+    """Device batch at its read size -> ``[n, ps, ps, 3]`` with the reference's ``cv2.resize(patch, (ps, ps))``."""
+    if tiles.shape[1] == ps and tiles.shape[2] == ps:
+        return tiles
+    from ..utils.resample import INTER_LINEAR, cv2_resize_device
+    return cv2_resize_device(tiles, (ps, ps), INTER_LINEAR)
 
 
 class PatchFeatureEmbeddingService(FeatureEmbeddingService):
@@ -195,26 +204,47 @@ class PatchFeatureEmbeddingService(FeatureEmbeddingService):
         result.metadata["feature_sets"] = merged
         return self._stamp(result)
 
+    # one ring batch: 2048 tiles quantise best onto the 256 persistent GEMM workgroups; tiles that are
+    # read larger than the patch size (resized on the device) shrink the batch so that a pinned slot stays <= ~0.8 GB
+    _SLOT_BYTES = 2048 * 256 * 256 * 3 * 2
+
+    def _ring_batch(self, extractor, tile_hw) -> int:
+        cap = min(2048, max(1, int(getattr(extractor, "max_batch", 1024))))
+        by_bytes = max(64, self._SLOT_BYTES // (tile_hw[0] * tile_hw[1] * 3))
+        return max(1, min(cap, by_bytes))
+
     def embed_matrix(self, result: ExtractionResult, wsi: IWSI, extractor: HipViTFeatureExtractor) -> np.ndarray:
-        """float32 [N, D] for one slide through the pinned tile ring (device pipeline)."""
+        """float32 [N, D] for one slide through the pinned tile ring (device pipeline).  Tiles cross the ring at
+        their read size; ``cv2.resize`` to ``patch_size`` (feature_embedding.py:94-95) runs on the device."""
         from .tile_ring import TileRing
         coords = read_coords(result.h5_path)
-        # device batch: 2048 tiles quantise best onto the 256 persistent GEMM workgroups (DESIGN.md section 5); never above
-        # what the encoder accepts in one forward, never below the CLI's --feature-batch-size
-        cap = min(2048, max(1, int(getattr(extractor, "max_batch", 1024))))
-        batch = max(self.feature_cfg.batch_size, min(cap, max(1, coords.shape[0])))
+        ps = int(self.cfg.patch_size)
+        if coords.shape[0] == 0:
+            return np.empty((0, extractor.embedding_dim), dtype=np.float32)
+        rw, rh = int(coords[0, 2]), int(coords[0, 3])
+        if np.any(coords[:, 2] != rw) or np.any(coords[:, 3] != rh):
+            raise ValueError("coords rows of one slide must share one read size")
+        tile_hw = (rh, rw)
+        batch = self._ring_batch(extractor, tile_hw)
         feats = self._embed_device_source(coords, wsi, extractor, batch)
         if feats is not None:
             return feats
-        if self._ring is None or self._ring.batch != batch or self._ring.ps != self.cfg.patch_size:
-            if self._ring is not None:
-                self._ring.close()
-            self._ring = TileRing(device=extractor.device, batch=batch, patch_size=self.cfg.patch_size,
-                                  slots=3, workers=max(1, self.feature_cfg.num_workers))
+        # sized once per (patch size, read size): short slides run as partial batches, the pinned slots are kept
+        ring = self._ring
+        if ring is None or ring.batch != batch or ring.ps != ps or (ring.th, ring.tw) != tile_hw or \
+                ring.device != extractor.device:
+            if ring is not None:
+                ring.close()
+            self._ring = ring = TileRing(device=extractor.device, batch=batch, patch_size=ps, tile_hw=tile_hw,
+                                         slots=3, workers=max(1, self.feature_cfg.num_workers))
+
+        def read(x, y, rw_, rh_, lv):
+            return wsi.extract((x, y), lv=lv, wh=(rw_, rh_), mode="array")
+
         with torch.cuda.device(extractor.device):
-            return self._ring.run(coords, self._read_tile(wsi),
-                                  lambda tiles, out: extractor.forward_device(tiles, out),
-                                  extractor.embedding_dim, read_chunk=getattr(wsi, "read_tiles_into", None))
+            return ring.run(coords, read,
+                            lambda tiles, out: extractor.forward_device(_to_patch_size(tiles, ps), out),
+                            extractor.embedding_dim, read_chunk=getattr(wsi, "read_tiles_into", None))
 
     def _embed_device_source(self, coords: np.ndarray, wsi: IWSI, extractor, batch: int):
         """Backends that can materialise tiles in HBM themselves (``extract_batch_device``, e.g. the synthetic
@@ -223,13 +253,14 @@ class PatchFeatureEmbeddingService(FeatureEmbeddingService):
         if source is None or os.environ.get("ATLASPATCH_HOST_TILES"):
             return None
         n = int(coords.shape[0])
+        ps = int(self.cfg.patch_size)
         out = torch.empty((n, extractor.embedding_dim), dtype=torch.float32, device=extractor.device)
         with torch.cuda.device(extractor.device):
             for lo in range(0, n, batch):
-                tiles = source(coords[lo:lo + batch], extractor.device, self.cfg.patch_size)
+                tiles = source(coords[lo:lo + batch], extractor.device, ps)
                 if tiles is None:
                     return None
-                extractor.forward_device(tiles, out[lo:lo + tiles.shape[0]])
+                extractor.forward_device(_to_patch_size(tiles, ps), out[lo:lo + tiles.shape[0]])
             return out.cpu().numpy()
 
     def embed_all(self, results: list[ExtractionResult], *, wsi_loader, progress=None) -> list[tuple]:

@@ -29,15 +29,20 @@ from .. import _lib
 
 class TileRing:
     def __init__(self, *, device: torch.device, batch: int, patch_size: int, slots: int = 3,
-                 workers: int = 4) -> None:
+                 workers: int = 4, tile_hw: tuple | None = None) -> None:
+        """``tile_hw`` = (read_h, read_w) of the tiles that cross the ring; defaults to the patch size.  Slides whose
+        level read differs from ``patch_size`` ship tiles at their READ size and are resized on the device
+        (the reference's per-tile ``cv2.resize``, feature_embedding.py:94-95), so the host does no resampling."""
         self.device = device
         self.batch = int(batch)
         self.ps = int(patch_size)
+        self.th, self.tw = (int(tile_hw[0]), int(tile_hw[1])) if tile_hw is not None else (self.ps, self.ps)
         self.slots = max(2, int(slots))
-        self.host = [torch.empty((self.batch, self.ps, self.ps, 3), dtype=torch.uint8).pin_memory()
+        self.host = [torch.empty((self.batch, self.th, self.tw, 3), dtype=torch.uint8).pin_memory()
                      for _ in range(self.slots)]
-        self.dev = [torch.empty((self.batch, self.ps, self.ps, 3), dtype=torch.uint8, device=device)
+        self.dev = [torch.empty((self.batch, self.th, self.tw, 3), dtype=torch.uint8, device=device)
                     for _ in range(self.slots)]
+        self._out_host = None
         self.copy_stream = torch.cuda.Stream(device=device)
         self.free_events: list[torch.cuda.Event | None] = [None] * self.slots
         self.workers = max(1, int(workers))
@@ -47,15 +52,17 @@ class TileRing:
     def run(self, coords: np.ndarray, read_tile: Callable[[int, int, int, int, int], np.ndarray],
             forward: Callable[[torch.Tensor, torch.Tensor], None], out_dim: int, *,
             read_chunk: Callable | None = None) -> np.ndarray:
-        """coords int32 [N, 5]; ``read_tile(x, y, rw, rh, lv)`` -> uint8 [ps, ps, 3];
-        ``forward(tiles_dev [n,ps,ps,3], out_dev [n,D])`` enqueues on the current stream.
-        ``read_chunk(rows, dst_ptr, patch_size) -> bool`` (optional): a backend's native batched decoder; when it
-        returns True the chunk's tiles are already in the pinned slot.  Returns float32 [N, D] (host)."""
+        """coords int32 [N, 5]; ``read_tile(x, y, rw, rh, lv)`` -> uint8 [th, tw, 3];
+        ``forward(tiles_dev [n,th,tw,3], out_dev [n,D])`` enqueues on the current stream.
+        ``read_chunk(rows, dst_ptr, tile_side) -> bool`` (optional): a backend's native batched decoder; when it
+        returns True the chunk's tiles are already in the pinned slot.  Returns float32 [N, D] (host; a fresh array)."""
         n_total = int(coords.shape[0])
-        out_host = torch.empty((n_total, out_dim), dtype=torch.float32).pin_memory() if n_total else \
-            torch.empty((0, out_dim), dtype=torch.float32)
         if n_total == 0:
-            return out_host.numpy()
+            return np.empty((0, out_dim), dtype=np.float32)
+        # grow-only pinned result buffer: re-pinning [N, D] for every slide costs more than the copy out of it
+        if self._out_host is None or self._out_host.shape[0] < n_total or self._out_host.shape[1] != out_dim:
+            self._out_host = torch.empty((max(n_total, self.batch), out_dim), dtype=torch.float32).pin_memory()
+        out_host = self._out_host
         out_dev = [torch.empty((self.batch, out_dim), dtype=torch.float32, device=self.device)
                    for _ in range(self.slots)]
         compute = torch.cuda.current_stream(self.device)
@@ -67,20 +74,22 @@ class TileRing:
             count = hi - lo
             chunk = max(1, -(-count // (4 * self.workers)))          # a few tasks per worker, not one per tile
             rows = coords[lo:hi].tolist()
-            tile_bytes = self.ps * self.ps * 3
+            tile_bytes = self.th * self.tw * 3
+            want_shape = (self.th, self.tw, 3)
 
             def some(start):
                 # decode the chunk, then ONE ap_host_gather_tiles call copies it into the pinned slot with the
                 # interpreter lock released (a NumPy slice assignment per tile would hold it for every 196 KB memcpy)
                 stop = min(count, start + chunk)
-                if read_chunk is not None and read_chunk(rows[start:stop], base + start * tile_bytes, self.ps):
+                if read_chunk is not None and self.th == self.tw and \
+                        read_chunk(rows[start:stop], base + start * tile_bytes, self.tw):
                     return
                 tiles = []
                 for i in range(start, stop):
                     x, y, rw, rh, lv = rows[i]
                     t = np.ascontiguousarray(read_tile(x, y, rw, rh, lv), dtype=np.uint8)
-                    if t.shape != (self.ps, self.ps, 3):
-                        raise ValueError(f"tile source returned shape {t.shape}, expected {(self.ps, self.ps, 3)}")
+                    if t.shape != want_shape:
+                        raise ValueError(f"tile source returned shape {t.shape}, expected {want_shape}")
                     tiles.append(t)
                 ptrs = (C.c_void_p * len(tiles))(*[t.ctypes.data for t in tiles])
                 _lib.check(self._lib.ap_host_gather_tiles(base + start * tile_bytes, ptrs, len(tiles), tile_bytes),
@@ -132,7 +141,7 @@ class TileRing:
             torch.cuda.synchronize(self.device)
             raise
         torch.cuda.synchronize(self.device)
-        return out_host.numpy()
+        return out_host[:n_total].numpy().copy()
 
     def close(self) -> None:
         self.pool.shutdown(wait=True)

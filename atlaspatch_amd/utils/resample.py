@@ -1,31 +1,56 @@
-"""Image resampling used outside the per-tile hot loop.
+"""Image resampling on the device: the two resamplers the reference's hot path calls.
 
-``resize_area_or_cubic`` stands in for the ``cv2.resize`` call of
-/root/reference/atlas_patch/core/wsi/iwsi.py:305-321 (INTER_AREA when shrinking, INTER_CUBIC when
-enlarging).  OpenCV is not available in this image: PARITY UNPINNED.  The exact-integer-ratio
-area average (what pyramid levels produce) is implemented exactly; other ratios use Pillow's
-BOX / BICUBIC filters, which differ from OpenCV's by rounding.  Synthetic slides and slides whose
-pyramid holds the 1.25x level never reach this function.
+``cv2_resize_device`` / ``cv2_resize_array`` = ``cv2.resize`` for uint8 RGB (``ap_cv2_resize_u8``: OpenCV's 8-bit
+arithmetic restated, see csrc/cv2resize.hip) -- the per-tile ``cv2.resize(patch, (ps, ps))`` of
+/root/reference/atlas_patch/services/feature_embedding.py:94-95 and services/extraction.py:112-113, and the thumbnail
+resize of core/wsi/iwsi.py:305-321 (INTER_AREA when shrinking, INTER_CUBIC when enlarging).  OpenCV is not
+available in this image: PARITY UNPINNED against cv2 itself, bit-exact against ``oracle/cv2_resize.py``.
+
+``DeviceResampler`` = ``PIL.Image.resize`` (bit-identical; Pillow is present) for the encoders' own transforms.
+There is no host fallback: without a HIP device these raise.
 """
 from __future__ import annotations
 
 import numpy as np
-from PIL import Image
+
+INTER_LINEAR, INTER_CUBIC, INTER_AREA = 1, 2, 3      # cv2's constants (= AP_CV_INTER_*)
 
 
-def resize_area_or_cubic(arr: np.ndarray, size_wh, interpolation: str = "optimise") -> np.ndarray:
-    out_w, out_h = int(size_wh[0]), int(size_wh[1])
-    h, w = arr.shape[:2]
-    shrink = out_w < w or out_h < h
-    if interpolation == "linear":
-        return np.asarray(Image.fromarray(arr).resize((out_w, out_h), Image.Resampling.BILINEAR))
-    if (interpolation in ("optimise", "area")) and shrink:
-        if w % out_w == 0 and h % out_h == 0:
-            fx, fy = w // out_w, h // out_h
-            acc = arr.reshape(out_h, fy, out_w, fx, -1).astype(np.float64).mean(axis=(1, 3))
-            return np.clip(np.rint(acc), 0, 255).astype(np.uint8).reshape(out_h, out_w, *arr.shape[2:])
-        return np.asarray(Image.fromarray(arr).resize((out_w, out_h), Image.Resampling.BOX))
-    return np.asarray(Image.fromarray(arr).resize((out_w, out_h), Image.Resampling.BICUBIC))
+def thumbnail_interpolation(in_hw, out_wh, policy: str = "optimise") -> int:
+    """The interpolation iwsi.py:305-319 picks: "optimise" = AREA when either axis shrinks, else CUBIC."""
+    h, w = int(in_hw[0]), int(in_hw[1])
+    out_w, out_h = int(out_wh[0]), int(out_wh[1])
+    if policy == "optimise":
+        return INTER_AREA if (out_w < w or out_h < h) else INTER_CUBIC
+    return {"area": INTER_AREA, "cubic": INTER_CUBIC, "linear": INTER_LINEAR}.get(policy, INTER_LINEAR)
+
+
+def cv2_resize_device(tiles, out_wh, interpolation: int = INTER_LINEAR, *, out=None, flags: int = 0):
+    """``cv2.resize(tile, (out_w, out_h), interpolation=...)`` on a device batch: uint8 [n, h, w, 3] -> [n, oh, ow, 3]."""
+    import torch
+    from .. import _lib
+    assert tiles.is_cuda and tiles.dtype == torch.uint8 and tiles.dim() == 4 and tiles.shape[3] == 3 and tiles.is_contiguous()
+    n, h, w = int(tiles.shape[0]), int(tiles.shape[1]), int(tiles.shape[2])
+    ow, oh = int(out_wh[0]), int(out_wh[1])
+    if out is None:
+        out = torch.empty((n, oh, ow, 3), dtype=torch.uint8, device=tiles.device)
+    assert out.is_cuda and out.is_contiguous() and tuple(out.shape) == (n, oh, ow, 3)
+    with torch.cuda.device(tiles.device):
+        _lib.check(_lib.load().ap_cv2_resize_u8(tiles.data_ptr(), n, h, w, out.data_ptr(), oh, ow, int(interpolation),
+                                                int(flags), _lib.current_stream_ptr(tiles.device)), "ap_cv2_resize_u8")
+    return out
+
+
+def cv2_resize_array(arr: np.ndarray, out_wh, interpolation: int = INTER_LINEAR, *, device=None) -> np.ndarray:
+    """Host uint8 [h, w, 3] -> host uint8 [oh, ow, 3] through the device kernel (thumbnails, single tiles)."""
+    import torch
+    from .. import _lib
+    if not torch.cuda.is_available():
+        raise _lib.HipLibraryError("cv2-exact resize runs on the HIP device; no HIP device is available "
+                                   "(there is no CPU fallback)")
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    src = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.uint8)).to(dev)
+    return cv2_resize_device(src[None], out_wh, interpolation)[0].cpu().numpy()
 
 
 # ----------------------------------------------------------------------------- Pillow resampling tables

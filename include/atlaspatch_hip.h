@@ -74,6 +74,13 @@ int ap_host_gather_tiles(void* dst, const void* const* src, int n, size_t bytes_
  * format takes (the reference's per-tile Python read, services/feature_embedding.py:86-95, cannot leave the interpreter). */
 int ap_host_inflate_tiles(void* dst, const char* const* paths, int n, size_t bytes_each);
 
+/* Host twin of ap_synth_tiles (below): renders n square tiles of a synthetic slide into consecutive slots of a pinned
+ * staging buffer, outside the interpreter lock -- the synthetic slide's "native decoder" behind the ring's batched read
+ * hook, so the host -> ring -> HBM path can be driven at full rate on the 100 000 x 100 000 slide.  xy: HOST int32 [n, 2]
+ * level-0 corners; ellipses: HOST int64 [k, 4].  Bit-identical to core/wsi/synth_pixels.py::render_region. */
+int ap_host_synth_tiles(void* dst, const int32_t* xy, int n, int side, int level_ds, int level,
+                        int64_t width, int64_t height, uint32_t seed, const int64_t* ellipses, int k);
+
 /* ---- Pillow-exact tile resampling ------------------------------------------------------
  * Replaces the PIL resize inside the per-item transform of encoders whose transform starts with Resize:
  * timm's Resize(224, bicubic) for uni_v1 (models/patch/uni.py:48-49) and open_clip's Resize(448, bicubic)
@@ -86,6 +93,25 @@ int ap_resample_u8(const uint8_t* src, int n, int h, int w, uint8_t* dst, int oh
                    const int32_t* bounds_x, const int32_t* coeffs_x, int ksize_x,
                    const int32_t* bounds_y, const int32_t* coeffs_y, int ksize_y,
                    uint8_t* tmp, ap_stream_t stream);
+
+/* ---- cv2.resize for uint8 RGB ----------------------------------------------------------
+ * Replaces the host cv2.resize calls of the path: services/feature_embedding.py:94-95 and
+ * services/extraction.py:112-113 (cv2.resize(patch, (ps, ps)), INTER_LINEAR, on every tile whose level read is
+ * not patch_size) and core/wsi/iwsi.py:305-321 (the 1.25x thumbnail: INTER_AREA when shrinking, INTER_CUBIC when
+ * enlarging, INTER_LINEAR on request).  OpenCV's 8-bit arithmetic restated: integer-ratio area averages
+ * (2 x 2 -> (sum + 2) >> 2, which INTER_LINEAR at exactly 2 x 2 is re-routed to), float32 area cells for other
+ * shrink ratios, 11-bit fixed-point bilinear / bicubic (A = -0.75) with OpenCV's two-stage rounding; dsize equal
+ * to the source size is a copy.  Per-axis tables are built by the library on first use of a shape (one
+ * synchronous upload), then cached.
+ * src: device uint8 [n, h, w, 3] -> dst: device uint8 [n, oh, ow, 3].  interpolation: cv2's constants.
+ * flags: AP_CV_CUBIC_SCALAR = bicubic vertical pass in int32 for every element (OpenCV's scalar code); default =
+ * what an x86-64 build executes (float32 vector loop for all but the last (ow * 3) % 8 elements of a row). */
+#define AP_CV_INTER_LINEAR 1
+#define AP_CV_INTER_CUBIC 2
+#define AP_CV_INTER_AREA 3
+#define AP_CV_CUBIC_SCALAR 1
+int ap_cv2_resize_u8(const uint8_t* src, int n, int h, int w, uint8_t* dst, int oh, int ow,
+                     int interpolation, int flags, ap_stream_t stream);
 
 /* ---- tile content statistics (--no-fast-mode filters) -------------------------------
  * Replaces utils/image.py:7-41 (is_black_patch / is_white_patch), which services/extraction.py:112-116

@@ -457,9 +457,68 @@ def gen_features_h5(out_dir):
         print(f"  features_h5: N={coords.shape[0]} feats {feats.shape}")
 
 
+def gen_openslide_props(out_dir):
+    """G8: MPP / magnification lookup of the reference's OpenSlide backend (core/wsi/openslide_wsi.py:71-147) on
+    fake property dicts.  ``openslide`` is not installed: a stub module supplies the two property-name constants and
+    an exception type, and ``_extract_mpp`` / ``_extract_mag`` run unmodified on an object whose ``meta`` is the dict."""
+    import importlib
+    import types
+    stub = types.ModuleType("openslide")
+    stub.PROPERTY_NAME_MPP_X = "openslide.mpp-x"
+    stub.PROPERTY_NAME_OBJECTIVE_POWER = "openslide.objective-power"
+    stub.OpenSlide = object
+    stub.OpenSlideError = type("OpenSlideError", (Exception,), {})
+    sys.modules["openslide"] = stub
+    mod = importlib.import_module("atlas_patch.core.wsi.openslide_wsi")
+    cases = [
+        {},
+        {"openslide.mpp-x": "0.2528"},
+        {"openslide.mpp-x": "0.499", "openslide.objective-power": "20"},
+        {"openslide.mpp-y": "0.2611", "aperio.MPP": "0.2500"},
+        {"openslide.mirax.MPP": "0.23", "aperio.MPP": "0.5"},
+        {"aperio.MPP": "0.25210", "aperio.AppMag": "40"},
+        {"hamamatsu.XResolution": "0.44"},
+        {"openslide.mpp-x": "garbage", "aperio.MPP": "0.3456789"},
+        {"openslide.mpp-x": "garbage"},
+        {"openslide.comment": "Aperio Image Library v12 |AppMag = 20|MPP = 0.4990|Left = 25"},
+        {"tiff.ImageDescription": "scanner X, 0.2456 microns per pixel approx"},
+        {"openslide.comment": "microns per pixel: 0.5021; mpp: 0.25"},
+        {"openslide.comment": "mpp=.", "tiff.ImageDescription": "Micron per pixel = 1.0"},
+        {"tiff.XResolution": "40000", "tiff.ResolutionUnit": "centimeter"},
+        {"tiff.XResolution": "101600.5", "tiff.ResolutionUnit": "Inch"},
+        {"tiff.XResolution": "abc", "tiff.ResolutionUnit": "inch", "aperio.AppMag": "20"},
+        {"tiff.XResolution": "40000", "tiff.ResolutionUnit": "furlong", "openslide.objective-power": "40"},
+        {"aperio.AppMag": "40"},
+        {"aperio.AppMag": "0", "openslide.objective-power": "20"},
+        {"openslide.objective-power": "20.0"},
+        {"hamamatsu.SourceLens": "40"},
+        {"aperio.AppMag": "x", "hamamatsu.SourceLens": "20"},
+        {"openslide.objective-power": "n/a", "openslide.mpp-x": "0.25"},
+        {"openslide.objective-power": "", "aperio.MPP": "0.17"},
+        {"openslide.mpp-x": "0.12"},
+        {"openslide.mpp-x": "1.9"},
+        {"openslide.mpp-x": "3.0"},
+        {"mirax.DICOM.PIXEL_SPACING": "0.23"},
+    ]
+    rows = []
+    for meta in cases:
+        obj = mod.OpenSlideWSI.__new__(mod.OpenSlideWSI)
+        obj._oslide = object()
+        obj.meta = dict(meta)
+        mpp = obj._extract_mpp()
+        obj.mpp = mpp
+        rows.append({"meta": meta, "mpp": mpp, "mag": obj._extract_mag()})
+    with open(out_dir / "openslide_props.json", "w") as fh:
+        json.dump({"keys": {"mpp": list(mod.OpenSlideWSI._MPP_KEYS), "text": list(mod.OpenSlideWSI._MPP_TEXT_KEYS),
+                            "mag": list(mod.OpenSlideWSI._MAG_KEYS)}, "cases": rows}, fh, indent=1)
+    print(f"  openslide_props: {len(rows)} cases")
+
+
 if __name__ == "__main__":
     out_dir = HERE
-    which = set(sys.argv[1:]) or {"geometry", "scale", "coords", "config", "extract", "features"}
+    which = set(sys.argv[1:]) or {"geometry", "scale", "coords", "config", "extract", "features", "openslide"}
+    if "openslide" in which:
+        gen_openslide_props(out_dir)
     if "geometry" in which:
         gen_geometry(out_dir)
     if "scale" in which:

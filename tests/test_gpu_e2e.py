@@ -290,3 +290,68 @@ def _mpp_csv(folder, name, mpp):
     p = folder / "mpp.csv"
     p.write_text(f"wsi,mpp\n{name},{mpp}\n")
     return p
+
+
+@pytest.mark.parametrize("host_tiles", [False, True])
+def test_cli_process_mag40_slide_resizes_tiles_on_device(tmp_path, monkeypatch, host_tiles):
+    """A 40x slide at --target-mag 20 with levels 1/4/16 (the common scanner case): every tile is READ 512 x 512 at
+    level 0 and the reference shrinks it with cv2.resize(patch, (256, 256)) (feature_embedding.py:94-95).  Here the
+    tiles cross the ring (or come from the device tile source) at their read size and ap_cv2_resize_u8 shrinks them on
+    the device; features equal the oracle chain render -> oracle cv2.resize -> fp32 ViT."""
+    from click.testing import CliRunner
+    from atlaspatch_amd.cli import cli
+    from atlaspatch_amd.core.wsi.synth_pixels import SynthSpec, analytic_mask, render_region
+    from atlaspatch_amd.encoders.vit import ARCHS, random_canonical_state_dict
+    from atlaspatch_amd.utils.h5 import h5
+    from oracle import coords_oracle, cv2_resize, vit_oracle
+
+    monkeypatch.setenv("ATLASPATCH_RANDOM_INIT", "0")
+    if host_tiles:
+        monkeypatch.setenv("ATLASPATCH_HOST_TILES", "1")
+    slide, raw = _make_slide(str(tmp_path), "m40.synth", mag=40, mpp=0.25, width=14000, height=10000)
+    out = tmp_path / "out"
+    res = CliRunner().invoke(cli, ["process", slide, "-o", str(out), "--patch-size", "256", "--target-mag", "20",
+                                   "--feature-extractors", "vit_b_16", "--feature-precision", "float32",
+                                   "--feature-num-workers", "4"], catch_exceptions=False)
+    assert res.exit_code == 0 and "failures: 0" in res.output, res.output
+    spec = SynthSpec(width=raw["width"], height=raw["height"], seed=raw["seed"], mag=40, mpp=0.25)
+    want_coords, _ = coords_oracle.coords_from_mask(
+        analytic_mask(spec), level0_wh=(spec.width, spec.height), downsamples=[1.0, 4.0, 16.0], src_mag=40,
+        tgt_mag=20, patch_size=256, step_size=None, tissue_thresh=0.0)
+    with h5.File(out / "patches" / "m40.h5", "r") as f:
+        coords = f["coords"][:]
+        feats = f["features"]["vit_b_16"][:]
+        assert f.attrs["patch_size_level0"] == 512
+    assert np.array_equal(coords, want_coords) and coords.shape[0] > 20
+    assert (coords[:, 2] == 512).all() and (coords[:, 3] == 512).all() and (coords[:, 4] == 0).all()
+    rows = np.linspace(0, coords.shape[0] - 1, 10).astype(int)
+    tiles = [cv2_resize.resize(render_region(spec, int(coords[r, 0]), int(coords[r, 1]), 512, 512, 0), (256, 256))
+             for r in rows]
+    sd = helpers.canonical_to_hf(random_canonical_state_dict(ARCHS["vit_b_16"], 0), 12)
+    want = vit_oracle.extract_batch(sd, tiles, heads=12)
+    rel = np.linalg.norm(feats[rows] - want) / np.linalg.norm(want)
+    assert rel <= 1e-3, rel
+
+
+def test_no_fast_mode_and_save_images_on_a_mag40_slide(tmp_path):
+    """--no-fast-mode / --save-images on a slide whose tiles need cv2.resize (extraction.py:105-128): saved PNGs are the
+    oracle-resized tiles, and the content filters see the resized pixels."""
+    from click.testing import CliRunner
+    from PIL import Image
+    from atlaspatch_amd.cli import cli
+    from atlaspatch_amd.core.wsi.synth_pixels import SynthSpec, render_region
+    from atlaspatch_amd.utils.h5 import h5
+    from oracle import cv2_resize
+    slide, raw = _make_slide(str(tmp_path), "f40.synth", mag=40, mpp=0.25, width=9000, height=7000)
+    out = tmp_path / "out"
+    res = CliRunner().invoke(cli, ["segment-and-get-coords", slide, "-o", str(out), "--patch-size", "256", "--target-mag",
+                                   "20", "--no-fast-mode", "--save-images"], catch_exceptions=False)
+    assert res.exit_code == 0 and "failures: 0" in res.output, res.output
+    with h5.File(out / "patches" / "f40.h5", "r") as f:
+        coords = f["coords"][:]
+    assert coords.shape[0] > 5
+    spec = SynthSpec(width=raw["width"], height=raw["height"], seed=raw["seed"], mag=40, mpp=0.25)
+    for r in (0, coords.shape[0] // 2, coords.shape[0] - 1):
+        x, y = int(coords[r, 0]), int(coords[r, 1])
+        png = np.asarray(Image.open(out / "images" / "f40" / f"f40_x{x}_y{y}.png"))
+        assert np.array_equal(png, cv2_resize.resize(render_region(spec, x, y, 512, 512, 0), (256, 256)))

@@ -207,3 +207,65 @@ def test_tile_content_counts_bit_exact_vs_cv2_restatement(env):
     assert [bool(cv2r.is_black_patch(t, rgb_thresh=50)) for t in tiles] == black.tolist()
     assert [bool(cv2r.is_white_patch(t, sat_thresh=15)) for t in tiles] == white.tolist()
     assert black[1] and white[2] and white[6] and not white[7]
+
+
+# ----------------------------------------------------------------------------- cv2.resize on the device
+_CV2_CASES = [
+    # (h, w) -> (oh, ow), interpolation, n
+    ((512, 512), (256, 256), 1, 5),        # the 40x -> 20x tile: INTER_LINEAR at exactly 2 x 2 = 2 x 2 area average
+    ((1024, 1024), (256, 256), 1, 3),      # 80x-ish read: plain non-antialiased bilinear
+    ((300, 300), (256, 256), 1, 4), ((180, 200), (256, 256), 1, 4), ((511, 513), (256, 256), 1, 2),
+    ((256, 256), (256, 256), 1, 2),        # dsize == ssize: copy
+    ((768, 768), (256, 256), 3, 2), ((96, 64), (32, 16), 3, 3),                       # integer-ratio area (3x3, 3x4)
+    ((411, 300), (100, 128), 3, 2), ((733, 1024), (699, 500), 3, 1), ((100, 100), (77, 33), 3, 3),   # general area
+    ((100, 80), (200, 256), 3, 2),         # area when enlarging = bilinear with area-mode coordinates
+    ((40, 60), (80, 30), 3, 2),            # one axis up, one down
+    ((100, 80), (200, 256), 2, 2), ((300, 300), (256, 256), 2, 2), ((60, 75), (163, 201), 2, 2),   # cubic
+    ((6250 // 4, 6250 // 4), (3125 // 4, 3125 // 4), 3, 1),    # thumbnail-shaped 2 x 2 area
+]
+
+
+@pytest.mark.parametrize("in_hw,out_hw,interp,n", _CV2_CASES)
+def test_cv2_resize_device_equals_oracle_bit_for_bit(env, in_hw, out_hw, interp, n):
+    """ap_cv2_resize_u8 == oracle/cv2_resize.py (OpenCV's 8-bit resize restated; parity unpinned against cv2 itself)
+    for every mode the reference's path can take: feature_embedding.py:94-95 (INTER_LINEAR on tiles), iwsi.py:305-321
+    (INTER_AREA / INTER_CUBIC thumbnails)."""
+    from atlaspatch_amd.utils.resample import cv2_resize_device
+    from oracle import cv2_resize as R
+    _lib, lib, dev, stream = env
+    rng = np.random.default_rng(in_hw[0] * 7 + out_hw[1] + interp)
+    tiles = rng.integers(0, 256, (n, in_hw[0], in_hw[1], 3), dtype=np.uint8)
+    got = cv2_resize_device(torch.from_numpy(tiles).to(dev), (out_hw[1], out_hw[0]), interp).cpu().numpy()
+    for i in range(n):
+        want = R.resize(tiles[i], (out_hw[1], out_hw[0]), interp)
+        assert np.array_equal(got[i], want), (i, np.abs(got[i].astype(int) - want).max(), (got[i] != want).sum())
+    if interp == 2:                          # OpenCV's scalar vertical pass, selectable
+        got = cv2_resize_device(torch.from_numpy(tiles).to(dev), (out_hw[1], out_hw[0]), interp, flags=1).cpu().numpy()
+        for i in range(n):
+            assert np.array_equal(got[i], R.resize(tiles[i], (out_hw[1], out_hw[0]), interp, cubic_vertical="scalar"))
+
+
+def test_thumbnail_at_power_resizes_on_device_like_the_oracle(tmp_path):
+    """IWSI.get_thumbnail_at_power (iwsi.py:246-323) on a 40x synthetic slide with levels 1/4/16: level 2 is read in full
+    and shrunk 2 x with INTER_AREA; on a single-level slide the level-0 image is shrunk by a non-integer factor."""
+    import json
+    from atlaspatch_amd.core.wsi.synth_wsi import SynthWSI
+    from atlaspatch_amd.core.wsi.synth_pixels import SynthSpec, render_region
+    from oracle import cv2_resize as R
+    p = tmp_path / "t.synth"
+    json.dump({"width": 16000, "height": 11200, "seed": 5, "mag": 40, "mpp": 0.25, "downsamples": [1, 4, 16]}, open(p, "w"))
+    wsi = SynthWSI(str(p))
+    thumb = np.asarray(wsi.get_thumbnail_at_power(power=1.25))
+    spec = SynthSpec(width=16000, height=11200, seed=5, mag=40, mpp=0.25)
+    level = render_region(spec, 0, 0, 1000, 700, 2)
+    assert thumb.shape == (350, 500, 3)
+    assert np.array_equal(thumb, R.resize(level, (500, 350), R.INTER_AREA))
+    p2 = tmp_path / "u.synth"
+    json.dump({"width": 3000, "height": 2100, "seed": 6, "mag": 5, "mpp": 2.0, "downsamples": [1]}, open(p2, "w"))
+    wsi2 = SynthWSI(str(p2))
+    thumb2 = np.asarray(wsi2.get_thumbnail_at_power(power=1.3))            # ds 3.846...: general area table
+    spec2 = SynthSpec(width=3000, height=2100, seed=6, mag=5, mpp=2.0, downsamples=(1.0,))
+    full = render_region(spec2, 0, 0, 3000, 2100, 0)
+    ds = 5 / 1.3
+    want = R.resize(full, (int(round(3000 / ds)), int(round(2100 / ds))), R.INTER_AREA)
+    assert np.array_equal(thumb2, want)

@@ -82,10 +82,26 @@ def _hf_extractor(layers, dtype, **kw):
     return ex, sd
 
 
-# tolerance: features vs the CPU fp32 path, norm-wise relative error
-#   float32 : BASELINE north_star tolerance 1e-3 (exact-f32 MFMA lands ~1e-6)
-#   float16 / bfloat16 : operand rounding 2^-11 / 2^-8 per GEMM input, f32 accumulation
-TOL = {torch.float32: 1e-3, torch.float16: 5e-3, torch.bfloat16: 3e-2}
+# tolerance: features vs the CPU fp32 path.  Two statistics:
+#   norm-wise    ||a - b||_F / ||b||_F                       (TOL)
+#   element-wise max_ij |a_ij - b_ij| / (|b_ij| + 0.05 max|b|)    (ETOL; elements below 5 % of the feature scale are
+#                                                             compared on that absolute scale)
+#   float32 : BASELINE north_star tolerance 1e-3 on BOTH (exact-f32 MFMA measures ~1e-6 / ~1e-5)
+#   float16 : set from what is measured at full depth (norm-wise 0.9e-3 ViT-B/16) with 1.7 x
+#             headroom; bfloat16 has 8 x coarser operands
+TOL = {torch.float32: 1e-3, torch.float16: 1.5e-3, torch.bfloat16: 1.2e-2}
+ETOL = {torch.float32: 1e-3, torch.float16: 1.5e-2, torch.bfloat16: 1.2e-1}
+
+
+def _elem(a, b, floor=0.05):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float((np.abs(a - b) / (np.abs(b) + floor * np.abs(b).max())).max())
+
+
+def _check(got, want, dtype, what=""):
+    r, e = _rel(got, want), _elem(got, want)
+    print(f"PARITY {what} {str(dtype).split('.')[-1]}: norm-wise {r:.3e} element-wise {e:.3e}")
+    assert r <= TOL[dtype] and e <= ETOL[dtype], (what, dtype, r, e)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
@@ -100,8 +116,7 @@ def test_extract_batch_matches_reference_golden(dtype, golden_dir):
         out = ex.extract_batch(patches[n], batch_size=32)
         assert out.dtype == np.float32 and out.shape == (n, 768) and out.flags.c_contiguous
         if n:
-            err = _rel(out, g[f"L2_n{n}_out"])
-            assert err <= TOL[dtype], (n, dtype, err)
+            _check(out, g[f"L2_n{n}_out"], dtype, f"G1 L2 n={n}")
     ex.cleanup()
 
 
@@ -113,15 +128,72 @@ def test_vit_b16_full_depth_vs_golden_and_oracle(dtype, golden_dir):
     ex, sd = _hf_extractor(12, dtype)
     patches = helpers.golden_patches((5,))[5]
     out = ex.extract_batch(patches, batch_size=32)
-    assert _rel(out, g["L12_n5_out"]) <= TOL[dtype]
+    _check(out, g["L12_n5_out"], dtype, "vit_b_16 L12 vs reference golden")
     rng = np.random.default_rng(11)
     more = [rng.integers(0, 256, (256, 256, 3), dtype=np.uint8) for _ in range(19)]
     want = vit_oracle.extract_batch(sd, more, heads=12, batch_size=32)
     got = ex.extract_batch(more, batch_size=7)        # chunking must not matter
-    assert _rel(got, want) <= TOL[dtype]
-    if dtype == torch.float32:
-        assert np.abs(got - want).max() <= 1e-3 * max(1.0, np.abs(want).max())
+    _check(got, want, dtype, "vit_b_16 L12 vs oracle")
     ex.cleanup()
+
+
+# ----------------------------------------------------------------------------- BASELINE configs 3 / 5 at their real depth
+def _pil_resized(tiles, size, filt):
+    from PIL import Image
+    pf = {"bicubic": Image.Resampling.BICUBIC, "bilinear": Image.Resampling.BILINEAR}[filt]
+    return np.stack([np.asarray(Image.fromarray(t).resize((size, size), pf)) for t in tiles], 0)
+
+
+@pytest.mark.parametrize("name,dtype", [("uni_v1", torch.float16), ("uni_v1", torch.float32), ("vit_l_16", torch.float16)])
+def test_vit_l_full_depth_vs_fp32_oracle(name, dtype):
+    """Config 3's encoder at its real size: 24 blocks, D = 1024, 16 heads; uni_v1 with LayerScale (gamma drawn in
+    [0.2, 0.7] so both residual branches matter) behind timm's Resize(224, bicubic); vit_l_16 behind torchvision's
+    ImageClassification(crop 224, resize 242) -- against the fp32 CPU restatement on 8 tiles."""
+    from atlaspatch_amd.encoders.vit import ARCHS, TRANSFORM_RESIZE, build_hip_vit_extractor, random_canonical_state_dict
+    from oracle import vit_oracle
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    arch = dict(ARCHS[name])
+    sd = random_canonical_state_dict(arch, seed=21)
+    g = torch.Generator().manual_seed(22)
+    if arch.get("layer_scale"):
+        for i in range(arch["depth"]):
+            sd[f"blocks.{i}.ls1"] = torch.rand(1024, generator=g) * 0.5 + 0.2
+            sd[f"blocks.{i}.ls2"] = torch.rand(1024, generator=g) * 0.5 + 0.2
+    size, filt = TRANSFORM_RESIZE[name]
+    ex = build_hip_vit_extractor(name=name, arch=arch, state_dict=sd, source="canonical", device=_dev(), dtype=dtype,
+                                 resize=(size, filt), expect_size=None)
+    rng = np.random.default_rng(23)
+    tiles = [rng.integers(0, 256, (256, 256, 3), dtype=np.uint8) for _ in range(8)]
+    got = ex.extract_batch(tiles, batch_size=32)
+    ex.cleanup()
+    x = vit_oracle.preprocess_center_crop(_pil_resized(tiles, size, filt), crop=224)
+    want = vit_oracle.vit_tokens_canonical(sd, x, heads=16, depth=24)[:, 0].numpy()
+    assert got.shape == (8, 1024)
+    _check(got, want, dtype, f"{name} L24")
+
+
+def test_conch_v1_full_depth_f16_vs_fp32_oracle():
+    """Config 5's encoder at its real size: 12-block ViT-B/16 trunk on 448-px input (785 tokens) + attentional pooler,
+    float16, against the fp32 CPU restatement on 8 tiles (parity unpinned against the absent conch package)."""
+    from atlaspatch_amd.encoders.vit import (ARCHS, OPENAI_CLIP_MEAN, OPENAI_CLIP_STD, TRANSFORM_RESIZE, attn_pool_canonical,
+                                             build_hip_vit_extractor, random_attn_pool, random_canonical_state_dict)
+    from oracle import vit_oracle
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    arch = dict(ARCHS["conch_v1"])
+    trunk_arch = {k: v for k, v in arch.items() if not k.startswith("pool")}
+    trunk = random_canonical_state_dict(trunk_arch, seed=31)
+    pool = random_attn_pool(arch, seed=31)
+    state = dict(trunk); state.update(attn_pool_canonical(pool))
+    rng = np.random.default_rng(32)
+    tiles = [rng.integers(0, 256, (256, 256, 3), dtype=np.uint8) for _ in range(8)]
+    ex = build_hip_vit_extractor(name="conch_v1", arch=arch, state_dict=state, source="canonical", device=_dev(),
+                                 dtype=torch.float16, mean=OPENAI_CLIP_MEAN, std=OPENAI_CLIP_STD,
+                                 resize=TRANSFORM_RESIZE["conch_v1"], expect_size=None)
+    got = ex.extract_batch(tiles, batch_size=32)
+    ex.cleanup()
+    want = vit_oracle.conch_encode_image(trunk, pool, tiles, heads=12, depth=12, pool_heads=8)
+    assert got.shape == (8, 512)
+    _check(got, want, torch.float16, "conch_v1 L12 @448")
 
 
 def test_vit_layer_scale_uni_shape():
@@ -435,7 +507,7 @@ def test_vit_b16_other_tile_sizes_resize_like_torchvision_on_pil():
 
 
 # ----------------------------------------------------------------------------- CONCH v1 (a16)
-@pytest.mark.parametrize("dtype,tol", [(torch.float16, 5e-3), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 1.5e-3), (torch.bfloat16, 1.2e-2)])
 def test_conch_visual_tower_vs_oracle(dtype, tol):
     """ViT-B/16 trunk at 448 px (785 tokens: the tiled attention kernel) + one-query attentional pooler + LN,
     against the torch fp32 restatement whose pooler attention is torch's own multi_head_attention_forward.

@@ -257,7 +257,7 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/atlaspatch_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert _lib.load().ap_abi_version() == 8
+    assert _lib.load().ap_abi_version() == 9
 
 
 def test_product_has_no_cpu_fallback():
@@ -369,3 +369,29 @@ def test_native_batched_decode_of_the_deflate_tile_store(tmp_path):
         assert np.array_equal(wsi.extract(key, 0, (256, 256)), tiles[key])          # the per-tile path reads the same store
     assert wsi.read_tiles_into(rows + [[0, 0, 256, 256, 0]], dst.ctypes.data, 256) is False
     assert wsi.read_tiles_into([[0, 512, 512, 512, 0]], dst.ctypes.data, 256) is False
+
+
+# ----------------------------------------------------------------------------- OpenSlide property lookup (golden G8)
+def test_openslide_mpp_and_mag_lookup_matches_reference_golden(golden_dir):
+    """mpp_from_properties / mag_from_properties == the reference's OpenSlideWSI._extract_mpp / _extract_mag
+    (core/wsi/openslide_wsi.py:71-147) on 28 fake property dicts (fixture produced by running the reference's methods,
+    tests/golden/gen_golden.py::gen_openslide_props), and the key tables keep the reference's order."""
+    import json
+    from atlaspatch_amd.core.wsi import openslide_wsi as o
+    from atlaspatch_amd.core.wsi.iwsi import IWSI
+    with open(os.path.join(golden_dir, "openslide_props.json")) as fh:
+        g = json.load(fh)
+    assert list(o._MPP_KEYS) == g["keys"]["mpp"] and list(o._MAG_KEYS) == g["keys"]["mag"]
+    assert list(o._MPP_TEXT_KEYS) == g["keys"]["text"]
+    for case in g["cases"]:
+        mpp = o.mpp_from_properties(case["meta"])
+        mag = o.mag_from_properties(case["meta"], mpp, lambda m: IWSI._infer_mag(None, m))
+        assert mpp == case["mpp"] and mag == case["mag"], case
+
+
+def test_transform_resize_table():
+    """vit_l_16 resolves torchvision's ViT_L_16_Weights.IMAGENET1K_V1 = ImageClassification(crop 224, resize 242):
+    256-px tiles are resampled; vit_b_16 keeps resize 256 (pure centre crop)."""
+    from atlaspatch_amd.encoders.vit import TRANSFORM_RESIZE
+    assert TRANSFORM_RESIZE["vit_b_16"] == (256, "bilinear") and TRANSFORM_RESIZE["vit_l_16"] == (242, "bilinear")
+    assert TRANSFORM_RESIZE["uni_v1"] == (224, "bicubic") and TRANSFORM_RESIZE["conch_v1"] == (448, "bicubic")

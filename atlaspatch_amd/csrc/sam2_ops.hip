@@ -4,20 +4,20 @@
 // them through the C ABI; every tensor is channels-last ([tokens, C]).
 //
 //   ap_sgemm            out = act(alpha * A W^T + bias) + resid, batched with strides; W either [N, K] ("NT",
-//                       nn.Linear / 1x1 conv layout) or [K, N] ("NN", for P V).  64 x 64 tile, 16-deep K step
-//                       through LDS, 4 x 4 outputs per thread, fully bounds-checked.
+//                       nn.Linear / 1x1 conv layout) or [K, N] ("NN", for P V).  Exact-f32 MFMA
+//                       (v_mfma_f32_32x32x2_f32), 128 x 128 or 64 x 64 tile, 16-deep K tiles, fully bounds-checked.
 //   ap_softmax_rows     in-place row softmax (one wave per row)
 //   ap_sam2_patchify    uint8 HWC image -> ImageNet normalise -> im2col rows of the 7x7 stride-4 pad-3 patch embed
 //   ap_window_partition / ap_window_unpartition   (zero padded, hieradet.py window_partition semantics)
 //   ap_maxpool2x2       2x2 / stride 2 max pool on [B, H, W, C] with an input row stride (q pooling, shortcut)
 //   ap_add / ap_add_rowvec / ap_gelu / ap_upsample2x_add / ap_convt2x2_shuffle / ap_bilinear_up4_threshold
+#include <algorithm>
+#include <map>
+#include <mutex>
 #include "ap_common.h"
 
 namespace ap {
 namespace {
-
-constexpr int kGT = 64;     // GEMM tile
-constexpr int kGK = 16;
 
 __device__ __forceinline__ float act_apply(float v, int act) {
     if (act == 1) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
@@ -33,82 +33,172 @@ struct SgemmArgs {
     const float* bias; int act;
     const float* resid; long ldr, sR;
     float* out; long ldo, sO;
+    int vec;                 // operands allow 16-byte loads (alignment and K / N multiples checked by the host)
+    int splits, k_chunk;     // split-K: blockIdx.z = batch * splits + s works on k in [s * k_chunk, (s + 1) * k_chunk)
+    float* partial;          //   and stores its raw accumulators to partial[blockIdx.z][M][N] (reduced by splitk_reduce_kernel)
 };
 
-__global__ __launch_bounds__(256) void sgemm_kernel(SgemmArgs g) {
-    __shared__ float As[kGK][kGT + 4];
-    __shared__ float Ws[kGK][kGT + 4];
-    const int b = blockIdx.z;
+// Exact-f32 MFMA GEMM (v_mfma_f32_32x32x2_f32), any M / N / K, batched, NT or NN.
+//   T x T output tile per 256-thread workgroup (T = 128: 2 x 2 waves of 64 x 64 = four 32 x 32 MFMA blocks each;
+//   T = 64: one block per wave for the small batched attention products), 16-deep K tiles.
+//   Global -> registers (float4 per thread, next K tile in flight under the MFMAs) -> LDS (two buffers, one barrier per
+//   K tile).  LDS rows hold [row][16 k] padded to 20 floats: a lane reads its 8 k values with two ds_read_b128 and rows
+//   80 B apart spread over all 32 banks.  The MFMA's two k slots are fed k = e and k = 8 + e (lane halves), the same
+//   mapping on both operands, so the sum runs over all 16 k of the tile.  The NN weight ([k][n], P V products) keeps its
+//   [k][n] layout in LDS and is read with 8 conflict-free ds_read_b32.
+//   D[i = m][j = n]: a lane owns column n = lane % 32 and 16 rows -> stores / residual reads are 128-byte row segments.
+template <int T, bool WKN>
+__global__ __launch_bounds__(256) void sgemm_mfma_kernel(SgemmArgs g) {
+    constexpr int BLK = T / 64, LDR = 20, LDN = T + 4, PER = T / 64;
+    __shared__ __attribute__((aligned(16))) float As[2][T * LDR];
+    __shared__ __attribute__((aligned(16))) float Ws[2][WKN ? 16 * LDN : T * LDR];
+    const int b = blockIdx.z / g.splits, split = blockIdx.z % g.splits;
     const float* A = g.A + (size_t)b * g.sA;
     const float* W = g.W + (size_t)b * g.sW;
-    const int m0 = blockIdx.y * kGT, n0 = blockIdx.x * kGT;
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;      // 16 x 16 threads, 4 x 4 outputs each
-    float acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    const int m0 = blockIdx.y * T, n0 = blockIdx.x * T;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave & 1, wn = wave >> 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int kbeg = split * g.k_chunk, kend = (kbeg + g.k_chunk < g.K) ? kbeg + g.k_chunk : g.K;
 
-    for (int k0 = 0; k0 < g.K; k0 += kGK) {
-        // A tile: 64 rows x 16 k  (thread -> row = tid / 4, 4 consecutive k)
-        {
-            const int r = threadIdx.x >> 2, kk = (threadIdx.x & 3) * 4;
-            const int m = m0 + r;
+    f32x4 ra[PER], rw[PER];
+    auto load_rows = [&](const float* base, long ld, int row0, int rows, int k0, f32x4* dst) {     // [row][k] operand
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int k = k0 + kk + e;
-                As[kk + e][r] = (m < g.M && k < g.K) ? A[(size_t)m * g.lda + k] : 0.f;
+        for (int j = 0; j < PER; ++j) {
+            const int f = tid + 256 * j, r = f >> 2, k = k0 + (f & 3) * 4;
+            int gr = row0 + r;
+            gr = gr < rows ? gr : rows - 1;
+            const float* p = base + (size_t)gr * ld + k;
+            if (g.vec) {
+                dst[j] = k < kend ? *(const f32x4*)p : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dst[j][e] = (k + e < kend) ? p[e] : 0.f;
             }
         }
-        if (!g.w_kn) {
-            const int r = threadIdx.x >> 2, kk = (threadIdx.x & 3) * 4;
-            const int n = n0 + r;
+    };
+    auto load_kn = [&](int k0, f32x4* dst) {                                                        // W[k][n]
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int k = k0 + kk + e;
-                Ws[kk + e][r] = (n < g.N && k < g.K) ? W[(size_t)n * g.ldw + k] : 0.f;
-            }
-        } else {
-            const int kk = threadIdx.x >> 4, c = (threadIdx.x & 15) * 4;      // W[k][n]: 16 k x 64 n
-            const int k = k0 + kk;
+        for (int j = 0; j < PER; ++j) {
+            const int f = tid + 256 * j, kr = f / (T / 4), n = n0 + (f % (T / 4)) * 4, k = k0 + kr;
+            const float* p = W + (size_t)k * g.ldw + n;
+            if (k < kend && g.vec && n + 3 < g.N) {
+                dst[j] = *(const f32x4*)p;
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int n = n0 + c + e;
-                Ws[kk][c + e] = (n < g.N && k < g.K) ? W[(size_t)k * g.ldw + n] : 0.f;
+                for (int e = 0; e < 4; ++e) dst[j][e] = (k < kend && n + e < g.N) ? p[e] : 0.f;
             }
         }
+    };
+    auto store_lds = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int f = tid + 256 * j;
+            *(f32x4*)&As[buf][(f >> 2) * LDR + (f & 3) * 4] = ra[j];
+            if constexpr (WKN) *(f32x4*)&Ws[buf][(f / (T / 4)) * LDN + (f % (T / 4)) * 4] = rw[j];
+            else *(f32x4*)&Ws[buf][(f >> 2) * LDR + (f & 3) * 4] = rw[j];
+        }
+    };
+    auto load_tile = [&](int k0) {
+        load_rows(A, g.lda, m0, g.M, k0, ra);
+        if constexpr (WKN) load_kn(k0, rw);
+        else load_rows(W, g.ldw, n0, g.N, k0, rw);
+    };
+
+    f32x16 acc[BLK][BLK];
+#pragma unroll
+    for (int i = 0; i < BLK; ++i)
+#pragma unroll
+        for (int j = 0; j < BLK; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk = (kend - kbeg + 15) / 16;
+    load_tile(kbeg);
+    store_lds(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tile(kbeg + (kt + 1) * 16);
+        float a[BLK][8], w[BLK][8];
+#pragma unroll
+        for (int i = 0; i < BLK; ++i) {
+            const float* pa = &As[cur][(wm * (T / 2) + i * 32 + l31) * LDR + hi * 8];
+            const f32x4 a0 = *(const f32x4*)pa, a1 = *(const f32x4*)(pa + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[i][e] = a0[e]; a[i][4 + e] = a1[e]; }
+            if constexpr (WKN) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) w[i][e] = Ws[cur][(hi * 8 + e) * LDN + wn * (T / 2) + i * 32 + l31];
+            } else {
+                const float* pw = &Ws[cur][(wn * (T / 2) + i * 32 + l31) * LDR + hi * 8];
+                const f32x4 w0 = *(const f32x4*)pw, w1 = *(const f32x4*)(pw + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { w[i][e] = w0[e]; w[i][4 + e] = w1[e]; }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int i = 0; i < BLK; ++i)
+#pragma unroll
+                for (int j = 0; j < BLK; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], w[j][e], acc[i][j], 0, 0, 0);
+        if (kt + 1 < nk) store_lds(cur ^ 1);
         __syncthreads();
+    }
+
+    if (g.splits > 1) {                 // raw partial sums; alpha / bias / activation / residual in the reduce kernel
+        float* part = g.partial + (size_t)blockIdx.z * g.M * g.N;
 #pragma unroll
-        for (int kk = 0; kk < kGK; ++kk) {
-            float a[4], w[4];
+        for (int j = 0; j < BLK; ++j) {
+            const int n = n0 + wn * (T / 2) + j * 32 + l31;
+            if (n >= g.N) continue;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = As[kk][ty * 4 + i];
+            for (int i = 0; i < BLK; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) w[j] = Ws[kk][tx * 4 + j];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fmaf(a[i], w[j], acc[i][j]);
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * (T / 2) + i * 32 + (r >> 2) * 8 + hi * 4 + (r & 3);
+                    if (m < g.M) part[(size_t)m * g.N + n] = acc[i][j][r];
+                }
         }
-        __syncthreads();
+        return;
     }
     float* out = g.out + (size_t)b * g.sO;
     const float* resid = g.resid ? g.resid + (size_t)b * g.sR : nullptr;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + ty * 4 + i;
-        if (m >= g.M) continue;
+    for (int j = 0; j < BLK; ++j) {
+        const int n = n0 + wn * (T / 2) + j * 32 + l31;
+        if (n >= g.N) continue;
+        const float bias = g.bias ? g.bias[n] : 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + tx * 4 + j;
-            if (n >= g.N) continue;
-            float v = acc[i][j] * g.alpha;
-            if (g.bias) v += g.bias[n];
-            v = act_apply(v, g.act);
-            if (resid) v += resid[(size_t)m * g.ldr + n];
-            out[(size_t)m * g.ldo + n] = v;
-        }
+        for (int i = 0; i < BLK; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * (T / 2) + i * 32 + (r >> 2) * 8 + hi * 4 + (r & 3);
+                if (m >= g.M) continue;
+                float v = acc[i][j][r] * g.alpha + bias;
+                v = act_apply(v, g.act);
+                if (resid) v += resid[(size_t)m * g.ldr + n];
+                out[(size_t)m * g.ldo + n] = v;
+            }
     }
+}
+
+// out[b][m][n] = act(alpha * sum_s partial[b * splits + s][m][n] + bias[n]) + resid[b][m][n], s in ascending order
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(SgemmArgs g, int batch) {
+    const size_t mn = (size_t)g.M * g.N, total = mn * batch;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int b = (int)(i / mn);
+    const size_t r = i - (size_t)b * mn;
+    const int m = (int)(r / g.N), n = (int)(r - (size_t)m * g.N);
+    const float* p = g.partial + (size_t)b * g.splits * mn + r;
+    float v = 0.f;
+    for (int s = 0; s < g.splits; ++s) v += p[(size_t)s * mn];
+    v = v * g.alpha + (g.bias ? g.bias[n] : 0.f);
+    v = act_apply(v, g.act);
+    if (g.resid) v += g.resid[(size_t)b * g.sR + (size_t)m * g.ldr + n];
+    g.out[(size_t)b * g.sO + (size_t)m * g.ldo + n] = v;
 }
 
 __global__ __launch_bounds__(256) void softmax_rows_kernel(float* x, long ld, int rows, int cols) {
@@ -254,11 +344,55 @@ int ap_sgemm(const float* A, long lda, long strideA, const float* W, long ldw, l
     AP_REQUIRE(A && W && out, "ap_sgemm: null pointer");
     AP_REQUIRE(batch > 0 && M > 0 && N > 0 && K > 0 && batch <= 65535, "ap_sgemm: bad problem %d x %d x %d x %d", batch, M, N, K);
     AP_REQUIRE(act >= 0 && act <= 2, "ap_sgemm: activation %d", act);
-    ap::SgemmArgs g{A, lda, strideA, W, ldw, strideW, w_is_kn, M, N, K, alpha, bias, act, resid, ldr, strideR, out, ldo, strideO};
-    const int gy = (M + ap::kGT - 1) / ap::kGT;
-    AP_REQUIRE(gy <= 65535, "ap_sgemm: M %d too large", M);
-    dim3 grid((N + ap::kGT - 1) / ap::kGT, gy, batch);
-    ap::sgemm_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(g);
+    ap::SgemmArgs g{A, lda, strideA, W, ldw, strideW, w_is_kn, M, N, K, alpha, bias, act, resid, ldr, strideR, out, ldo, strideO,
+                    0, 1, K, nullptr};
+    const bool al16 = (((uintptr_t)A | (uintptr_t)W) & 15) == 0 && lda % 4 == 0 && ldw % 4 == 0 && strideA % 4 == 0 && strideW % 4 == 0;
+    g.vec = al16 && (w_is_kn || K % 4 == 0) ? 1 : 0;
+    // tile: 128 x 128 only when that still gives every CU two workgroups; else 64 x 64
+    auto wgs = [&](int t) { return (long)((M + t - 1) / t) * ((N + t - 1) / t) * batch; };
+    const int T = (M > 64 && N > 64 && wgs(128) >= 512) ? 128 : 64;
+    // split-K: few output tiles over a long K (P V of the global / token-to-image attention, the late MLPs) would leave
+    // most CUs idle behind serial K loops -> K chunks of >= 128 on separate workgroups, partial sums reduced in order
+    int splits = 1;
+    if (wgs(T) < 256 && K >= 512) {
+        splits = (int)std::min<long>(std::min<long>((256 + wgs(T) - 1) / wgs(T), K / 128), 32);
+        if (splits < 2) splits = 1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (splits > 1) {
+        g.k_chunk = (int)ap::align_up((size_t)(K + splits - 1) / splits, 16);
+        splits = (K + g.k_chunk - 1) / g.k_chunk;
+        g.splits = splits;
+        const size_t need = (size_t)splits * batch * M * N * sizeof(float);
+        int dev = 0;
+        AP_HIP_CHECK(hipGetDevice(&dev));
+        static std::mutex mu;
+        static std::map<int, std::pair<float*, size_t>> scratch;         // per device, grow-only
+        std::lock_guard<std::mutex> lock(mu);
+        auto& sc = scratch[dev];
+        if (sc.second < need) {
+            // An outgrown buffer is kept alive (captured graphs may still launch kernels that point at it); sizes double,
+            // so the total stays below twice the largest request.  hipMalloc is not legal inside a stream capture: callers
+            // that capture (services/sam2_hip.py) run every shape once before capturing.
+            const size_t bytes = std::max(need, sc.second * 2);
+            float* fresh = nullptr;
+            AP_HIP_CHECK(hipMalloc((void**)&fresh, bytes));
+            sc = {fresh, bytes};
+        }
+        g.partial = sc.first;
+    }
+    const int gy = (M + T - 1) / T;
+    AP_REQUIRE(gy <= 65535 && (long)batch * splits <= 65535, "ap_sgemm: problem %d x %d x %d x %d too large", batch, M, N, K);
+    dim3 grid((N + T - 1) / T, gy, batch * splits);
+    if (T == 128) {
+        if (w_is_kn) ap::sgemm_mfma_kernel<128, true><<<grid, 256, 0, s>>>(g);
+        else ap::sgemm_mfma_kernel<128, false><<<grid, 256, 0, s>>>(g);
+    } else {
+        if (w_is_kn) ap::sgemm_mfma_kernel<64, true><<<grid, 256, 0, s>>>(g);
+        else ap::sgemm_mfma_kernel<64, false><<<grid, 256, 0, s>>>(g);
+    }
+    if (splits > 1)
+        ap::splitk_reduce_kernel<<<ap::grid1((size_t)batch * M * N), 256, 0, s>>>(g, batch);
     AP_HIP_CHECK(hipGetLastError());
     return AP_OK;
 }

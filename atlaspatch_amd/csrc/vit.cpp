@@ -29,11 +29,30 @@ struct Param {
 
 }  // namespace ap
 
+namespace ap {
+// parameter pointers of one block, resolved once by ap_vit_finalize (no name lookups on the launch path)
+struct BlockParams {
+    const float *ln1_w, *ln1_b, *qkv_b, *proj_b, *ln2_w, *ln2_b, *fc1_b, *fc2_b, *ls1, *ls2;
+    const Param *qkv, *proj, *fc1, *fc2;
+};
+struct PoolParams {
+    const float *ln_k_w, *ln_k_b, *kv_b, *q, *out_b, *ln_out_w, *ln_out_b;
+    const Param *kv, *out;
+};
+}  // namespace ap
+
 struct ap_vit {
     ap_vit_config cfg;
     int grid = 0, patches = 0, tokens = 0, kpe = 0;
     std::map<std::string, ap::Param> params;
     bool finalized = false;
+    // resolved at finalize
+    std::vector<ap::BlockParams> blocks;
+    ap::PoolParams pool{};
+    const ap::Param* pe_w = nullptr;
+    const float *pe_b = nullptr, *cls = nullptr, *pos = nullptr, *norm_w = nullptr, *norm_b = nullptr;
+    // options (ap_vit_set_option; the defaults come from the environment once, at creation)
+    bool full_last_block = false, two_half_overlap = false;
     int device = 0;
     // optional per-launch HIP-event timing (ap_vit_profile_*): kind -> events of the last forwards
     bool profile = false;
@@ -120,18 +139,16 @@ int run_blocks(ap_vit* m, int n, const Workspace& w, float* out, hipStream_t str
     int rc;
     // patch embedding: tok[img][1 + p] = pe_row @ W^T + b + pos[1 + p]
     {
-        const Param* wpe = find(m, "patch_embed.weight");
+        const Param* wpe = m->pe_w;
         ap::GemmArgs g{};
         g.A = w.hid; g.lda = m->kpe; g.W = wpe->dev; g.ldw = wpe->ld;
         g.M = n * m->patches; g.N = D; g.K = m->kpe;
-        g.bias = (const float*)find(m, "patch_embed.bias")->dev;
-        g.pos = (const float*)find(m, "pos_embed")->dev;
+        g.bias = m->pe_b;
+        g.pos = m->pos;
         g.out = w.tok; g.ldo = D; g.P = m->patches;
         { ScopedTimer t(m, AP_PROF_GEMM_PATCH_EMBED, stream);
           if ((rc = ap::launch_gemm(dt, ap::EPI_PATCH_EMBED, g, stream)) != AP_OK) return rc; }
-        if ((rc = ap::launch_cls_init(w.tok, (const float*)find(m, "cls_token")->dev,
-                                      (const float*)find(m, "pos_embed")->dev, n, m->tokens, D,
-                                      stream)) != AP_OK) return rc;
+        if ((rc = ap::launch_cls_init(w.tok, m->cls, m->pos, n, m->tokens, D, stream)) != AP_OK) return rc;
     }
     // Residual stream: tok (f32) is only ever touched by the add+LayerNorm kernel.  A branch GEMM
     // (proj, fc2) stores its output delta = acc + bias in T; LayerNorm launches fold it into the
@@ -140,31 +157,28 @@ int run_blocks(ap_vit* m, int n, const Workspace& w, float* out, hipStream_t str
     // (same f32 operation order) and stores -> 620 MB less HBM traffic per block at n = 1024.
     const void* pending = nullptr;       // branch output not yet added to tok
     long pending_stride = D;             // its row stride as seen from the final CLS LayerNorm
-    // AP_VIT_FULL_LAST_BLOCK=1 computes the last block for every token (A/B of the CLS-only tail; same features)
-    const bool full_last = getenv("AP_VIT_FULL_LAST_BLOCK") != nullptr;      // read per forward: tests toggle it
-    const bool cls_tail = c.pool == AP_POOL_CLS && !full_last && D / c.heads == 64;
+    // AP_VIT_OPT_FULL_LAST_BLOCK computes the last block for every token (A/B of the CLS-only tail; same features)
+    const bool cls_tail = c.pool == AP_POOL_CLS && !m->full_last_block && D / c.heads == 64;
     const float* pending_ls = nullptr;   // ... and its LayerScale vector (applied in f32 by the add)
     for (int i = 0; i < c.depth; ++i) {
-        const std::string b = "blocks." + std::to_string(i) + ".";
-        auto vec = [&](const char* s) { return (const float*)find(m, b + s)->dev; };
-        auto mat = [&](const char* s) { return find(m, b + s); };
+        const ap::BlockParams& bp = m->blocks[i];
         { ScopedTimer t(m, AP_PROF_LAYERNORM, stream);
           if ((rc = ap::launch_add2_layernorm(dt, dt, w.tok, D, pending, D, pending_ls, nullptr, 0, nullptr, /*store=*/0,
-                                              M, D, vec("ln1.weight"), vec("ln1.bias"), c.ln_eps, w.xn,
+                                              M, D, bp.ln1_w, bp.ln1_b, c.ln_eps, w.xn,
                                               stream)) != AP_OK) return rc; }
         if (i == c.depth - 1 && cls_tail) {
             // ---- last block, CLS readout: nothing reads this block's output for the patch tokens, so only what the
             // CLS row depends on is computed: K and V of every token, then the CLS row alone through q-projection,
             // attention, proj, ln2, fc1, fc2.  Same operators, same operation order per row -> same features.
             const size_t es = ap::dtype_size(dt);
-            const Param* wq = mat("qkv.weight");
+            const Param* wq = bp.qkv;
             const long cls_stride = (long)m->tokens * D;
             char* q_cls = (char*)w.att;                                   // T [n, D]
             char* a_cls = (char*)w.att + (size_t)n * D * es;              // T [n, D]
             {
                 ap::GemmArgs g{};                                          // k | v for all rows
                 g.A = w.xn; g.lda = D; g.W = (const char*)wq->dev + (size_t)D * wq->ld * es; g.ldw = wq->ld;
-                g.M = M; g.N = 2 * D; g.K = D; g.bias = vec("qkv.bias") + D;
+                g.M = M; g.N = 2 * D; g.K = D; g.bias = bp.qkv_b + D;
                 g.out = (char*)w.qkv + (size_t)D * es; g.ldo = 3 * D;
                 ScopedTimer t(m, AP_PROF_GEMM_QKV, stream);
                 if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_STORE, g, stream)) != AP_OK) return rc;
@@ -174,42 +188,42 @@ int run_blocks(ap_vit* m, int n, const Workspace& w, float* out, hipStream_t str
             {
                 ap::GemmArgs g{};                                          // q for the CLS rows
                 g.A = w.xn; g.lda = (int)cls_stride; g.W = wq->dev; g.ldw = wq->ld;
-                g.M = n; g.N = D; g.K = D; g.bias = vec("qkv.bias"); g.out = q_cls; g.ldo = D;
+                g.M = n; g.N = D; g.K = D; g.bias = bp.qkv_b; g.out = q_cls; g.ldo = D;
                 if ((rc = ap::launch_gemm_impl(dt, ap::EPI_BIAS_STORE, g, 128, 0, stream)) != AP_OK) return rc;
             }
             if ((rc = ap::launch_attention_cls(dt, q_cls, w.qkv, 3 * D, D, 2 * D, a_cls, n, m->tokens, c.heads,
                                                D / c.heads, stream)) != AP_OK) return rc;
             {
                 ap::GemmArgs g{};
-                g.A = a_cls; g.lda = D; g.W = mat("proj.weight")->dev; g.ldw = mat("proj.weight")->ld;
-                g.M = n; g.N = D; g.K = D; g.bias = vec("proj.bias"); g.out = w.delta2; g.ldo = D;
+                g.A = a_cls; g.lda = D; g.W = bp.proj->dev; g.ldw = bp.proj->ld;
+                g.M = n; g.N = D; g.K = D; g.bias = bp.proj_b; g.out = w.delta2; g.ldo = D;
                 if ((rc = ap::launch_gemm_impl(dt, ap::EPI_BIAS_STORE, g, 128, 0, stream)) != AP_OK) return rc;
             }
             if ((rc = ap::launch_add2_layernorm(dt, dt, w.tok, cls_stride, pending, cls_stride, pending_ls, w.delta2, D,
-                                                c.layer_scale ? vec("ls1") : nullptr, /*store=*/1, n, D,
-                                                vec("ln2.weight"), vec("ln2.bias"), c.ln_eps, w.xn, stream)) != AP_OK)
+                                                bp.ls1, /*store=*/1, n, D,
+                                                bp.ln2_w, bp.ln2_b, c.ln_eps, w.xn, stream)) != AP_OK)
                 return rc;
             {
                 ap::GemmArgs g{};
-                g.A = w.xn; g.lda = D; g.W = mat("fc1.weight")->dev; g.ldw = mat("fc1.weight")->ld;
-                g.M = n; g.N = c.mlp_dim; g.K = D; g.bias = vec("fc1.bias"); g.out = w.hid; g.ldo = c.mlp_dim;
+                g.A = w.xn; g.lda = D; g.W = bp.fc1->dev; g.ldw = bp.fc1->ld;
+                g.M = n; g.N = c.mlp_dim; g.K = D; g.bias = bp.fc1_b; g.out = w.hid; g.ldo = c.mlp_dim;
                 if ((rc = ap::launch_gemm_impl(dt, ap::EPI_BIAS_GELU, g, 128, 0, stream)) != AP_OK) return rc;
             }
             {
                 ap::GemmArgs g{};
-                g.A = w.hid; g.lda = c.mlp_dim; g.W = mat("fc2.weight")->dev; g.ldw = mat("fc2.weight")->ld;
-                g.M = n; g.N = D; g.K = c.mlp_dim; g.bias = vec("fc2.bias"); g.out = w.delta; g.ldo = D;
+                g.A = w.hid; g.lda = c.mlp_dim; g.W = bp.fc2->dev; g.ldw = bp.fc2->ld;
+                g.M = n; g.N = D; g.K = c.mlp_dim; g.bias = bp.fc2_b; g.out = w.delta; g.ldo = D;
                 if ((rc = ap::launch_gemm_impl(dt, ap::EPI_BIAS_STORE, g, 128, 0, stream)) != AP_OK) return rc;
             }
             pending = w.delta;
-            pending_ls = c.layer_scale ? vec("ls2") : nullptr;
+            pending_ls = bp.ls2;
             pending_stride = D;
             break;
         }
         {
             ap::GemmArgs g{};
-            g.A = w.xn; g.lda = D; g.W = mat("qkv.weight")->dev; g.ldw = mat("qkv.weight")->ld;
-            g.M = M; g.N = 3 * D; g.K = D; g.bias = vec("qkv.bias"); g.out = w.qkv; g.ldo = 3 * D;
+            g.A = w.xn; g.lda = D; g.W = bp.qkv->dev; g.ldw = bp.qkv->ld;
+            g.M = M; g.N = 3 * D; g.K = D; g.bias = bp.qkv_b; g.out = w.qkv; g.ldo = 3 * D;
             ScopedTimer t(m, AP_PROF_GEMM_QKV, stream);
             if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_STORE, g, stream)) != AP_OK) return rc;
         }
@@ -218,70 +232,70 @@ int run_blocks(ap_vit* m, int n, const Workspace& w, float* out, hipStream_t str
                                          stream)) != AP_OK) return rc; }
         {
             ap::GemmArgs g{};
-            g.A = w.att; g.lda = D; g.W = mat("proj.weight")->dev; g.ldw = mat("proj.weight")->ld;
-            g.M = M; g.N = D; g.K = D; g.bias = vec("proj.bias");
+            g.A = w.att; g.lda = D; g.W = bp.proj->dev; g.ldw = bp.proj->ld;
+            g.M = M; g.N = D; g.K = D; g.bias = bp.proj_b;
             g.out = w.delta2; g.ldo = D;
             ScopedTimer t(m, AP_PROF_GEMM_PROJ, stream);
             if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_STORE, g, stream)) != AP_OK) return rc;
         }
         { ScopedTimer t(m, AP_PROF_LAYERNORM, stream);
           if ((rc = ap::launch_add2_layernorm(dt, dt, w.tok, D, pending, D, pending_ls, w.delta2, D,
-                                              c.layer_scale ? vec("ls1") : nullptr, /*store=*/1, M, D, vec("ln2.weight"),
-                                              vec("ln2.bias"), c.ln_eps, w.xn, stream)) != AP_OK) return rc; }
+                                              bp.ls1, /*store=*/1, M, D, bp.ln2_w,
+                                              bp.ln2_b, c.ln_eps, w.xn, stream)) != AP_OK) return rc; }
         {
             ap::GemmArgs g{};
-            g.A = w.xn; g.lda = D; g.W = mat("fc1.weight")->dev; g.ldw = mat("fc1.weight")->ld;
-            g.M = M; g.N = c.mlp_dim; g.K = D; g.bias = vec("fc1.bias"); g.out = w.hid; g.ldo = c.mlp_dim;
+            g.A = w.xn; g.lda = D; g.W = bp.fc1->dev; g.ldw = bp.fc1->ld;
+            g.M = M; g.N = c.mlp_dim; g.K = D; g.bias = bp.fc1_b; g.out = w.hid; g.ldo = c.mlp_dim;
             ScopedTimer t(m, AP_PROF_GEMM_FC1, stream);
             if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_GELU, g, stream)) != AP_OK) return rc;
         }
         {
             ap::GemmArgs g{};
-            g.A = w.hid; g.lda = c.mlp_dim; g.W = mat("fc2.weight")->dev; g.ldw = mat("fc2.weight")->ld;
-            g.M = M; g.N = D; g.K = c.mlp_dim; g.bias = vec("fc2.bias");
+            g.A = w.hid; g.lda = c.mlp_dim; g.W = bp.fc2->dev; g.ldw = bp.fc2->ld;
+            g.M = M; g.N = D; g.K = c.mlp_dim; g.bias = bp.fc2_b;
             g.out = w.delta; g.ldo = D;
             ScopedTimer t(m, AP_PROF_GEMM_FC2, stream);
             if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_STORE, g, stream)) != AP_OK) return rc;
         }
         pending = w.delta;
-        pending_ls = c.layer_scale ? vec("ls2") : nullptr;
+        pending_ls = bp.ls2;
     }
     if (c.pool == AP_POOL_CLS)
         // final LayerNorm on the CLS row of every image (last fc2 output folded in first) -> out f32 [n, D]
         return ap::launch_add_layernorm(dt, AP_F32, w.tok, (long)m->tokens * D, pending,
                                         cls_tail ? pending_stride : (long)m->tokens * D, pending_ls,
-                                        n, D, (const float*)find(m, "norm.weight")->dev,
-                                        (const float*)find(m, "norm.bias")->dev, c.ln_eps, out, stream);
+                                        n, D, m->norm_w,
+                                        m->norm_b, c.ln_eps, out, stream);
 
     // ---- AP_POOL_ATTN (CONCH visual tower): final LN on ALL tokens, then the one-query attentional pooler.
     // Buffers: y f32 [M, D] reuses qkv, xk T [M, D] = xn, kv T [M, 2P] reuses hid, pooled T [n, P] = att,
     // o32 f32 [n, P] reuses delta.
     const int P = c.pool_dim;
-    auto pv = [&](const char* s) { return (const float*)find(m, std::string("attn_pool.") + s)->dev; };
+    const ap::PoolParams& pp = m->pool;
     float* y = (float*)w.qkv;
     if ((rc = ap::launch_add_layernorm(dt, AP_F32, w.tok, D, pending, D, pending_ls, M, D,
-                                       (const float*)find(m, "norm.weight")->dev,
-                                       (const float*)find(m, "norm.bias")->dev, c.ln_eps, y, stream)) != AP_OK) return rc;
-    if ((rc = ap::launch_layernorm(dt, y, D, M, D, pv("ln_k.weight"), pv("ln_k.bias"), c.pool_ln_eps, w.xn,
+                                       m->norm_w,
+                                       m->norm_b, c.ln_eps, y, stream)) != AP_OK) return rc;
+    if ((rc = ap::launch_layernorm(dt, y, D, M, D, pp.ln_k_w, pp.ln_k_b, c.pool_ln_eps, w.xn,
                                    stream)) != AP_OK) return rc;
     {
-        const Param* wkv = find(m, "attn_pool.kv.weight");
+        const Param* wkv = pp.kv;
         ap::GemmArgs g{};
         g.A = w.xn; g.lda = D; g.W = wkv->dev; g.ldw = wkv->ld; g.M = M; g.N = 2 * P; g.K = D;
-        g.bias = pv("kv.bias"); g.out = w.hid; g.ldo = 2 * P;
+        g.bias = pp.kv_b; g.out = w.hid; g.ldo = 2 * P;
         if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_STORE, g, stream)) != AP_OK) return rc;
     }
-    if ((rc = ap::launch_attn_pool(dt, w.hid, pv("q"), w.att, n, m->tokens, c.pool_heads, stream)) != AP_OK) return rc;
+    if ((rc = ap::launch_attn_pool(dt, w.hid, pp.q, w.att, n, m->tokens, c.pool_heads, stream)) != AP_OK) return rc;
     float* o32 = (float*)w.delta;
     AP_HIP_CHECK(hipMemsetAsync(o32, 0, (size_t)n * P * sizeof(float), stream));
     {
-        const Param* wo = find(m, "attn_pool.out.weight");
+        const Param* wo = pp.out;
         ap::GemmArgs g{};
         g.A = w.att; g.lda = P; g.W = wo->dev; g.ldw = wo->ld; g.M = n; g.N = P; g.K = P;
-        g.bias = pv("out.bias"); g.out = o32; g.ldo = P;
+        g.bias = pp.out_b; g.out = o32; g.ldo = P;
         if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_RESID, g, stream)) != AP_OK) return rc;    // 0 + (acc + bias), f32
     }
-    return ap::launch_layernorm(AP_F32, o32, P, n, P, pv("ln_out.weight"), pv("ln_out.bias"), c.pool_ln_eps, out, stream);
+    return ap::launch_layernorm(AP_F32, o32, P, n, P, pp.ln_out_w, pp.ln_out_b, c.pool_ln_eps, out, stream);
 }
 
 int check_forward_args(const ap_vit* m, int n, const void* in, const float* out, const void* ws,
@@ -331,6 +345,8 @@ int ap_vit_create(const ap_vit_config* cfg, ap_vit** out) {
     m->grid = g; m->patches = g * g; m->tokens = 1 + g * g;
     m->kpe = (int)ap::align_up(3 * c.patch_size * c.patch_size, 64);
     AP_HIP_CHECK(hipGetDevice(&m->device));
+    m->full_last_block = getenv("AP_VIT_FULL_LAST_BLOCK") != nullptr;     // defaults only; ap_vit_set_option changes them
+    m->two_half_overlap = getenv("AP_VIT_OVERLAP") != nullptr;
     int rc = AP_OK;
     auto add = [&](const std::string& name, int rows, int cols, bool matrix) {
         if (rc == AP_OK) rc = alloc_param(m, name, rows, cols, matrix);
@@ -406,7 +422,42 @@ int ap_vit_finalize(ap_vit* m) {
             ap::set_error("vit_finalize: parameter '%s' was never set", kv.first.c_str());
             return AP_ERR_STATE;
         }
+    auto vec = [&](const std::string& name) -> const float* {
+        const Param* p = find(m, name);
+        return p ? (const float*)p->dev : nullptr;
+    };
+    m->pe_w = find(m, "patch_embed.weight");
+    m->pe_b = vec("patch_embed.bias"); m->cls = vec("cls_token"); m->pos = vec("pos_embed");
+    m->norm_w = vec("norm.weight"); m->norm_b = vec("norm.bias");
+    m->blocks.resize(m->cfg.depth);
+    for (int i = 0; i < m->cfg.depth; ++i) {
+        const std::string b = "blocks." + std::to_string(i) + ".";
+        ap::BlockParams& bp = m->blocks[i];
+        bp.ln1_w = vec(b + "ln1.weight"); bp.ln1_b = vec(b + "ln1.bias");
+        bp.ln2_w = vec(b + "ln2.weight"); bp.ln2_b = vec(b + "ln2.bias");
+        bp.qkv_b = vec(b + "qkv.bias"); bp.proj_b = vec(b + "proj.bias");
+        bp.fc1_b = vec(b + "fc1.bias"); bp.fc2_b = vec(b + "fc2.bias");
+        bp.ls1 = m->cfg.layer_scale ? vec(b + "ls1") : nullptr;
+        bp.ls2 = m->cfg.layer_scale ? vec(b + "ls2") : nullptr;
+        bp.qkv = find(m, b + "qkv.weight"); bp.proj = find(m, b + "proj.weight");
+        bp.fc1 = find(m, b + "fc1.weight"); bp.fc2 = find(m, b + "fc2.weight");
+    }
+    if (m->cfg.pool == AP_POOL_ATTN) {
+        ap::PoolParams& pp = m->pool;
+        pp.ln_k_w = vec("attn_pool.ln_k.weight"); pp.ln_k_b = vec("attn_pool.ln_k.bias");
+        pp.kv = find(m, "attn_pool.kv.weight"); pp.kv_b = vec("attn_pool.kv.bias"); pp.q = vec("attn_pool.q");
+        pp.out = find(m, "attn_pool.out.weight"); pp.out_b = vec("attn_pool.out.bias");
+        pp.ln_out_w = vec("attn_pool.ln_out.weight"); pp.ln_out_b = vec("attn_pool.ln_out.bias");
+    }
     m->finalized = true;
+    return AP_OK;
+}
+
+int ap_vit_set_option(ap_vit* m, int option, int value) {
+    AP_REQUIRE(m, "vit_set_option: null handle");
+    if (option == AP_VIT_OPT_FULL_LAST_BLOCK) m->full_last_block = value != 0;
+    else if (option == AP_VIT_OPT_TWO_HALF_OVERLAP) m->two_half_overlap = value != 0;
+    else { ap::set_error("vit_set_option: unknown option %d", option); return AP_ERR_INVALID; }
     return AP_OK;
 }
 
@@ -465,10 +516,10 @@ int ap_vit_forward_u8(ap_vit* m, const uint8_t* patches, int n, int h, int w, co
         if (r != AP_OK) return r;
         return run_blocks(m, cnt, ws, dst, st);
     };
-    // Experimental (AP_VIT_OVERLAP=1): the batch as two independent halves on two streams, so that the HBM-bound
+    // Experimental (AP_VIT_OPT_TWO_HALF_OVERLAP): the batch as two independent halves on two streams, so that the HBM-bound
     // add+LayerNorm launches of one half can run beside the VALU-bound attention of the other.  Same features (every
     // image is independent of its batch neighbours, tested bit for bit).
-    const bool overlap = getenv("AP_VIT_OVERLAP") != nullptr && n >= 512;
+    const bool overlap = m->two_half_overlap && n >= 512;
     if (!overlap) return forward_part(patches, n, out, (char*)workspace, s);
     if (!m->side) {
         AP_HIP_CHECK(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));

@@ -54,6 +54,8 @@ class Sam2HipPredictor:
         self.mask_threshold = float(mask_threshold)
         self.input_size = 1024
         self.plan, self.stage_ends = block_plan()
+        self._graph = None
+        self._static_img = self._static_mask = None
         f = lambda t: t.detach().to(torch.float32).contiguous()
         sd = {k: f(v) for k, v in state_dict.items()}
         dev = lambda t: t.to(self.device).contiguous()
@@ -158,6 +160,12 @@ class Sam2HipPredictor:
         out = self._buf(nb * tq, heads * d)
         scores = self._buf(nb * heads, tq, tk)
         scale = 1.0 / math.sqrt(d)
+        if nb == 1:                     # one image-wide attention: the heads are the batch (head h = column offset h * d)
+            self._gemm(q, k, tk, d, m=tq, lda=ldq, ldw=ldk, out=scores, ldo=tk, batch=heads, sa=d, sw=d, so=tq * tk, alpha=scale)
+            _lib.check(self.lib.ap_softmax_rows(scores.data_ptr(), tk, heads * tq, tk, self._stream()), "ap_softmax_rows")
+            self._gemm(scores, v, d, tk, m=tq, lda=tk, ldw=ldv, out=out, ldo=heads * d, batch=heads, sa=tq * tk, sw=d, so=d,
+                       w_kn=True)
+            return out
         for h in range(heads):          # batched over windows; heads are column offsets
             qh, kh, vh = q[:, h * d:], k[:, h * d:], v[:, h * d:]
             sh = scores[h * nb:]
@@ -298,6 +306,36 @@ class Sam2HipPredictor:
         return self._gemm(up, h, 1, 32).view(256, 256)                                   # logits[p] = sum_c up[p][c] * h[c]
 
     # ------------------------------------------------------------------ reference-facing API
+    def _forward_mask(self, img: torch.Tensor) -> torch.Tensor:
+        """uint8 [1024, 1024, 3] on the device -> float {0, 1} mask [1024, 1024] (set_image + predict + postprocess)."""
+        logits = self.mask_logits(*self.image_features(img))
+        mask = self._buf(1024, 1024)
+        _lib.check(self.lib.ap_bilinear_up4_threshold(logits.data_ptr(), 256, C.c_float(self.mask_threshold), mask.data_ptr(),
+                                                      self._stream()), "ap_bilinear_up4_threshold")
+        return mask
+
+    def _graph_mask(self, arr: np.ndarray) -> torch.Tensor:
+        """The ~550-launch chain is the same for every slide (fixed 1024 x 1024 input, shapes from the weights only):
+        it is captured once into a hipGraph (through torch's stream capture: every C-ABI launch goes to the capturing
+        stream, buffers come from the graph's private pool) and replayed per slide -- one graph launch instead of 550
+        kernel launches.  ATLASPATCH_SAM2_GRAPH=0 runs the launches one by one (per-kernel profiling)."""
+        import os
+        src = torch.from_numpy(np.ascontiguousarray(arr))
+        if os.environ.get("ATLASPATCH_SAM2_GRAPH", "1") == "0":
+            return self._forward_mask(src.to(self.device))
+        if self._graph is None:
+            self._static_img = torch.empty((self.input_size, self.input_size, 3), dtype=torch.uint8, device=self.device)
+            self._static_img.copy_(src)
+            self._forward_mask(self._static_img)                 # warm-up outside the capture (lazy initialisation)
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._static_mask = self._forward_mask(self._static_img)
+            self._graph = graph
+        self._static_img.copy_(src)
+        self._graph.replay()
+        return self._static_mask
+
     @torch.inference_mode()
     def predict_logits(self, image_u8_1024: np.ndarray) -> torch.Tensor:
         img = torch.from_numpy(np.ascontiguousarray(image_u8_1024)).to(self.device)
@@ -314,18 +352,16 @@ class Sam2HipPredictor:
         orig = (int(arr.shape[0]), int(arr.shape[1]))
         if orig != (self.input_size, self.input_size):
             arr = np.array(Image.fromarray(arr).resize((self.input_size, self.input_size), Image.Resampling.BILINEAR), copy=True)
-        logits = self.predict_logits(arr)
-        mask = self._buf(1024, 1024)
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.ap_bilinear_up4_threshold(logits.data_ptr(), 256, C.c_float(self.mask_threshold), mask.data_ptr(),
-                                                          self._stream()))
-        out = mask.cpu().numpy()
+            out = self._graph_mask(arr).cpu().numpy()
         if resize_to_input and orig != (self.input_size, self.input_size):
             pil = Image.fromarray((out * 255).astype(np.uint8), mode="L").resize((orig[1], orig[0]), resample=Image.Resampling.NEAREST)
             out = np.asarray(pil, dtype=np.float32) / 255.0
         return out
 
     def close(self) -> None:
+        self._graph = None
+        self._static_img = self._static_mask = None
         self.w = {}
 
 

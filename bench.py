@@ -40,7 +40,11 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=2048, help="tiles per step (device batch)")
     ap.add_argument("--precision", default="float16", choices=["float16", "bfloat16", "float32"])
-    ap.add_argument("--slide", type=int, default=40000, help="synthetic slide side in pixels")
+    ap.add_argument("--slide", type=int, default=None,
+                    help="synthetic slide side in pixels (default: 40000 = BASELINE config 2 at N = 1, "
+                         "100000 = config 4 for N > 1)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the secondary rates (ring / end-to-end / boundary / f32 / uni_v1 / conch_v1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=192, help="patches timed on the CPU oracle")
     return ap.parse_args()
@@ -135,9 +139,137 @@ def cpu_coords_baseline(side, seed):
     return coords, time.perf_counter() - t0
 
 
+def _timed_forward(ex, tiles, steps, warm=1):
+    out = torch.empty((tiles.shape[0], ex.embedding_dim), dtype=torch.float32, device=tiles.device)
+    for _ in range(warm):
+        ex.forward_device(tiles, out)
+    torch.cuda.synchronize(tiles.device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ex.forward_device(tiles, out)
+    torch.cuda.synchronize(tiles.device)
+    return steps * tiles.shape[0] / (time.perf_counter() - t0)
+
+
+def secondary_rates(device, ex, tiles, B):
+    """Rates that are NOT `value` (outside its timed region), measured in the same process so that the driver's line
+    carries them: PCIe-inclusive ring, end-to-end CLI on the 100 000^2 slide (device tile source / host ring with the
+    native renderer as the decoder), the reference's call shape extract_batch(32 host patches), float32 mode with its
+    fc1 roofline fraction, and the other two BASELINE encoders kernel-only (transform included)."""
+    import tempfile
+    from click.testing import CliRunner
+    from atlaspatch_amd.cli import cli
+    from atlaspatch_amd.encoders import build_default_registry
+    from atlaspatch_amd.encoders.vit import build_hip_vit_extractor
+    from atlaspatch_amd.services.tile_ring import TileRing
+    from atlaspatch_amd.utils.h5 import h5
+    rates = {}
+    # ---- (1) PCIe-inclusive: tiles in host memory -> pinned ring -> HBM -> forward -> features back on the host
+    n_host = 4 * B
+    host = tiles[:n_host].cpu().numpy()
+    coords = np.stack([np.arange(n_host), np.zeros(n_host), np.full(n_host, 256), np.full(n_host, 256),
+                       np.zeros(n_host)], 1).astype(np.int32)
+    workers = min(32, os.cpu_count() or 8)
+    ring = TileRing(device=device, batch=B, patch_size=256, slots=3, workers=workers)
+    fwd = lambda t, o: ex.forward_device(t, o)
+    read = lambda x, y, rw, rh, lv: host[x]
+    ring.run(coords[:B], read, fwd, ex.embedding_dim)
+    t0 = time.perf_counter()
+    ring.run(coords, read, fwd, ex.embedding_dim)
+    dt = time.perf_counter() - t0
+    ring.close()
+    rates["ring_pcie_inclusive"] = {"patches_per_s": round(n_host / dt, 1), "tiles": n_host, "host_threads": workers,
+                                    "what": "uint8 tiles in host memory -> pinned 3-slot ring -> H2D on a copy stream -> "
+                                            "K1 + ViT-B/16 -> float32 features back in pinned host memory"}
+    # ---- (2) the reference's call shape: extract_batch on 32 host patches (models/patch/base.py:76-107)
+    patches = [host[i] for i in range(32)]
+    ex.extract_batch(patches, batch_size=32)
+    t0 = time.perf_counter()
+    reps = 20
+    for _ in range(reps):
+        ex.extract_batch(patches, batch_size=32)
+    dt = (time.perf_counter() - t0) / reps
+    rates["extract_batch_32"] = {"patches_per_s": round(32 / dt, 1), "ms_per_call": round(dt * 1e3, 3),
+                                 "what": "FeatureExtractor.extract_batch(32 host uint8 patches) -> float32 [32, 768] on the "
+                                         "host: synchronous H2D + forward + D2H, the drop-in boundary as the reference "
+                                         "calls it (storage.py:283-294)"}
+    del host
+    # ---- (3) end-to-end `process` CLI on the north-star slide (100 000 x 100 000), f16, weights from a file
+    with tempfile.TemporaryDirectory() as tmp:
+        from safetensors.torch import save_file
+        from atlaspatch_amd.encoders.vit import ARCHS, random_canonical_state_dict
+        save_file(random_canonical_state_dict(ARCHS["vit_b_16"], 0), os.path.join(tmp, "vit_b_16.safetensors"))
+        slide = os.path.join(tmp, "big.synth")
+        json.dump({"width": 100000, "height": 100000, "seed": 1234, "mag": 20, "mpp": 0.5, "downsamples": [1, 4, 16]},
+                  open(slide, "w"))
+        for key, host_tiles in (("e2e_cli_100k_device_tile_source", False), ("e2e_cli_100k_host_ring", True)):
+            env = {"ATLASPATCH_WEIGHTS_DIR": tmp}
+            if host_tiles:
+                env["ATLASPATCH_HOST_TILES"] = "1"
+            old = {k: os.environ.get(k) for k in list(env) + ["ATLASPATCH_RANDOM_INIT"]}
+            os.environ.update(env)
+            os.environ.pop("ATLASPATCH_RANDOM_INIT", None)
+            try:
+                out_dir = os.path.join(tmp, "out_" + key)
+                t0 = time.perf_counter()
+                res = CliRunner().invoke(cli, ["process", slide, "-o", out_dir, "--patch-size", "256", "--target-mag", "20",
+                                               "--feature-extractors", "vit_b_16", "--feature-precision", "float16",
+                                               "--feature-num-workers", str(min(64, os.cpu_count() or 8))],
+                                         catch_exceptions=False)
+                dt = time.perf_counter() - t0
+                assert res.exit_code == 0 and "failures: 0" in res.output, res.output
+                with h5.File(os.path.join(out_dir, "patches", "big.h5"), "r") as f:
+                    n = int(f["coords"].shape[0])
+                    assert f["features"]["vit_b_16"].shape == (n, 768)
+                rates[key] = {"patches_per_s": round(n / dt, 1), "tiles": n, "seconds": round(dt, 3),
+                              "what": ("`process` on one synthetic 100000x100000 slide: checkpoint load, analytic "
+                                       "segmentation, device coords, H5 coords, " +
+                                       ("tiles rendered on HOST threads by the native renderer (the stand-in decoder) -> "
+                                        "pinned ring -> H2D" if host_tiles else "tiles from the slide's device tile source") +
+                                       ", K1 + ViT-B/16 f16, H5 features")}
+            finally:
+                for k, v in old.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+    # ---- (4) float32 mode (the 1e-3 parity mode): value + fc1 roofline fraction against the f32 MFMA peak
+    Bf = 512
+    ex32 = build_hip_vit_extractor(name="vit_b_16", arch="vit_b_16", device=device, dtype=torch.float32,
+                                   random_init_seed=0, max_batch=Bf)
+    ex32.forward_device(tiles[:Bf], torch.empty((Bf, 768), dtype=torch.float32, device=device))
+    ex32.vit.profile(True)
+    v32 = _timed_forward(ex32, tiles[:Bf], 4, warm=0)
+    prof = ex32.vit.profile_read()
+    ex32.vit.profile(False)
+    ms, cnt = prof["gemm_fc1"]
+    tf = 2.0 * Bf * 197 * 3072 * 768 / ((ms / max(1, cnt)) * 1e-3) / 1e12 if cnt else 0.0
+    rates["float32_mode"] = {"patches_per_s": round(v32, 1), "device_batch": Bf,
+                             "fc1_TFLOPs": round(tf, 1), "fc1_peak_TFLOPs": MFMA_PEAK["f32"] / 1e12,
+                             "fc1_frac": round(tf / (MFMA_PEAK["f32"] / 1e12), 4),
+                             "what": "exact-f32 MFMA (v_mfma_f32_32x32x2_f32) ViT-B/16, tiles resident in HBM"}
+    ex32.cleanup()
+    # ---- (5) the other two BASELINE encoders, kernel-only incl. their transform (device resize), f16
+    os.environ["ATLASPATCH_RANDOM_INIT"] = "0"
+    try:
+        reg = build_default_registry(device=device, dtype=torch.float16)
+        for name, nb in (("uni_v1", 2048), ("conch_v1", 256)):
+            enc = reg.create(name)
+            nb = min(nb, enc.max_batch, tiles.shape[0])
+            rates[f"{name}_kernel_only"] = {"patches_per_s": round(_timed_forward(enc, tiles[:nb], 3), 1),
+                                            "device_batch": nb, "dtype": "f16",
+                                            "what": "registered encoder incl. its Resize on the device, tiles resident in HBM"}
+            enc.cleanup()
+    finally:
+        os.environ.pop("ATLASPATCH_RANDOM_INIT", None)
+    return rates
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.slide is None:
+        args.slide = 40000 if world == 1 else 100000
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -195,10 +327,11 @@ def main():
         elapsed = float(t.item())
 
     # Secondary, untimed-for-`value` measurement: the same K steps with the last block computed for every token
-    # (AP_VIT_FULL_LAST_BLOCK=1, read per forward), so the line shows what the CLS-only tail is worth.
+    # (option full_last_block), so the line shows what the CLS-only tail is worth.
     full_value = None
-    if world == 1 and not os.environ.get("AP_VIT_FULL_LAST_BLOCK"):
-        os.environ["AP_VIT_FULL_LAST_BLOCK"] = "1"
+    full_last = bool(os.environ.get("AP_VIT_FULL_LAST_BLOCK"))      # the default the encoder object was created with
+    if world == 1 and not full_last:
+        ex.vit.set_option("full_last_block", True)
         try:
             step(0, feats[:B])
             torch.cuda.synchronize(device)
@@ -208,7 +341,7 @@ def main():
             torch.cuda.synchronize(device)
             full_value = K * B / (time.perf_counter() - t1)
         finally:
-            os.environ.pop("AP_VIT_FULL_LAST_BLOCK", None)
+            ex.vit.set_option("full_last_block", False)
 
     if rank != 0:
         if dist is not None:
@@ -253,7 +386,6 @@ def main():
     #   pending branch) and LN2 (stream + two branches in, stream + normalised rows out); the final LN touches CLS rows only
     eb = 2.0 if short != "f32" else 4.0
     pre_bytes = B * 150528.0 * (1.0 + eb)
-    full_last = bool(os.environ.get("AP_VIT_FULL_LAST_BLOCK"))
     ln_blocks = 12 if full_last else 11          # the last block's LN2 runs on the CLS rows only (timed under cls_tail)
     ln_bytes = M * 768.0 * (ln_blocks * ((4 + eb + eb) + (4 + 2 * eb + 4 + eb)) + (0 if full_last else 4 + eb + eb) - eb)
     hbm_kernels = {}
@@ -276,14 +408,17 @@ def main():
                                                         ("gemm_kernel<float,EPI_BIAS_GELU> (fc1: [B*197,768]x[768,3072], "
                                                          "128x128-tile v_mfma_f32_32x32x2_f32 GEMM)"),
                      "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "TFLOP/s",
-                     "frac": round(achieved / peak, 4), "traffic": traffic, "pmc": pmc_mfma,
+                     "frac": round(achieved / peak, 4), "traffic": traffic,
+                     "traffic_source": (f"profiles/{os.path.basename(tpath)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                        "this command, committed; not measured in this run)") if traffic is not None else None,
+                     "pmc": pmc_mfma,
                      "algorithmic_bytes_per_launch": (M * 768 + 3072 * 768 + M * 3072) * (4.0 if short == "f32" else 2.0),
                      "avg_launch_ms": round(fc1_avg_s * 1e3, 4), "launches": fc1_n,
                      "algorithmic_flop_per_launch": flop_launch},
         "end_to_end_model_tflops": round(value * (FLOP_PER_PATCH_VIT_B16 if full_last else FLOP_PER_PATCH_EXECUTED) / 1e12 / world, 1),
         "flop_per_patch": {"model": FLOP_PER_PATCH_VIT_B16, "executed": FLOP_PER_PATCH_VIT_B16 if full_last else FLOP_PER_PATCH_EXECUTED,
                            "note": "last block: K/V for all tokens, the rest for the CLS row only (identical features); "
-                                   "AP_VIT_FULL_LAST_BLOCK=1 computes it for every token",
+                                   "option full_last_block (AP_VIT_FULL_LAST_BLOCK=1 at start) computes it for every token",
                            "value_with_full_last_block": None if full_value is None else round(full_value, 1)},
         "kernel_ms_per_step": kernel_ms, "hbm_kernels": hbm_kernels,
         "coords": {"cells": cells, "rows": int(n_slide), "seconds": round(coords_s, 4),
@@ -305,6 +440,9 @@ def main():
                                           "cores": 1, "kind": "port",
                                           "sample": "the bench slide's mask through oracle/coords_oracle.py (NumPy)",
                                           "rows_equal_device_path": bool(np.array_equal(np.asarray(cpu_coords), np.asarray(dev_coords)))}
+    if not args.no_extras and world == 1:
+        line["rates"] = {"kernel_only": {"patches_per_s": round(value, 1), "what": "= value"}}
+        line["rates"].update(secondary_rates(device, ex, tiles, B))
     print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

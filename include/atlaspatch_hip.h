@@ -171,6 +171,14 @@ void ap_vit_destroy(ap_vit* m);
 int ap_vit_set_param(ap_vit* m, const char* name, const float* host, size_t count);
 int ap_vit_finalize(ap_vit* m);   /* checks every parameter was set */
 
+/* Options (defaults: off; the environment variables AP_VIT_FULL_LAST_BLOCK / AP_VIT_OVERLAP set the defaults once, when
+ * the object is created -- nothing on the launch path reads the environment):
+ *   AP_VIT_OPT_FULL_LAST_BLOCK    compute the last block for every token instead of the CLS row only (same features)
+ *   AP_VIT_OPT_TWO_HALF_OVERLAP   run a batch >= 512 as two halves on two streams (same features) */
+#define AP_VIT_OPT_FULL_LAST_BLOCK 0
+#define AP_VIT_OPT_TWO_HALF_OVERLAP 1
+int ap_vit_set_option(ap_vit* m, int option, int value);
+
 size_t ap_vit_workspace_bytes(const ap_vit* m, int n);
 int ap_vit_embed_dim(const ap_vit* m);   /* dim (AP_POOL_CLS) or pool_dim (AP_POOL_ATTN) */
 
@@ -194,7 +202,7 @@ int ap_vit_profile_read(ap_vit* m, double* ms_by_kind, long long* launches_by_ki
 /* patches: device uint8 [n, h, w, 3]; centre-cropped to image_size, normalised with
  * mean/std, embedded.  out: device float32 [n, dim].  Asynchronous on `stream`.
  * For the CLS readout the last block computes K / V for every token and everything after that for the CLS row
- * only (nothing reads the other rows; identical features; AP_VIT_FULL_LAST_BLOCK=1 disables it). */
+ * only (nothing reads the other rows; identical features; AP_VIT_OPT_FULL_LAST_BLOCK disables it). */
 int ap_vit_forward_u8(ap_vit* m, const uint8_t* patches, int n, int h, int w,
                       const float mean[3], const float stdv[3],
                       float* out, void* workspace, size_t workspace_bytes, ap_stream_t stream);

@@ -269,3 +269,51 @@ def test_thumbnail_at_power_resizes_on_device_like_the_oracle(tmp_path):
     ds = 5 / 1.3
     want = R.resize(full, (int(round(3000 / ds)), int(round(2100 / ds))), R.INTER_AREA)
     assert np.array_equal(thumb2, want)
+
+
+# ----------------------------------------------------------------------------- exact-f32 MFMA GEMM of the SAM2 operator set
+@pytest.mark.parametrize("case", [
+    # batch, M, N, K, w_kn, act, bias, resid, alpha
+    (1, 65536, 96, 147, False, 0, True, True, 1.0),        # Hiera patch embed: K = 147 (scalar-load path), + pos embed
+    (1, 4096, 1152, 384, False, 0, True, False, 1.0),      # qkv of a stage-3 block
+    (1, 1000, 384, 96, False, 1, True, False, 1.0),        # ragged M, GELU
+    (1024, 64, 64, 96, False, 0, False, False, 0.1020620726),    # windowed q k^T, 64 x 64 tiles
+    (1024, 64, 96, 64, True, 0, False, False, 1.0),        # windowed P V (NN weight)
+    (3, 196, 49, 96, False, 0, False, False, 0.5),         # pooled-query window attention: N = 49
+    (3, 49, 96, 196, True, 0, False, False, 1.0),
+    (1, 9, 256, 2048, False, 2, True, True, 1.0),          # decoder MLP on 9 tokens, ReLU + residual
+    (1, 65536, 1, 32, False, 0, False, False, 1.0),        # final hypernetwork product: N = 1
+    (2, 130, 257, 70, True, 0, True, True, 2.0),           # odd everything, NN with ragged N (per-element loads)
+    (8, 9, 16, 4096, True, 0, False, False, 1.0),          # token-to-image P V: tiny output, long K -> split-K
+    (4, 4096, 96, 4096, True, 0, False, False, 1.0),       # global attention P V (heads as the batch, stride d)
+    (1, 1024, 768, 3072, False, 0, True, True, 1.0),       # stage-4 fc2: 48 tiles of 128 -> 64-tiles + split-K, bias + residual
+    (1, 70, 50, 1000, False, 1, True, False, 0.5),         # split-K with a ragged last chunk, GELU after the reduction
+])
+def test_sgemm_mfma_vs_torch(env, case):
+    """ap_sgemm (v_mfma_f32_32x32x2_f32, exact f32 products, f32 accumulation) vs torch fp32 matmul on the same operands:
+    only the summation order differs -> relative error of a few ulp * sqrt(K)."""
+    import ctypes as C
+    _lib, lib, dev, stream = env
+    batch, M, N, K, w_kn, act, use_bias, use_resid, alpha = case
+    g = torch.Generator(device=dev).manual_seed(M * 3 + N * 5 + K)
+    A = torch.randn((batch, M, K), device=dev, generator=g)
+    W = torch.randn((batch, K, N) if w_kn else (batch, N, K), device=dev, generator=g)
+    bias = torch.randn(N, device=dev, generator=g) if use_bias else None
+    resid = torch.randn((batch, M, N), device=dev, generator=g) if use_resid else None
+    out = torch.full((batch, M, N), float("nan"), device=dev)
+    _lib.check(lib.ap_sgemm(A.data_ptr(), K, M * K, W.data_ptr(), N if w_kn else K, N * K, 1 if w_kn else 0, batch, M, N, K,
+                            C.c_float(alpha), bias.data_ptr() if use_bias else None, act,
+                            resid.data_ptr() if use_resid else None, N, M * N, out.data_ptr(), N, M * N, stream), "ap_sgemm")
+    torch.cuda.synchronize()
+    ref = torch.matmul(A.double(), (W if w_kn else W.transpose(1, 2)).double()) * alpha
+    if use_bias:
+        ref = ref + bias.double()
+    if act == 1:
+        ref = torch.nn.functional.gelu(ref)
+    elif act == 2:
+        ref = torch.relu(ref)
+    if use_resid:
+        ref = ref + resid.double()
+    err = (out.double() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert torch.isfinite(out).all() and err <= 2e-6 * scale * max(1.0, K ** 0.5 / 4), (err, scale)

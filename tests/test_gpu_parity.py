@@ -87,10 +87,11 @@ def _hf_extractor(layers, dtype, **kw):
 #   element-wise max_ij |a_ij - b_ij| / (|b_ij| + 0.05 max|b|)    (ETOL; elements below 5 % of the feature scale are
 #                                                             compared on that absolute scale)
 #   float32 : BASELINE north_star tolerance 1e-3 on BOTH (exact-f32 MFMA measures ~1e-6 / ~1e-5)
-#   float16 : set from what is measured at full depth (norm-wise 0.9e-3 ViT-B/16) with 1.7 x
-#             headroom; bfloat16 has 8 x coarser operands
+#   float16 : set from what is measured (norm-wise 0.7e-3 at depth 2, 0.9e-3 at depth 12; element-wise -- a maximum
+#             over 25 000 elements, heavy tailed -- 1.1e-2) with ~2 x headroom;
+#             bfloat16 has 8 x coarser operands (measured 5.3e-3 / 1.2e-1)
 TOL = {torch.float32: 1e-3, torch.float16: 1.5e-3, torch.bfloat16: 1.2e-2}
-ETOL = {torch.float32: 1e-3, torch.float16: 1.5e-2, torch.bfloat16: 1.2e-1}
+ETOL = {torch.float32: 1e-3, torch.float16: 3e-2, torch.bfloat16: 2.5e-1}
 
 
 def _elem(a, b, floor=0.05):
@@ -394,7 +395,7 @@ def test_full_size_batch_properties():
 
 
 def test_two_half_overlap_mode_is_bit_identical():
-    """AP_VIT_OVERLAP=1 (opt-in): the batch runs as two halves on two streams; features are the same bits."""
+    """Option two_half_overlap (opt-in): the batch runs as two halves on two streams; features are the same bits."""
     import os
     from atlaspatch_amd.encoders.vit import ARCHS, build_hip_vit_extractor, random_canonical_state_dict
     arch = dict(ARCHS["vit_b_16"]); arch["depth"] = 3
@@ -405,15 +406,12 @@ def test_two_half_overlap_mode_is_bit_identical():
     ref = torch.empty((n, ex.embedding_dim), dtype=torch.float32, device=_dev())
     out = torch.empty_like(ref)
     ex.forward_device(tiles, ref)
-    os.environ["AP_VIT_OVERLAP"] = "1"
-    try:
-        for _ in range(5):
-            out.zero_()
-            ex.forward_device(tiles, out)
-            torch.cuda.synchronize()
-            assert torch.equal(out, ref)
-    finally:
-        os.environ.pop("AP_VIT_OVERLAP", None)
+    ex.vit.set_option("two_half_overlap", True)
+    for _ in range(5):
+        out.zero_()
+        ex.forward_device(tiles, out)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
     ex.cleanup()
 
 
@@ -422,7 +420,7 @@ def test_two_half_overlap_mode_is_bit_identical():
 @pytest.mark.parametrize("arch_name", ["vit_b_16", "uni_v1"])
 def test_cls_tail_equals_full_last_block(dtype, tol, arch_name):
     """The default forward computes the last block's K / V for every token and everything after for the CLS row only;
-    AP_VIT_FULL_LAST_BLOCK=1 runs the block for all tokens like the reference module does.  Same features (the CLS
+    option full_last_block runs the block for all tokens like the reference module does.  Same features (the CLS
     row never depends on the other rows' outputs of that block); tolerance = rounding differences of the one-row
     attention kernel (f32 softmax weights) vs the tiled one (weights rounded to T before the PV MFMA)."""
     import os
@@ -434,11 +432,8 @@ def test_cls_tail_equals_full_last_block(dtype, tol, arch_name):
     rng = np.random.default_rng(3)
     tiles = [rng.integers(0, 256, (256, 256, 3), dtype=np.uint8) for _ in range(5)]
     got = ex.extract_batch(tiles)
-    os.environ["AP_VIT_FULL_LAST_BLOCK"] = "1"
-    try:
-        want = ex.extract_batch(tiles)
-    finally:
-        os.environ.pop("AP_VIT_FULL_LAST_BLOCK", None)
+    ex.vit.set_option("full_last_block", True)
+    want = ex.extract_batch(tiles)
     ex.cleanup()
     assert _rel(got, want) <= tol, _rel(got, want)
 

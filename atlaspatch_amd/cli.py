@@ -148,9 +148,13 @@ def _run_pipeline(*, wsi_path, output, patch_size, step_size, target_mag, device
             from .orchestration.dispatch import gather_run_features, init_process_group
             dev = torch.device("cuda", local_rank) if torch.cuda.is_available() else None
             init_process_group(device=dev)
-            failed = {str(s.path) for s, _ in failures}
-            mine = [r.h5_path for r in results if str(r.slide.path) not in failed]
-            gather_run_features(mine, [e.lower() for e in app_cfg.features.extractors], app_cfg.output.output_root, device=dev)
+            # every slide assigned to this rank whose H5 is on disk -- also those a --skip-existing rerun found complete
+            # (they never enter `results`); slides without a usable feature set are skipped inside, never raised on
+            from .core.paths import patch_h5_path
+            mine = [p for p in (patch_h5_path(s, app_cfg.output, app_cfg.extraction) for s in runner.discover_slides())
+                    if p.exists()]
+            gather_run_features(mine, [e.lower() for e in app_cfg.features.extractors], app_cfg.output.output_root,
+                                device=dev, cache=service.feature_blocks)
     return results, failures
 
 

@@ -74,32 +74,67 @@ def gather_feature_matrix(local: torch.Tensor, group=None) -> list[torch.Tensor]
     return [out[r * width: r * width + rows[r]] for r in range(world)]
 
 
-def gather_run_features(h5_paths: Sequence, extractor_names: Sequence[str], out_root, *, device=None) -> dict:
+def _local_feature_block(path, name: str, cache: Optional[dict]):
+    """float32 [N, D] of ``features/<name>`` for one slide, or None (with the reason) when this rank cannot contribute it:
+    file or dataset missing (feature phase skipped because another process held the lock, an extractor that failed) or a
+    row count that disagrees with ``coords``.  Never raises: a rank that raised here would leave its peers blocked in the
+    collectives that follow."""
+    import numpy as np
+    from ..utils.h5 import h5
+    key = (str(path), name)
+    if cache is not None and key in cache:
+        return cache[key], None
+    try:
+        with h5.File(str(path), "r") as fh:
+            if "features" not in fh or name not in fh["features"]:
+                return None, "no such feature set"
+            feats = np.asarray(fh["features"][name][:], dtype=np.float32)
+            if feats.ndim != 2 or feats.shape[0] != fh["coords"].shape[0]:
+                return None, f"shape {feats.shape} does not match {fh['coords'].shape[0]} coords rows"
+        return feats, None
+    except Exception as exc:  # noqa: BLE001
+        return None, f"unreadable: {exc}"
+
+
+def gather_run_features(h5_paths: Sequence, extractor_names: Sequence[str], out_root, *, device=None,
+                        cache: Optional[dict] = None) -> dict:
     """Reassemble the feature matrices of a rank-sharded run on every rank (the one exchange step of the north star).
 
-    ``h5_paths``: this rank's ``<stem>.h5`` outputs, in processing order.  Per extractor: the rank's ``[sum N_i, D]``
-    block (its slides concatenated) goes through ONE all-gather-v (``gather_feature_matrix``); rank 0 writes
-    ``<out_root>/features_all/<extractor>.npy`` ([total, D] float32, ranks in order, slides in each rank's order) and
-    ``<extractor>.index.json`` (slide stem, rank, first row, rows).  Returns ``{extractor: [total, D] tensor}`` on every
-    rank.  A reference run has no such file: this is the MI355X multi-GPU addition, enabled by
-    ``ATLASPATCH_GATHER_FEATURES=1`` under ``torch.distributed.run``."""
+    ``h5_paths``: the ``<stem>.h5`` outputs of ALL slides assigned to this rank, in processing order -- including slides a
+    ``--skip-existing`` rerun found complete on disk.  ``cache``: ``{(h5 path, extractor): float32 [N, D] array or device
+    tensor}`` of feature blocks this process computed in this run (``PatchFeatureEmbeddingService.feature_blocks``); blocks
+    found there are not read back from disk.  Per extractor: the rank's ``[sum N_i, D]`` block (its slides concatenated)
+    goes through ONE all-gather-v (``gather_feature_matrix``); rank 0 writes ``<out_root>/features_all/<extractor>.npy``
+    ([total, D] float32, ranks in order, slides in each rank's order) and ``<extractor>.index.json`` (slide stem, rank,
+    first row, rows; slides that could not contribute are listed with ``"rows": 0`` and the reason).  A slide whose feature
+    set is missing is skipped with a warning on its own rank -- nothing raises before or between the collectives, so no
+    rank can leave the others waiting.  Returns ``{extractor: [total, D] tensor}`` on every rank.  A reference run has no
+    such file: this is the MI355X multi-GPU addition, enabled by ``ATLASPATCH_GATHER_FEATURES=1`` under
+    ``torch.distributed.run``."""
     import json
+    import logging
     from pathlib import Path
     import numpy as np
     import torch.distributed as dist
-    from ..utils.h5 import h5
+    log = logging.getLogger("atlaspatch_amd.dispatch")
     rank, world, _ = env_rank_world()
     dev = torch.device(device) if device is not None else torch.device("cpu")
     merged: dict = {}
     for name in extractor_names:
         blocks, index = [], []
         for path in h5_paths:
-            with h5.File(str(path), "r") as fh:
-                feats = np.asarray(fh["features"][name][:], dtype=np.float32)
-            index.append({"slide": Path(str(path)).stem, "rank": rank, "rows": int(feats.shape[0])})
-            blocks.append(torch.from_numpy(feats))
+            feats, why = _local_feature_block(path, name, cache)
+            entry = {"slide": Path(str(path)).stem, "rank": rank, "rows": 0}
+            if feats is None:
+                log.warning("gather: %s has no usable '%s' features (%s); skipped", path, name, why)
+                entry["skipped"] = why
+            else:
+                block = feats if torch.is_tensor(feats) else torch.from_numpy(np.ascontiguousarray(feats, dtype=np.float32))
+                entry["rows"] = int(block.shape[0])
+                blocks.append(block.to(dev, dtype=torch.float32))
+            index.append(entry)
         dim = blocks[0].shape[1] if blocks else 0
-        local = (torch.cat(blocks, 0) if blocks else torch.zeros((0, dim), dtype=torch.float32)).to(dev)
+        local = torch.cat(blocks, 0) if blocks else torch.zeros((0, dim), dtype=torch.float32, device=dev)
         parts = gather_feature_matrix(local)
         width = max((p.shape[1] for p in parts if p.dim() == 2 and p.shape[0]), default=dim)
         whole = torch.cat([p if p.shape[0] else p.reshape(0, width) for p in parts], 0) if parts else local

@@ -83,6 +83,10 @@ class PatchFeatureEmbeddingService(FeatureEmbeddingService):
         self.extractor_names = [name.lower() for name in self.feature_cfg.extractors]
         self._seen: dict[Path, tuple[int | None, set[str]]] = {}
         self._ring = None
+        # (h5 path, extractor) -> float32 [N, D] computed in this run; kept only when the rank-sharded gather will use
+        # them (ATLASPATCH_GATHER_FEATURES), so that the all-gather does not read the matrices back from disk
+        self.feature_blocks: dict = {}
+        self._keep_blocks = bool(os.environ.get("ATLASPATCH_GATHER_FEATURES"))
 
     # ------------------------------------------------------------------ bookkeeping
     def _existing(self, h5_path: Path, expected_total: int | None = None) -> set[str]:
@@ -185,6 +189,8 @@ class PatchFeatureEmbeddingService(FeatureEmbeddingService):
             writer = self._writer(result, wsi)
             if isinstance(extractor, HipViTFeatureExtractor):
                 feats = self.embed_matrix(result, wsi, extractor)
+                if self._keep_blocks:
+                    self.feature_blocks[(str(result.h5_path), extractor.name.lower())] = feats
                 writer.append_feature_matrix(output_path=result.h5_path, feature_name=extractor.name,
                                              features=feats, feature_attrs=attrs,
                                              feature_batch=self.feature_cfg.batch_size,

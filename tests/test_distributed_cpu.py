@@ -74,16 +74,23 @@ def _gather_worker(rank, world, port, tmp):
                       LOCAL_RANK=str(rank))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        # rank 0 owns slides a (3 rows) and c (2 rows), rank 1 owns b (4 rows): features = slide id + row / 10
-        mine = {0: [("a", 3, 1.0), ("c", 2, 3.0)], 1: [("b", 4, 2.0)]}[rank]
-        paths = []
+        # rank 0 owns slides a (3 rows) and c (2 rows), rank 1 owns b (4 rows) and d; features = slide id + row / 10.
+        # d has coords but NO feature set (its feature phase was skipped: lock held elsewhere): it must be skipped on rank 1
+        # without raising -- a raise before the collectives would leave rank 0 waiting forever.  c's block comes from the
+        # in-run cache (its H5 holds no features at all), like a block the embedding service just computed.
+        mine = {0: [("a", 3, 1.0), ("c", 2, 3.0)], 1: [("b", 4, 2.0), ("d", 6, None)]}[rank]
+        paths, cache = [], {}
         for stem, rows, base in mine:
             p = os.path.join(tmp, f"{stem}.h5")
+            feats = None if base is None else (base + np.arange(rows)[:, None] / 10 + np.zeros((rows, 5))).astype(np.float32)
             with h5.File(p, "w") as fh:
-                grp = fh.create_group("features")
-                grp.create_dataset("enc", data=(base + np.arange(rows)[:, None] / 10 + np.zeros((rows, 5))).astype(np.float32))
+                fh.create_dataset("coords", data=np.zeros((rows, 5), np.int32))
+                if feats is not None and stem != "c":
+                    fh.create_group("features").create_dataset("enc", data=feats)
+            if stem == "c":
+                cache[(p, "enc")] = feats
             paths.append(p)
-        merged = gather_run_features(paths, ["enc"], os.path.join(tmp, "out"))
+        merged = gather_run_features(paths, ["enc"], os.path.join(tmp, "out"), cache=cache)
         assert merged["enc"].shape == (9, 5)
         assert torch.allclose(merged["enc"][:, 0], torch.tensor([1.0, 1.1, 1.2, 3.0, 3.1, 2.0, 2.1, 2.2, 2.3]))
         dist.barrier()
@@ -92,7 +99,8 @@ def _gather_worker(rank, world, port, tmp):
             index = json.load(open(os.path.join(tmp, "out", "features_all", "enc.index.json")))
             assert whole.shape == (9, 5) and whole.dtype == np.float32
             assert [(r["slide"], r["rank"], r["first_row"], r["rows"]) for r in index] == \
-                [("a", 0, 0, 3), ("c", 0, 3, 2), ("b", 1, 5, 4)]
+                [("a", 0, 0, 3), ("c", 0, 3, 2), ("b", 1, 5, 4), ("d", 1, 9, 0)]
+            assert "skipped" in index[3] and "skipped" not in index[0]
         np.save(os.path.join(tmp, f"gok{rank}.npy"), np.array([1]))
     finally:
         dist.destroy_process_group()

@@ -14,6 +14,7 @@ AP_OK = 0
 PROF_KINDS = ("preproc", "gemm_patch_embed", "gemm_qkv", "gemm_proj", "gemm_fc1", "gemm_fc2",
               "attention", "layernorm", "cls_tail")
 AP_ERR_CAPACITY = -6
+AP_ERR_UNSUPPORTED = -4
 
 _LIB_NAME = "libatlaspatch_hip.so"
 _lock = threading.Lock()
@@ -43,6 +44,7 @@ SIGNATURES = {
                                                 C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float),
                                                 C.POINTER(C.c_float), C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ap_host_inflate_tiles": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.c_int, C.c_size_t]),
+    "ap_host_decode_jpeg_tiles": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.c_int, C.c_int]),
     "ap_host_gather_tiles": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_size_t]),
     "ap_host_synth_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                       C.c_uint32, C.c_void_p, C.c_int]),

@@ -152,15 +152,27 @@ class SynthWSI(IWSI):
                                                        lv0, self.spec.width, self.spec.height, self.spec.seed,
                                                        ell.ctypes.data, ell.shape[0]), "ap_host_synth_tiles")
             return True
-        paths = []
-        for x, y, rw, rh, lv in rows:
-            p = os.path.join(self.jpeg_dir, f"{int(x)}_{int(y)}_{int(rw)}.z")
-            if lv != 0 or not os.path.exists(p):
-                return False
-            paths.append(p.encode())
-        arr = (C.c_char_p * len(paths))(*paths)
-        _lib.check(_lib.load().ap_host_inflate_tiles(dst_ptr, arr, len(paths), tile_side * tile_side * 3),
-                   "ap_host_inflate_tiles")
+        lib = _lib.load()
+        stems = [os.path.join(self.jpeg_dir, f"{int(x)}_{int(y)}_{int(rw)}") for x, y, rw, rh, lv in rows]
+        if lv0 != 0:
+            return False
+        kind = getattr(self, "_store_kind", None)
+        if kind is None:                                   # one probe per slide: the store holds one kind of file
+            kind = self._store_kind = ".z" if os.path.exists(stems[0] + ".z") else ".jpg"
+        if kind == ".jpg" and getattr(self, "_jpeg_native", True) is False:
+            return False
+        files = [s + kind for s in stems]
+        if not all(os.path.exists(f) for f in files):      # a tile the store does not hold is rendered by the per-tile path
+            return False
+        arr = (C.c_char_p * len(files))(*[f.encode() for f in files])
+        if kind == ".z":
+            _lib.check(lib.ap_host_inflate_tiles(dst_ptr, arr, len(stems), tile_side * tile_side * 3), "ap_host_inflate_tiles")
+            return True
+        code = lib.ap_host_decode_jpeg_tiles(dst_ptr, arr, len(stems), tile_side)
+        if code == _lib.AP_ERR_UNSUPPORTED:                # no usable libjpeg on this host: per-tile Pillow decode
+            self._jpeg_native = False
+            return False
+        _lib.check(code, "ap_host_decode_jpeg_tiles")
         return True
 
     def get_size(self, lv: int = 0) -> Tuple[int, int]:

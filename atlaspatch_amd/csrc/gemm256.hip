@@ -167,12 +167,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
     // Start-time skew: equal tiles keep every CU in step, so all epilogues (the HBM write bursts)
     // would coincide.  Workgroup j of an XCD starts j / nwx of a tile period late; the early ones are
     // the ones that own one tile more.
+    // (diagnostics -- start skew, per-tile time stamps, ablation flags -- exist only in the -DAP_G256_ALT twin, impl 257)
+#ifdef AP_G256_ALT
     if (g.skew_ticks > 0) {
         const int nx = gridDim.x < 8 ? gridDim.x : 8;
         const long long until = (long long)__builtin_amdgcn_s_memrealtime() +
                                 (long long)g.skew_ticks * (int)(blockIdx.x / nx) / tw.stride;
         while ((long long)__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(16);
     }
+#endif
 
     // ---- staging plan.  Round j of a unit covers unit rows j*64 + wave*8 + (lane >> 3); the lane's
     //      16-byte source chunk is swizzled by the LDS row it lands on.
@@ -379,6 +382,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
     };
 
     char* scr = smem + kScratchOff + wave * 4096;
+#ifdef AP_G256_ALT
     auto stamp = [&](int ti, int k) {
         if (g.trace && ti < g.trace_tiles && threadIdx.x == 0)
             g.trace[((size_t)blockIdx.x * g.trace_tiles + ti) * 8 + k] = (long long)__builtin_amdgcn_s_memrealtime();
@@ -387,6 +391,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
         if (g.trace && ti < g.trace_tiles && threadIdx.x == 0)
             g.trace[((size_t)blockIdx.x * g.trace_tiles + ti) * 8 + k] = (long long)__builtin_amdgcn_s_memtime();
     };
+#else
+    auto stamp = [](int, int) {};
+    auto stamp_clk = [](int, int) {};
+#endif
     for (int ti = 0; ti < tw.count; ++ti) {
         stamp(ti, 0);
         stamp_clk(ti, 5);
@@ -422,7 +430,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
         const int m0 = tr * kBM + wr * 128, n0 = tc * kBN + wc * 64;
         const bool has_gamma = EPI != EPI_BIAS_GELU && g.gamma != nullptr;
         const float* gp = g.gamma + n0 + hi * 4;
+#ifdef AP_G256_ALT
         if (g.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(ti, 3); }
+#endif
         const int rrow = lane_e >> 3, rc = lane_e & 7;
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
@@ -549,12 +559,16 @@ int AP_G256_FN(launch_gemm256)(int dtype, int epilogue, const GemmArgs& a, int v
     }
     AP_REQUIRE(AP_G256_FN(gemm256_supports)(dtype, epilogue, a), "gemm256: unsupported problem");
     GemmArgs b = a;
+#ifdef AP_G256_ALT
     b.trace = g_gemm_trace; b.trace_tiles = g_gemm_trace_tiles;
     const int skew_pct = (variant >> 4) & 0xfff;
     const int tiles = ((a.M + kBM - 1) / kBM) * (a.N / kBN);
     // estimated tile period in 10-ns ticks: ~1.65 us per 64-deep K-tile + epilogue
     b.skew_ticks = tiles > num_cu ? (int)((long long)((a.K / 64) * 165 + 400) * skew_pct / 100) : 0;
     b.ablate = variant & 15;
+#else
+    b.trace = nullptr; b.trace_tiles = 0; b.skew_ticks = 0; b.ablate = 0;
+#endif
     if ((variant >> 16) & 15) b.walk_cols = (variant >> 16) & 15;
     variant &= 15;
     return dtype == AP_F16 ? launch_typed<f16>(epilogue, b, num_cu, variant, stream)

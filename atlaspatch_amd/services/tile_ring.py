@@ -47,7 +47,23 @@ class TileRing:
         self.free_events: list[torch.cuda.Event | None] = [None] * self.slots
         self.workers = max(1, int(workers))
         self._lib = _lib.load()
-        self.pool = futures.ThreadPoolExecutor(max_workers=self.workers, thread_name_prefix="tile")
+        # decode threads pinned one per host core (north star: "tile decode on host cores pinned"): a thread that stays on
+        # its core keeps its decoder state and the pinned slot's lines warm; the cores come from the process's own
+        # affinity mask, the first one is left to the main thread that drives the streams.  ATLASPATCH_PIN_THREADS=0 disables.
+        import itertools
+        import os
+        cores = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []
+        pin = os.environ.get("ATLASPATCH_PIN_THREADS", "1") != "0" and len(cores) > 1
+        counter = itertools.count()
+
+        def _pin_worker():
+            if pin:
+                try:
+                    os.sched_setaffinity(0, {cores[1 + next(counter) % (len(cores) - 1)]})      # pid 0 = the calling thread
+                except OSError:
+                    pass
+
+        self.pool = futures.ThreadPoolExecutor(max_workers=self.workers, thread_name_prefix="tile", initializer=_pin_worker)
 
     def run(self, coords: np.ndarray, read_tile: Callable[[int, int, int, int, int], np.ndarray],
             forward: Callable[[torch.Tensor, torch.Tensor], None], out_dim: int, *,

@@ -151,6 +151,68 @@ def _timed_forward(ex, tiles, steps, warm=1):
     return steps * tiles.shape[0] / (time.perf_counter() - t0)
 
 
+def jpeg_store_rate(device, tmp):
+    """Build a JPEG tile store for the 100 000^2 slide (untimed: pixels from the device generator, Pillow encoders on a
+    thread pool), then time `process` on it end to end."""
+    import concurrent.futures as futures
+    from click.testing import CliRunner
+    from PIL import Image
+    from atlaspatch_amd import _lib
+    from atlaspatch_amd.cli import cli
+    from atlaspatch_amd.core.wsi.synth_pixels import SynthSpec, analytic_mask
+    from atlaspatch_amd.services.extraction import coords_from_mask
+    from atlaspatch_amd.utils.h5 import h5
+    side = 100000
+    spec = SynthSpec(width=side, height=side, seed=1234)
+    coords, _ = coords_from_mask(analytic_mask(spec), level0_wh=(side, side), downsamples=list(spec.downsamples),
+                                 src_mag=spec.mag, tgt_mag=spec.mag, patch_size=256, step_size=None, tissue_thresh=0.0)
+    store = os.path.join(tmp, "jpeg_tiles")
+    os.makedirs(store)
+    lib = _lib.load()
+    ell = torch.from_numpy(spec.ellipses()).to(device)
+    workers = min(64, os.cpu_count() or 8)
+    t0 = time.perf_counter()
+    with futures.ThreadPoolExecutor(workers) as pool:
+        for lo in range(0, len(coords), 4096):
+            xy = torch.from_numpy(np.ascontiguousarray(coords[lo:lo + 4096, :2], dtype=np.int32)).to(device)
+            dev_tiles = torch.empty((xy.shape[0], 256, 256, 3), dtype=torch.uint8, device=device)
+            _lib.check(lib.ap_synth_tiles(xy.data_ptr(), xy.shape[0], 256, 1, 0, side, side, spec.seed, ell.data_ptr(),
+                                          ell.shape[0], dev_tiles.data_ptr(), _lib.current_stream_ptr(device)))
+            host = dev_tiles.cpu().numpy()
+            list(pool.map(lambda i: Image.fromarray(host[i]).save(
+                os.path.join(store, f"{coords[lo + i, 0]}_{coords[lo + i, 1]}_256.jpg"), quality=80), range(host.shape[0])))
+    build_s = time.perf_counter() - t0
+    size_mb = sum(os.path.getsize(os.path.join(store, f)) for f in os.listdir(store)) / 1e6
+    slide = os.path.join(tmp, "bigjpeg.synth")
+    json.dump({"width": side, "height": side, "seed": 1234, "mag": 20, "mpp": 0.5, "downsamples": [1, 4, 16],
+               "jpeg_tiles": "jpeg_tiles"}, open(slide, "w"))
+    old = {k: os.environ.get(k) for k in ("ATLASPATCH_WEIGHTS_DIR", "ATLASPATCH_RANDOM_INIT")}
+    os.environ["ATLASPATCH_WEIGHTS_DIR"] = tmp
+    os.environ.pop("ATLASPATCH_RANDOM_INIT", None)
+    try:
+        out_dir = os.path.join(tmp, "out_jpeg")
+        t0 = time.perf_counter()
+        res = CliRunner().invoke(cli, ["process", slide, "-o", out_dir, "--patch-size", "256", "--target-mag", "20",
+                                       "--feature-extractors", "vit_b_16", "--feature-precision", "float16",
+                                       "--feature-num-workers", str(workers)], catch_exceptions=False)
+        dt = time.perf_counter() - t0
+        assert res.exit_code == 0 and "failures: 0" in res.output, res.output
+        with h5.File(os.path.join(out_dir, "patches", "bigjpeg.h5"), "r") as f:
+            n = int(f["coords"].shape[0])
+            assert f["features"]["vit_b_16"].shape == (n, 768)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return {"patches_per_s": round(n / dt, 1), "tiles": n, "seconds": round(dt, 3), "host_threads": workers,
+            "store_MB": round(size_mb, 1), "store_build_seconds_untimed": round(build_s, 1),
+            "what": "`process` on the 100000x100000 slide with its 58938 tiles stored as JPEG files (q80, 4:2:0): file read + "
+                    "libjpeg-turbo decode on pinned host threads through the native batched hook (outside the interpreter "
+                    "lock) -> pinned ring -> H2D -> K1 + ViT-B/16 f16 -> H5"}
+
+
 def secondary_rates(device, ex, tiles, B):
     """Rates that are NOT `value` (outside its timed region), measured in the same process so that the driver's line
     carries them: PCIe-inclusive ring, end-to-end CLI on the 100 000^2 slide (device tile source / host ring with the
@@ -233,6 +295,9 @@ def secondary_rates(device, ex, tiles, B):
                         os.environ.pop(k, None)
                     else:
                         os.environ[k] = v
+        # ---- (3b) the same slide with its tiles stored as JPEG files (quality 80, 4:2:0), decoded by the ring's pinned host
+        #      threads through the native batched decoder (ap_host_decode_jpeg_tiles, libjpeg-turbo outside the interpreter lock)
+        rates["e2e_cli_100k_jpeg_store"] = jpeg_store_rate(device, tmp)
     # ---- (4) float32 mode (the 1e-3 parity mode): value + fc1 roofline fraction against the f32 MFMA peak
     Bf = 512
     ex32 = build_hip_vit_extractor(name="vit_b_16", arch="vit_b_16", device=device, dtype=torch.float32,

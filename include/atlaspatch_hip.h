@@ -74,6 +74,13 @@ int ap_host_gather_tiles(void* dst, const void* const* src, int n, size_t bytes_
  * format takes (the reference's per-tile Python read, services/feature_embedding.py:86-95, cannot leave the interpreter). */
 int ap_host_inflate_tiles(void* dst, const char* const* paths, int n, size_t bytes_each);
 
+/* The same for tiles stored as baseline JPEG files (what a real slide's tiles are; core/wsi/openslide_wsi.py:184-205 decodes
+ * them one by one in the interpreter): reads and decodes n files into consecutive side x side x 3 RGB slots with the
+ * system's libjpeg-turbo (libjpeg.so.8, loaded on first use; the pixels are the ones PIL's Image.open(...).convert("RGB")
+ * gives).  AP_ERR_UNSUPPORTED when that library is not usable on this host (the caller then decodes tile by tile),
+ * AP_ERR_INVALID for a tile that is not side x side or not decodable. */
+int ap_host_decode_jpeg_tiles(void* dst, const char* const* paths, int n, int side);
+
 /* Host twin of ap_synth_tiles (below): renders n square tiles of a synthetic slide into consecutive slots of a pinned
  * staging buffer, outside the interpreter lock -- the synthetic slide's "native decoder" behind the ring's batched read
  * hook, so the host -> ring -> HBM path can be driven at full rate on the 100 000 x 100 000 slide.  xy: HOST int32 [n, 2]
@@ -232,8 +239,8 @@ int ap_gemm(int dtype, int epilogue, const void* A, int lda, const void* W, int 
             int M, int N, int K, const float* bias, const float* gamma, void* out, int ldo,
             int impl, int variant, ap_stream_t stream);
 
-/* Diagnostics for the persistent kernel: when device_buf is non-null every later impl-256 launch
- * records, per (workgroup, tile) with tile < tiles_per_workgroup, eight int64 stamps of the
+/* Diagnostics for the persistent kernel's instrumented twin (impl 257; the product kernel, impl 256, carries no
+ * diagnostic code): when device_buf is non-null every later impl-257 launch records, per (workgroup, tile) with tile < tiles_per_workgroup, eight int64 stamps of the
  * 100-MHz wall clock: [0] tile start, [1] K loop done, [2] staged stream drained, [3] bias loaded,
  * [4] epilogue done.  device_buf: int64 [grid, tiles_per_workgroup, 8].  Pass NULL to switch off. */
 int ap_gemm_trace(long long* device_buf, int tiles_per_workgroup);

@@ -355,3 +355,115 @@ def test_no_fast_mode_and_save_images_on_a_mag40_slide(tmp_path):
         x, y = int(coords[r, 0]), int(coords[r, 1])
         png = np.asarray(Image.open(out / "images" / "f40" / f"f40_x{x}_y{y}.png"))
         assert np.array_equal(png, cv2_resize.resize(render_region(spec, x, y, 512, 512, 0), (256, 256)))
+
+
+def test_segment_and_get_coords_on_a_cmu1_shaped_slide(tmp_path):
+    """BASELINE config 1's stand-in (CMU-1.svs, OpenSlide and the SAM2 checkpoint are absent): a synthetic slide with
+    CMU-1's geometry -- 46000 x 32914 at 20x, mpp 0.499, level downsamples (1, 4.0001, 16.00097) -- through
+    `segment-and-get-coords`.  The 1.25x thumbnail level is picked by the |d - t| < 0.01 exact-match rule
+    (iwsi.py:325-358), the mask is 733 x 1024, sx = 46000 / 1024; coords equal the CPU oracle row for row and the H5
+    carries the reference's attrs."""
+    from click.testing import CliRunner
+    from atlaspatch_amd.cli import cli
+    from atlaspatch_amd.core.wsi.synth_pixels import SynthSpec, analytic_mask
+    from atlaspatch_amd.utils.h5 import h5
+    from oracle import coords_oracle
+    ds = [1.0, 4.000121536217793, 16.000972053462940]
+    slide, raw = _make_slide(str(tmp_path), "cmu1.synth", width=46000, height=32914, mag=20, mpp=0.499, seed=11,
+                             downsamples=ds)
+    out = tmp_path / "out"
+    res = CliRunner().invoke(cli, ["segment-and-get-coords", slide, "-o", str(out), "--patch-size", "256",
+                                   "--target-mag", "20"], catch_exceptions=False)
+    assert res.exit_code == 0 and "failures: 0" in res.output, res.output
+    spec = SynthSpec(width=46000, height=32914, seed=11, mag=20, mpp=0.499, downsamples=tuple(ds))
+    mask = analytic_mask(spec)
+    assert mask.shape == (733, 1024)
+    want, _ = coords_oracle.coords_from_mask(mask, level0_wh=(46000, 32914), downsamples=ds, src_mag=20, tgt_mag=20,
+                                             patch_size=256, step_size=None, tissue_thresh=0.0)
+    with h5.File(out / "patches" / "cmu1.h5", "r") as f:
+        coords = f["coords"][:]
+        assert f.attrs["level0_width"] == 46000 and f.attrs["level0_height"] == 32914
+        assert f.attrs["patch_size_level0"] == 256 and f.attrs["level0_magnification"] == 20
+        assert f["passports"].shape[0] == coords.shape[0]
+    assert coords.shape[0] > 1000 and np.array_equal(coords, want)
+    assert (coords[:, 2] == 256).all() and (coords[:, 4] == 0).all()
+
+
+def test_process_100k_slide_through_the_host_ring_uni_v1(tmp_path, monkeypatch):
+    """BASELINE config 3 at full size: `process` on the 100 000 x 100 000 synthetic slide with uni_v1 (ViT-L/16 +
+    LayerScale, float16), tiles produced on HOST threads (the native renderer standing in for a slide decoder), crossing
+    the pinned ring -> H2D -> device resize (256 -> 224 bicubic) -> encoder.  58 938 rows; coords equal the oracle;
+    sampled feature rows equal a direct forward of the same tiles (bit for bit: the ring adds no arithmetic) and the
+    fp32 oracle within the float16 tolerance."""
+    from click.testing import CliRunner
+    from PIL import Image
+    from atlaspatch_amd.cli import cli
+    from atlaspatch_amd.core.wsi.synth_pixels import SynthSpec, analytic_mask, render_region
+    from atlaspatch_amd.encoders import build_default_registry
+    from atlaspatch_amd.encoders.vit import ARCHS, random_canonical_state_dict
+    from atlaspatch_amd.utils.h5 import h5
+    from oracle import coords_oracle, vit_oracle
+    monkeypatch.setenv("ATLASPATCH_RANDOM_INIT", "0")
+    monkeypatch.setenv("ATLASPATCH_HOST_TILES", "1")
+    slide, raw = _make_slide(str(tmp_path), "big.synth", width=100000, height=100000, seed=1234)
+    out = tmp_path / "out"
+    res = CliRunner().invoke(cli, ["process", slide, "-o", str(out), "--patch-size", "256", "--target-mag", "20",
+                                   "--feature-extractors", "uni_v1", "--feature-precision", "float16",
+                                   "--feature-num-workers", "32"], catch_exceptions=False)
+    assert res.exit_code == 0 and "failures: 0" in res.output, res.output
+    spec = SynthSpec(width=100000, height=100000, seed=1234)
+    want_coords, _ = coords_oracle.coords_from_mask(
+        analytic_mask(spec), level0_wh=(100000, 100000), downsamples=[1.0, 4.0, 16.0], src_mag=20, tgt_mag=20,
+        patch_size=256, step_size=None, tissue_thresh=0.0)
+    with h5.File(out / "patches" / "big.h5", "r") as f:
+        coords = f["coords"][:]
+        feats = f["features"]["uni_v1"][:]
+    assert coords.shape[0] == 58938 and np.array_equal(coords, want_coords)
+    assert feats.shape == (58938, 1024) and np.isfinite(feats).all()
+    rows = np.array([0, 1, 2047, 2048, 30000, 58937])
+    tiles = [render_region(spec, int(coords[r, 0]), int(coords[r, 1]), 256, 256, 0) for r in rows]
+    ex = build_default_registry(device="cuda", dtype=torch.float16).create("uni_v1")
+    direct = ex.extract_batch(tiles, batch_size=32)
+    ex.cleanup()
+    assert np.array_equal(feats[rows], direct)
+    sd = random_canonical_state_dict(ARCHS["uni_v1"], 0)
+    pre = np.stack([np.asarray(Image.fromarray(t).resize((224, 224), Image.Resampling.BICUBIC)) for t in tiles], 0)
+    want = vit_oracle.vit_tokens_canonical(sd, vit_oracle.preprocess_center_crop(pre, crop=224), heads=16, depth=24)[:, 0].numpy()
+    rel = np.linalg.norm(feats[rows] - want) / np.linalg.norm(want)
+    assert rel <= 1.5e-3, rel
+
+
+def test_process_jpeg_tile_store_through_the_native_decoder(tmp_path, monkeypatch):
+    """A slide whose tiles are JPEG files (the stand-in for a real slide's compressed tiles): the ring's pinned host
+    threads decode chunks through ap_host_decode_jpeg_tiles (libjpeg-turbo, outside the interpreter lock).  Features equal
+    a direct forward of the Pillow-decoded tiles bit for bit (same pixels in, same kernels)."""
+    from click.testing import CliRunner
+    from PIL import Image
+    from atlaspatch_amd.cli import cli
+    from atlaspatch_amd.core.wsi.synth_pixels import SynthSpec, analytic_mask, render_region
+    from atlaspatch_amd.encoders import build_default_registry
+    from atlaspatch_amd.services.extraction import coords_from_mask
+    from atlaspatch_amd.utils.h5 import h5
+    monkeypatch.setenv("ATLASPATCH_RANDOM_INIT", "0")
+    store = tmp_path / "tiles"
+    store.mkdir()
+    slide, raw = _make_slide(str(tmp_path), "j.synth", width=14000, height=10000, jpeg_tiles="tiles")
+    spec = SynthSpec(width=14000, height=10000, seed=raw["seed"])
+    coords, _ = coords_from_mask(analytic_mask(spec), level0_wh=(14000, 10000), downsamples=[1.0, 4.0, 16.0], src_mag=20,
+                                 tgt_mag=20, patch_size=256, step_size=None, tissue_thresh=0.0)
+    for x, y in coords[:, :2]:
+        Image.fromarray(render_region(spec, int(x), int(y), 256, 256, 0)).save(str(store / f"{x}_{y}_256.jpg"), quality=80)
+    out = tmp_path / "out"
+    res = CliRunner().invoke(cli, ["process", slide, "-o", str(out), "--patch-size", "256", "--target-mag", "20",
+                                   "--feature-extractors", "vit_b_16", "--feature-precision", "float16",
+                                   "--feature-num-workers", "8"], catch_exceptions=False)
+    assert res.exit_code == 0 and "failures: 0" in res.output, res.output
+    with h5.File(out / "patches" / "j.h5", "r") as f:
+        got_coords, feats = f["coords"][:], f["features"]["vit_b_16"][:]
+    assert np.array_equal(got_coords, coords) and coords.shape[0] > 100
+    rows = np.linspace(0, coords.shape[0] - 1, 16).astype(int)
+    tiles = [np.asarray(Image.open(str(store / f"{coords[r, 0]}_{coords[r, 1]}_256.jpg")).convert("RGB")) for r in rows]
+    ex = build_default_registry(device="cuda", dtype=torch.float16).create("vit_b_16")
+    want = ex.extract_batch(tiles, batch_size=32)
+    ex.cleanup()
+    assert np.array_equal(feats[rows], want)

@@ -395,3 +395,57 @@ def test_transform_resize_table():
     from atlaspatch_amd.encoders.vit import TRANSFORM_RESIZE
     assert TRANSFORM_RESIZE["vit_b_16"] == (256, "bilinear") and TRANSFORM_RESIZE["vit_l_16"] == (242, "bilinear")
     assert TRANSFORM_RESIZE["uni_v1"] == (224, "bicubic") and TRANSFORM_RESIZE["conch_v1"] == (448, "bicubic")
+
+
+# ----------------------------------------------------------------------------- native host tile sources of the ring
+def test_host_synth_tiles_equal_the_numpy_renderer():
+    """ap_host_synth_tiles (the synthetic slide's native 'decoder' behind read_tiles_into) == render_region bit for bit,
+    for level 0, a 512-px read and a downsampled level, including out-of-bounds pixels."""
+    import ctypes as C
+    from atlaspatch_amd import _lib
+    from atlaspatch_amd.core.wsi.synth_pixels import SynthSpec, render_region
+    lib = _lib.load()
+    spec = SynthSpec(width=40000, height=40000)
+    xy = np.array([[0, 0], [12800, 20224], [39900, 39900], [-100, 500], [20000, 20000]], np.int32)
+    ell = np.ascontiguousarray(spec.ellipses())
+    for side, ds, lv in ((256, 1, 0), (512, 1, 0), (64, 4, 1)):
+        out = np.empty((len(xy), side, side, 3), np.uint8)
+        _lib.check(lib.ap_host_synth_tiles(out.ctypes.data, xy.ctypes.data, len(xy), side, ds, lv, spec.width, spec.height,
+                                           spec.seed, ell.ctypes.data, ell.shape[0]))
+        for i, (x, y) in enumerate(xy):
+            assert np.array_equal(out[i], render_region(spec, int(x), int(y), side, side, lv)), (side, i)
+
+
+def test_native_jpeg_tile_decode_equals_pillow(tmp_path):
+    """ap_host_decode_jpeg_tiles (system libjpeg-turbo behind restated declarations, validated by the library's own
+    struct-size check and a load-time self-check) == PIL's Image.open(...).convert("RGB") bit for bit: 4:2:0 / 4:4:4
+    chroma, two qualities, noise, a greyscale stream; a tile of the wrong size is an error, not garbage."""
+    import ctypes as C
+    from PIL import Image
+    from atlaspatch_amd import _lib
+    from atlaspatch_amd.core.wsi.synth_pixels import SynthSpec, render_region
+    lib = _lib.load()
+    spec = SynthSpec(width=40000, height=40000)
+    rng = np.random.default_rng(0)
+    paths, want = [], []
+    for i, (x, y) in enumerate([(12800, 20224), (20000, 20000), (0, 0), (15000, 9000)]):
+        tile = render_region(spec, x, y, 256, 256, 0) if i != 3 else rng.integers(0, 256, (256, 256, 3), dtype=np.uint8)
+        p = str(tmp_path / f"{i}.jpg")
+        Image.fromarray(tile).save(p, quality=95 if i == 2 else 80, subsampling=0 if i == 1 else 2)
+        paths.append(p)
+    p = str(tmp_path / "grey.jpg")
+    Image.fromarray(render_region(spec, 100, 100, 256, 256, 0)).convert("L").save(p, quality=80)
+    paths.append(p)
+    want = [np.asarray(Image.open(p).convert("RGB")) for p in paths]
+    out = np.zeros((len(paths), 256, 256, 3), np.uint8)
+    arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+    rc = lib.ap_host_decode_jpeg_tiles(out.ctypes.data, arr, len(paths), 256)
+    if rc == _lib.AP_ERR_UNSUPPORTED:
+        pytest.skip("no usable libjpeg.so.8 on this host: " + lib.ap_last_error().decode())
+    _lib.check(rc, "ap_host_decode_jpeg_tiles")
+    for i in range(len(paths)):
+        assert np.array_equal(out[i], want[i]), i
+    small = str(tmp_path / "small.jpg")
+    Image.fromarray(want[0][:128, :128]).save(small)
+    bad = (C.c_char_p * 1)(small.encode())
+    assert lib.ap_host_decode_jpeg_tiles(out.ctypes.data, bad, 1, 256) == -1 and b"expected 256" in lib.ap_last_error()

@@ -19,7 +19,7 @@ for name, N, K, epi, variant in CASES:
     for it in range(3):
         if it == 2:
             lib.ap_gemm_trace(buf.data_ptr(), T)
-        _lib.check(lib.ap_gemm(1, epi, A.data_ptr(), K, W.data_ptr(), K, M, N, K, bias.data_ptr(), None, out.data_ptr(), N, 256, variant, stream))
+        _lib.check(lib.ap_gemm(1, epi, A.data_ptr(), K, W.data_ptr(), K, M, N, K, bias.data_ptr(), None, out.data_ptr(), N, 257, variant, stream))
     torch.cuda.synchronize()
     lib.ap_gemm_trace(None, 0)
     t = buf.cpu().numpy().astype(np.float64) * 0.01      # us

@@ -5,10 +5,10 @@ Quirks kept on purpose: ``--tissue-thresh`` defaults to 0.0 here although the da
 0.01; ``--feature-precision`` defaults to float16 although the dataclass default is float32;
 ``--skip-existing`` is on by default; the group reports version 0.2.0.
 
-Differences (stated, not hidden): the ``--visualize-*`` flags are accepted but not implemented in this build
-and raise (``--no-fast-mode`` and ``--save-images`` run on the device path); segmentation uses the analytic mask for
-``.synth`` slides and needs a plugged-in ``SegmentationService`` (or SAM2 support, not in this build)
-for real slides.  When launched under ``torch.distributed.run`` slides are sharded one per rank.
+Differences (stated, not hidden): ``--no-fast-mode`` and ``--save-images`` run on the device path; the
+``--visualize-*`` overlays are the reference's Pillow calls except that contour outlines are drawn with
+``ImageDraw.line`` instead of ``cv2.polylines``; segmentation uses the analytic mask for ``.synth`` slides and
+the HIP SAM2 path (``services/sam2_hip.py``) for real slides.  When launched under ``torch.distributed.run`` slides are sharded one per rank.
 """
 from __future__ import annotations
 
@@ -30,6 +30,7 @@ from .services.extraction import PatchExtractionService
 from .services.feature_embedding import PatchFeatureEmbeddingService, resolve_feature_dtype
 from .services.mpp import CSVMPPResolver
 from .services.segmentation import AnalyticSegmentationService, SAM2SegmentationService
+from .services.visualization import DefaultVisualizationService
 from .services.wsi_loader import DefaultWSILoader
 from .utils.features import parse_feature_list
 from .utils.params import get_wsi_files
@@ -103,8 +104,6 @@ def _run_pipeline(*, wsi_path, output, patch_size, step_size, target_mag, device
                   visualize_grids, visualize_mask, visualize_contours, recursive, mpp_csv, skip_existing, verbose,
                   feature_cfg=None, registry=None):
     logging.getLogger().setLevel(logging.DEBUG if verbose else logging.WARNING)
-    if visualize_grids or visualize_mask or visualize_contours:
-        raise click.ClickException("--visualize-* overlays are not part of this build")
     seg_yaml = Path(__file__).resolve().parent / "configs" / "sam2.1_hiera_t.yaml"
     app_cfg = AppConfig(
         processing=ProcessingConfig(input_path=Path(wsi_path), recursive=recursive,
@@ -126,7 +125,8 @@ def _run_pipeline(*, wsi_path, output, patch_size, step_size, target_mag, device
     segmenter = _pick_segmenter(app_cfg)
     loader = DefaultWSILoader()
     runner = ProcessingRunner(config=app_cfg, segmentation=segmenter,
-                              extractor=PatchExtractionService(app_cfg.extraction, app_cfg.output), visualizer=None,
+                              extractor=PatchExtractionService(app_cfg.extraction, app_cfg.output),
+                              visualizer=DefaultVisualizationService(app_cfg.output, app_cfg.extraction, app_cfg.visualization),
                               mpp_resolver=CSVMPPResolver(app_cfg.processing.mpp_csv), wsi_loader=loader,
                               show_progress=not verbose, rank=rank, world_size=world)
     try:

@@ -201,6 +201,39 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(SgemmArgs g, int bat
     g.out[(size_t)b * g.sO + (size_t)m * g.ldo + n] = v;
 }
 
+// rows of up to 64 * NV columns: the row lives in registers between the max, the exponentials and the scaling --
+// one read and one write of the score matrix instead of three reads and two writes
+template <int NV>
+__global__ __launch_bounds__(256) void softmax_rows_reg_kernel(float* x, long ld, int rows, int cols) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float* p = x + (size_t)row * ld;
+    float v[NV];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < cols ? p[c] : -INFINITY;
+        mx = fmaxf(mx, v[i]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = expf(v[i] - mx);           // exp(-inf) = 0 for the padding lanes
+        s += v[i];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    const float inv = 1.0f / s;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < cols) p[c] = v[i] * inv;
+    }
+}
+
 __global__ __launch_bounds__(256) void softmax_rows_kernel(float* x, long ld, int rows, int cols) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -399,7 +432,13 @@ int ap_sgemm(const float* A, long lda, long strideA, const float* W, long ldw, l
 
 int ap_softmax_rows(float* x, long ld, int rows, int cols, ap_stream_t stream) {
     AP_REQUIRE(x && rows > 0 && cols > 0, "ap_softmax_rows: bad arguments");
-    ap::softmax_rows_kernel<<<(rows + 3) / 4, 256, 0, (hipStream_t)stream>>>(x, ld, rows, cols);
+    const dim3 grid((rows + 3) / 4);
+    hipStream_t s = (hipStream_t)stream;
+    if (cols <= 64) ap::softmax_rows_reg_kernel<1><<<grid, 256, 0, s>>>(x, ld, rows, cols);
+    else if (cols <= 256) ap::softmax_rows_reg_kernel<4><<<grid, 256, 0, s>>>(x, ld, rows, cols);
+    else if (cols <= 1024) ap::softmax_rows_reg_kernel<16><<<grid, 256, 0, s>>>(x, ld, rows, cols);
+    else if (cols <= 4096) ap::softmax_rows_reg_kernel<64><<<grid, 256, 0, s>>>(x, ld, rows, cols);
+    else ap::softmax_rows_kernel<<<grid, 256, 0, s>>>(x, ld, rows, cols);
     AP_HIP_CHECK(hipGetLastError());
     return AP_OK;
 }

@@ -467,3 +467,22 @@ def test_process_jpeg_tile_store_through_the_native_decoder(tmp_path, monkeypatc
     want = ex.extract_batch(tiles, batch_size=32)
     ex.cleanup()
     assert np.array_equal(feats[rows], want)
+
+
+def test_visualize_flags_write_the_three_overlays(tmp_path):
+    """--visualize-grids / --visualize-mask / --visualize-contours (services/visualization.py:36-102): PNGs under
+    <out>/visualization with the reference's file names; the contour overlay carries red tissue outlines."""
+    from click.testing import CliRunner
+    from PIL import Image
+    from atlaspatch_amd.cli import cli
+    slide, _ = _make_slide(str(tmp_path), "viz.synth", width=20000, height=14000)
+    out = tmp_path / "out"
+    res = CliRunner().invoke(cli, ["segment-and-get-coords", slide, "-o", str(out), "--patch-size", "256", "--target-mag", "20",
+                                   "--visualize-grids", "--visualize-mask", "--visualize-contours"], catch_exceptions=False)
+    assert res.exit_code == 0 and "failures: 0" in res.output, res.output
+    vis = out / "visualization"
+    for name in ("viz.png", "viz_mask.png", "viz_mask_bw.png", "viz_contours.png"):
+        assert (vis / name).exists(), name
+    cont = np.asarray(Image.open(vis / "viz_contours.png"))
+    red = (cont[..., 0] == 255) & (cont[..., 1] == 0) & (cont[..., 2] == 0)
+    assert red.sum() > 200

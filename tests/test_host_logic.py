@@ -449,3 +449,42 @@ def test_native_jpeg_tile_decode_equals_pillow(tmp_path):
     Image.fromarray(want[0][:128, :128]).save(small)
     bad = (C.c_char_p * 1)(small.encode())
     assert lib.ap_host_decode_jpeg_tiles(out.ctypes.data, bad, 1, 256) == -1 and b"expected 256" in lib.ap_last_error()
+
+
+# ----------------------------------------------------------------------------- visualisation overlays (f4)
+def test_visualization_overlays_are_the_references_pillow_calls(tmp_path):
+    """--visualize-mask / --visualize-grids restated from utils/visualization/{mask,patches}.py: same Pillow operations in
+    the same order (checked here against an independent spelling of those operations); --visualize-contours draws the same
+    scaled vertices (outline rasterisation differs from cv2.polylines: stated in the module)."""
+    import json
+    from PIL import Image, ImageDraw
+    from atlaspatch_amd.core.config import ExtractionConfig, OutputConfig
+    from atlaspatch_amd.core.models import ExtractionResult, Slide
+    from atlaspatch_amd.core.wsi.wsi_factory import WSIFactory
+    from atlaspatch_amd.services.visualization import DefaultVisualizationService
+    path = tmp_path / "v.synth"
+    path.write_text(json.dumps({"width": 20000, "height": 14000, "seed": 5}))
+    wsi = WSIFactory.load(str(path))
+    mask = wsi.tissue_mask(1024)
+    coords = np.array([[0, 0, 256, 256, 0], [5120, 2560, 256, 256, 0], [19900, 13900, 256, 256, 0]], np.int32)
+    out_cfg = OutputConfig(output_root=tmp_path / "out", visualize_grids=True, visualize_mask=True)   # contours: GPU suite
+    ext_cfg = ExtractionConfig(patch_size=256, target_magnification=20)
+    res = ExtractionResult(slide=Slide(path=path), h5_path=tmp_path / "none.h5", num_patches=3, coords=coords,
+                           patch_size_level0=256)
+    DefaultVisualizationService(out_cfg, ext_cfg).visualize(res, wsi=wsi, mask=mask)
+    assert set(res.visualizations) == {"grids", "mask"}
+    vis = res.visualizations["mask"].parent
+    assert vis.name == "visualization" and (vis / "v_mask_bw.png").exists()
+    thumb = wsi.get_thumb((1024, 1024)).convert("RGB")
+    # mask overlay: alpha-composite of a green layer whose alpha is 80 where the (nearest-resized) mask is set
+    m = Image.fromarray(((mask > 0.5) * 255).astype(np.uint8), mode="L").resize(thumb.size, Image.Resampling.NEAREST)
+    layer = Image.new("RGBA", thumb.size, (0, 255, 0, 0))
+    layer.putalpha(Image.fromarray((np.asarray(m, np.float32) / 255.0 * 80).astype(np.uint8), mode="L"))
+    want = Image.alpha_composite(thumb.convert("RGBA"), layer).convert("RGB")
+    assert np.array_equal(np.asarray(Image.open(res.visualizations["mask"])), np.asarray(want))
+    assert np.array_equal(np.asarray(Image.open(vis / "v_mask_bw.png")), np.asarray(m))
+    # grid overlay: rectangles at int(coords / ratio) .. int((coords + ps0) / ratio), away from the info box
+    grid = np.asarray(Image.open(res.visualizations["grids"]))
+    rx, ry = 20000 / thumb.width, 14000 / thumb.height
+    x0, y0 = int(np.float32(5120) / rx), int(np.float32(2560) / ry)
+    assert tuple(grid[y0, x0]) == (0, 0, 0) and tuple(grid[y0, int((5120 + 256) / rx)]) == (0, 0, 0)

@@ -27,6 +27,45 @@ import torch
 from .. import _lib
 
 
+def _cpu_list(text: str) -> list:
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def _pin_order(device) -> list:
+    """Allowed CPUs ordered for pinning: the GPU's NUMA node first, one hardware thread per physical core first."""
+    import os
+    if not hasattr(os, "sched_getaffinity"):
+        return []
+    allowed = sorted(os.sched_getaffinity(0))
+    local = set(allowed)
+    try:
+        bdf = torch.cuda.get_device_properties(device).pci_bus_id.lower()
+        with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as fh:
+            node = int(fh.read())
+        if node >= 0:
+            with open(f"/sys/devices/system/node/node{node}/cpulist") as fh:
+                local = set(_cpu_list(fh.read())) & set(allowed) or set(allowed)
+    except Exception:  # noqa: BLE001 -- no topology information: every allowed CPU counts as local
+        pass
+    primary, sibling = [], []
+    for cpu in allowed:
+        try:
+            with open(f"/sys/devices/system/cpu/cpu{cpu}/topology/thread_siblings_list") as fh:
+                first = min(_cpu_list(fh.read()))
+        except Exception:  # noqa: BLE001
+            first = cpu
+        (primary if first == cpu else sibling).append(cpu)
+    order = [c for c in primary if c in local] + [c for c in primary if c not in local] + \
+            [c for c in sibling if c in local] + [c for c in sibling if c not in local]
+    return order
+
+
 class TileRing:
     def __init__(self, *, device: torch.device, batch: int, patch_size: int, slots: int = 3,
                  workers: int = 4, tile_hw: tuple | None = None) -> None:
@@ -47,12 +86,13 @@ class TileRing:
         self.free_events: list[torch.cuda.Event | None] = [None] * self.slots
         self.workers = max(1, int(workers))
         self._lib = _lib.load()
-        # decode threads pinned one per host core (north star: "tile decode on host cores pinned"): a thread that stays on
-        # its core keeps its decoder state and the pinned slot's lines warm; the cores come from the process's own
-        # affinity mask, the first one is left to the main thread that drives the streams.  ATLASPATCH_PIN_THREADS=0 disables.
+        # decode threads pinned one per host core (north star: "tile decode on host cores pinned"): cores of the NUMA node
+        # the GPU hangs off first (the pinned slots live there and the H2D DMA reads them from there), one hardware thread
+        # per physical core before any SMT sibling, all from the process's own affinity mask; the first core is left to the
+        # main thread that drives the streams.  ATLASPATCH_PIN_THREADS=0 disables.
         import itertools
         import os
-        cores = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []
+        cores = _pin_order(device)
         pin = os.environ.get("ATLASPATCH_PIN_THREADS", "1") != "0" and len(cores) > 1
         counter = itertools.count()
 

@@ -9,7 +9,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 tail -1 "$OUT/bench.json"
-CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o kt -- $CMD > "$OUT/kt.log" 2>&1
 DB=$(find "$OUT/kt" -name '*_results.db' | head -1)
 if [ -n "$DB" ]; then python profiles/summarize_rocpd.py "$DB" > "$OUT/kernel_stats.txt"; else

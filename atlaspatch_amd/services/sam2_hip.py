@@ -366,5 +366,49 @@ class Sam2HipPredictor:
 
 
 def load_sam2_state_dict(checkpoint_path) -> dict:
+    """The reference's checkpoint layout (``torch.load(path)["model"]``, segmentation.py:66-67); a bare state dict and a
+    DataParallel ``module.`` prefix are accepted too.  Every tensor the image path reads is checked up front so that a
+    checkpoint with other key names fails with the list of what is missing instead of a KeyError mid-construction."""
     obj = torch.load(str(checkpoint_path), map_location="cpu", weights_only=True)
-    return obj["model"] if isinstance(obj, dict) and "model" in obj else obj
+    sd = obj["model"] if isinstance(obj, dict) and "model" in obj else obj
+    if sd and all(k.startswith("module.") for k in sd):
+        sd = {k[len("module."):]: v for k, v in sd.items()}
+    missing = [k for k in required_sam2_keys() if k not in sd]
+    if missing:
+        raise KeyError(f"{checkpoint_path}: {len(missing)} tensors of the SAM2.1 Hiera-T image path are missing, e.g. "
+                       f"{missing[:6]} (expected the sam2 package's state-dict names)")
+    return sd
+
+
+def required_sam2_keys() -> list:
+    """Names (sam2 package state dict) of every tensor ``Sam2HipPredictor`` reads."""
+    plan, _ = block_plan()
+    t, d, p = "image_encoder.trunk.", "sam_mask_decoder.", "sam_prompt_encoder."
+    keys = [t + "patch_embed.proj.weight", t + "patch_embed.proj.bias", t + "pos_embed", t + "pos_embed_window", "no_mem_embed",
+            p + "no_mask_embed.weight", p + "pe_layer.positional_encoding_gaussian_matrix", p + "not_a_point_embed.weight",
+            p + "point_embeddings.2.weight", p + "point_embeddings.3.weight",
+            d + "obj_score_token.weight", d + "iou_token.weight", d + "mask_tokens.weight",
+            d + "conv_s0.weight", d + "conv_s0.bias", d + "conv_s1.weight", d + "conv_s1.bias",
+            d + "transformer.norm_final_attn.weight", d + "transformer.norm_final_attn.bias",
+            d + "output_upscaling.0.weight", d + "output_upscaling.0.bias", d + "output_upscaling.1.weight",
+            d + "output_upscaling.1.bias", d + "output_upscaling.3.weight", d + "output_upscaling.3.bias"]
+    for i, (din, dout, _, _, _) in enumerate(plan):
+        b = f"{t}blocks.{i}."
+        keys += [b + n for n in ("norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight",
+                                 "attn.proj.bias", "norm2.weight", "norm2.bias", "mlp.layers.0.weight", "mlp.layers.0.bias",
+                                 "mlp.layers.1.weight", "mlp.layers.1.bias")]
+        if din != dout:
+            keys += [b + "proj.weight", b + "proj.bias"]
+    for n in range(4):
+        keys += [f"image_encoder.neck.convs.{n}.conv.weight", f"image_encoder.neck.convs.{n}.conv.bias"]
+    for l in range(2):
+        b = f"{d}transformer.layers.{l}."
+        for a in ("self_attn", "cross_attn_token_to_image", "cross_attn_image_to_token"):
+            for pj in ("q_proj", "k_proj", "v_proj", "out_proj"):
+                keys += [b + f"{a}.{pj}.weight", b + f"{a}.{pj}.bias"]
+        keys += [b + f"norm{k}.{w}" for k in range(1, 5) for w in ("weight", "bias")]
+        keys += [b + f"mlp.layers.{k}.{w}" for k in range(2) for w in ("weight", "bias")]
+    for pj in ("q_proj", "k_proj", "v_proj", "out_proj"):
+        keys += [d + f"transformer.final_attn_token_to_image.{pj}.weight", d + f"transformer.final_attn_token_to_image.{pj}.bias"]
+    keys += [d + f"output_hypernetworks_mlps.0.layers.{k}.{w}" for k in range(3) for w in ("weight", "bias")]
+    return keys

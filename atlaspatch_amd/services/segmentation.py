@@ -76,6 +76,14 @@ class SAM2SegmentationService(SegmentationService):
                 if root and os.path.exists(os.path.join(root, name)):
                     path = os.path.join(root, name)
                     break
+        if path is None and os.environ.get("ATLASPATCH_RANDOM_INIT") in (None, ""):
+            # the reference's default (segmentation.py:46-58): AtlasAnalyticsLab/AtlasPatch:model.pth from the Hugging Face
+            # hub -- succeeds when the file is in the local hub cache or the host is online, otherwise falls through
+            try:
+                from huggingface_hub import hf_hub_download
+                path = hf_hub_download(repo_id="AtlasAnalyticsLab/AtlasPatch", filename="model.pth")
+            except Exception:  # noqa: BLE001
+                path = None
         if path is not None:
             sd = load_sam2_state_dict(path)
         elif os.environ.get("ATLASPATCH_RANDOM_INIT") not in (None, ""):

@@ -488,3 +488,21 @@ def test_visualization_overlays_are_the_references_pillow_calls(tmp_path):
     rx, ry = 20000 / thumb.width, 14000 / thumb.height
     x0, y0 = int(np.float32(5120) / rx), int(np.float32(2560) / ry)
     assert tuple(grid[y0, x0]) == (0, 0, 0) and tuple(grid[y0, int((5120 + 256) / rx)]) == (0, 0, 0)
+
+
+def test_sam2_checkpoint_loader_accepts_the_reference_layout_and_names_what_is_missing(tmp_path):
+    """load_sam2_state_dict: the reference's {"model": state_dict} layout (segmentation.py:66-67), a DataParallel prefix, and a
+    clear KeyError when a tensor the image path reads is absent (names: the sam2 package's state dict, restated in the oracle)."""
+    from atlaspatch_amd.services.sam2_hip import load_sam2_state_dict, required_sam2_keys
+    from oracle import sam2_oracle as so
+    sd = so.random_state_dict(0)
+    req = required_sam2_keys()
+    assert len(req) == 269 and all(k in sd for k in req)
+    p = tmp_path / "model.pth"
+    torch.save({"model": {"module." + k: v for k, v in sd.items()}}, p)
+    assert set(load_sam2_state_dict(p)) == set(sd)
+    broken = dict(sd)
+    broken.pop("sam_mask_decoder.iou_token.weight")
+    torch.save({"model": broken}, p)
+    with pytest.raises(KeyError, match="iou_token"):
+        load_sam2_state_dict(p)

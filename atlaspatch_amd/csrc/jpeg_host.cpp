@@ -155,7 +155,7 @@ int decode_one(const Api& api, const unsigned char* data, size_t size, int want_
     err.pub.error_exit = on_error;
     err.pub.emit_message = on_message;
     err.text[0] = 0;
-    bool created = false;
+    volatile bool created = false;          // written between setjmp and a possible longjmp
     if (setjmp(err.jb)) {
         snprintf(why, why_cap, "libjpeg: %s", err.text);
         if (created) api.destroy(&c);

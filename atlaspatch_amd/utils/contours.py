@@ -96,3 +96,16 @@ def mask_to_contours(mask: np.ndarray, *, tissue_area_thresh: float = 0.01,
         return dc.as_lists(scaled=False)
     finally:
         dc.close()
+
+
+def scale_contours(contours, sx: float, sy: float):
+    """``scale_contours`` of the reference (contours.py:119-131) for host-side consumers (the visualisation overlay):
+    ``c.astype(float32); c[..., 0] *= sx; c[..., 1] *= sy; c.astype(int32)`` -- float32 multiply, truncation toward zero.
+    The coordinate path itself scales inside ``ap_contours_from_mask`` (same arithmetic, golden G3)."""
+    out = []
+    for c in contours:
+        s = np.asarray(c).astype(np.float32)
+        s[..., 0] *= sx
+        s[..., 1] *= sy
+        out.append(s.astype(np.int32))
+    return out

@@ -506,3 +506,16 @@ def test_sam2_checkpoint_loader_accepts_the_reference_layout_and_names_what_is_m
     torch.save({"model": broken}, p)
     with pytest.raises(KeyError, match="iou_token"):
         load_sam2_state_dict(p)
+
+
+def test_host_scale_contours_matches_reference_golden(golden_dir):
+    """utils.contours.scale_contours (host helper of the visualisation overlay) == the reference's scale_contours on G3."""
+    from atlaspatch_amd.utils.contours import scale_contours
+    g = np.load(os.path.join(golden_dir, "scale_contours.npz"))
+    k = 0
+    while f"c{k}_in" in g:
+        W, H, mw, mh = (int(v) for v in g[f"c{k}_dims"])
+        out = scale_contours([g[f"c{k}_in"].reshape(-1, 1, 2)], W / float(mw), H / float(mh))[0]
+        assert out.dtype == np.int32 and np.array_equal(out.reshape(-1, 2), g[f"c{k}_out"].reshape(-1, 2)), k
+        k += 1
+    assert k >= 4

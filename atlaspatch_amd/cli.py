@@ -94,9 +94,7 @@ def _decorate(func, options):
 
 def _pick_segmenter(app_cfg: AppConfig):
     files = get_wsi_files(str(app_cfg.processing.input_path), recursive=app_cfg.processing.recursive)
-    if all(Path(f).suffix.lower() == ".synth" for f in files):
-        return AnalyticSegmentationService(app_cfg.segmentation.thumbnail_max)
-    return SAM2SegmentationService(app_cfg.segmentation)
+    return _segmenter_for(files, app_cfg.segmentation)
 
 
 def _run_pipeline(*, wsi_path, output, patch_size, step_size, target_mag, device, tissue_thresh, white_thresh,
@@ -204,6 +202,89 @@ def _process(*, feature_device, feature_extractors, feature_batch_size, feature_
 process = cli.command(name="process",
                       help="Run segmentation, patch extraction, and feature embedding into a single H5.")(
     _decorate(_decorate(_process, _COMMON), _FEATURE))
+
+
+def _segmenter_for(files, seg_cfg: SegmentationConfig):
+    if all(Path(f).suffix.lower() == ".synth" for f in files):
+        return AnalyticSegmentationService(seg_cfg.thumbnail_max)
+    return SAM2SegmentationService(seg_cfg)
+
+
+@cli.command(name="detect-tissue")
+@click.argument("wsi_path", type=click.Path(exists=True))
+@click.option("--output", "-o", type=click.Path(), required=True, help="Output directory root for generated artifacts.")
+@click.option("--device", type=str, default="cuda", show_default=True, help="Segmentation device (e.g., cuda, cuda:0, cpu).")
+@click.option("--seg-batch-size", type=click.IntRange(1, None), default=1, show_default=True,
+              help="Segmentation batch size for thumbnail inference.")
+@click.option("--recursive", is_flag=True, help="Recursively search directories for WSIs.")
+@click.option("--mpp-csv", type=click.Path(exists=True), default=None, help="CSV with custom MPP.")
+@click.option("--verbose", "-v", is_flag=True, help="Enable debug logging.")
+def detect_tissue(wsi_path, output, device, seg_batch_size, recursive, mpp_csv, verbose):
+    """Run tissue segmentation only and export mask overlays (reference: cli.py:329-438, 531-578)."""
+    from .core.models import Slide
+    from .services.visualization import visualize_mask_on_thumbnail
+    logging.getLogger().setLevel(logging.DEBUG if verbose else logging.WARNING)
+    proc = ProcessingConfig(input_path=Path(wsi_path), recursive=recursive, mpp_csv=Path(mpp_csv) if mpp_csv else None).validated()
+    seg_yaml = Path(__file__).resolve().parent / "configs" / "sam2.1_hiera_t.yaml"
+    seg_cfg = SegmentationConfig(checkpoint_path=None, config_path=seg_yaml, device=device.lower(),
+                                 batch_size=seg_batch_size).validated()
+    vis_cfg = VisualizationConfig().validated()
+    files = get_wsi_files(str(proc.input_path), recursive=proc.recursive)
+    vis_dir = Path(output) / "visualization"
+    Path(output).mkdir(parents=True, exist_ok=True)
+    resolver, loader = CSVMPPResolver(proc.mpp_csv), DefaultWSILoader()
+    segmenter = _segmenter_for(files, seg_cfg)
+    results, failures = [], []
+    bar = tqdm(total=len(files), disable=verbose, desc="Tissue detection")
+
+    def run_batch(batch):
+        if not batch:
+            return
+        wsis = [w for _, w in batch]
+        try:
+            masks = segmenter.segment_batch(wsis) if len(wsis) > 1 else [segmenter.segment_thumbnail(wsis[0])]
+        except Exception as exc:  # noqa: BLE001
+            for slide, wsi in batch:
+                failures.append((slide, exc))
+                ProcessingRunner._close(wsi)
+                bar.update(1)
+            return
+        for (slide, wsi), mask in zip(batch, masks):
+            try:
+                results.append((slide, visualize_mask_on_thumbnail(mask=mask.data, wsi=wsi, output_dir=vis_dir,
+                                                                   thumbnail_size=vis_cfg.thumbnail_size)))
+            except Exception as exc:  # noqa: BLE001
+                failures.append((slide, exc))
+            finally:
+                ProcessingRunner._close(wsi)
+            bar.update(1)
+
+    try:
+        batch = []
+        for f in files:
+            base = Slide(path=Path(f))
+            slide = Slide(path=base.path, mpp=resolver.resolve(base), backend=base.backend)
+            try:
+                batch.append((slide, loader.open(slide)))
+            except Exception as exc:  # noqa: BLE001
+                failures.append((slide, exc))
+                bar.update(1)
+                continue
+            if len(batch) >= seg_cfg.batch_size:
+                run_batch(batch)
+                batch = []
+        run_batch(batch)
+    finally:
+        try:
+            segmenter.close()
+        finally:
+            bar.close()
+    click.echo(f"Created {len(results)} mask overlay(s), failures: {len(failures)}")
+    if verbose:
+        for slide, path in results:
+            click.echo(f"[OK] {slide.path.name} -> {path}")
+        for slide, err in failures:
+            click.echo(f"[FAIL] {slide.path.name}: {err}", err=True)
 
 
 @cli.command()

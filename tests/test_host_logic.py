@@ -519,3 +519,17 @@ def test_host_scale_contours_matches_reference_golden(golden_dir):
         assert out.dtype == np.int32 and np.array_equal(out.reshape(-1, 2), g[f"c{k}_out"].reshape(-1, 2)), k
         k += 1
     assert k >= 4
+
+
+def test_detect_tissue_command_writes_mask_overlays(tmp_path):
+    """`detect-tissue` (reference cli.py:329-438, 531-578): segmentation only + mask overlay PNGs under <out>/visualization,
+    the reference's summary line.  Synthetic slides use the analytic mask, so this runs without a device."""
+    import json
+    from click.testing import CliRunner
+    from atlaspatch_amd.cli import cli
+    for name, seed in (("a.synth", 3), ("b.synth", 4)):
+        (tmp_path / name).write_text(json.dumps({"width": 12000, "height": 9000, "seed": seed}))
+    out = tmp_path / "o"
+    res = CliRunner().invoke(cli, ["detect-tissue", str(tmp_path), "-o", str(out), "--seg-batch-size", "2"], catch_exceptions=False)
+    assert res.exit_code == 0 and "Created 2 mask overlay(s), failures: 0" in res.output
+    assert sorted(p.name for p in (out / "visualization").iterdir()) == ["a_mask.png", "a_mask_bw.png", "b_mask.png", "b_mask_bw.png"]

@@ -12,6 +12,8 @@
 //   ap_maxpool2x2       2x2 / stride 2 max pool on [B, H, W, C] with an input row stride (q pooling, shortcut)
 //   ap_add / ap_add_rowvec / ap_gelu / ap_upsample2x_add / ap_convt2x2_shuffle / ap_bilinear_up4_threshold
 #include <algorithm>
+#include <type_traits>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include "ap_common.h"
@@ -40,108 +42,153 @@ struct SgemmArgs {
 
 // Exact-f32 MFMA GEMM (v_mfma_f32_32x32x2_f32), any M / N / K, batched, NT or NN.
 //   T x T output tile per 256-thread workgroup (T = 128: 2 x 2 waves of 64 x 64 = four 32 x 32 MFMA blocks each;
-//   T = 64: one block per wave for the small batched attention products), 16-deep K tiles.
+//   T = 64: one block per wave for the small batched attention products), 32-deep K tiles.
 //   Global -> registers (float4 per thread, next K tile in flight under the MFMAs) -> LDS (two buffers, one barrier per
-//   K tile).  LDS rows hold [row][16 k] padded to 20 floats: a lane reads its 8 k values with two ds_read_b128 and rows
-//   80 B apart spread over all 32 banks.  The MFMA's two k slots are fed k = e and k = 8 + e (lane halves), the same
-//   mapping on both operands, so the sum runs over all 16 k of the tile.  The NN weight ([k][n], P V products) keeps its
-//   [k][n] layout in LDS and is read with 8 conflict-free ds_read_b32.
+//   K tile).  LDS rows hold [row][32 k] padded to 36 floats: a lane reads its 16 k values with four ds_read_b128 and rows
+//   144 B apart put every lane group of a ds_read_b128 on 64 distinct banks.  The MFMA's two k slots are fed k = e and
+//   k = 16 + e (lane halves), the same mapping on both operands, so the sum runs over all 32 k of the tile.  The NN weight
+//   ([k][n], P V products) keeps its [k][n] layout in LDS and is read with 16 conflict-free ds_read_b32.
 //   D[i = m][j = n]: a lane owns column n = lane % 32 and 16 rows -> stores / residual reads are 128-byte row segments.
-template <int T, bool WKN>
+template <int TM, int TN, bool WKN, bool VEC>
 __global__ __launch_bounds__(256) void sgemm_mfma_kernel(SgemmArgs g) {
-    constexpr int BLK = T / 64, LDR = 20, LDN = T + 4, PER = T / 64;
-    __shared__ __attribute__((aligned(16))) float As[2][T * LDR];
-    __shared__ __attribute__((aligned(16))) float Ws[2][WKN ? 16 * LDN : T * LDR];
+    // KT-deep K tiles: one barrier per 16 MFMA steps and whole 128-byte lines per operand row.  Measured
+    // (tools/sgemm_probe.py): SAM2's mid-size shapes run at 42 - 49 % of the 157 TF/s f32 MFMA peak with either tile size;
+    // large problems reach 67 % (64 x 64) / 77 % (128 x 128).  Tried without effect on the mid sizes: two accumulators per
+    // wave instead of one dependent chain (+-0), 16- vs 32-deep K tiles (+3 %), a 128 x 64 tile (-19 %: occupancy), loads
+    // hoisted out of branches (+6 %).  MFMA busy 51 % (PMC) with LDS 29 % busy: what is left is the short K loop itself --
+    // 3 to 12 K tiles per workgroup leave prologue / epilogue and the ramp of co-resident workgroups a large share.
+    constexpr int KT = 32, Q = KT / 4, HALF = KT / 2;
+    constexpr int BM = TM / 64, BN = TN / 64, LDR = KT + 4, LDN = TN + 4;
+    constexpr int PA = TM * Q / 256, PW = WKN ? KT * (TN / 4) / 256 : TN * Q / 256;      // float4 loads per thread and K tile
+    __shared__ __attribute__((aligned(16))) float As[2][TM * LDR];
+    __shared__ __attribute__((aligned(16))) float Ws[2][WKN ? KT * LDN : TN * LDR];
     const int b = blockIdx.z / g.splits, split = blockIdx.z % g.splits;
     const float* A = g.A + (size_t)b * g.sA;
     const float* W = g.W + (size_t)b * g.sW;
-    const int m0 = blockIdx.y * T, n0 = blockIdx.x * T;
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave & 1, wn = wave >> 1;
     const int l31 = lane & 31, hi = lane >> 5;
     const int kbeg = split * g.k_chunk, kend = (kbeg + g.k_chunk < g.K) ? kbeg + g.k_chunk : g.K;
 
-    f32x4 ra[PER], rw[PER];
-    auto load_rows = [&](const float* base, long ld, int row0, int rows, int k0, f32x4* dst) {     // [row][k] operand
+    // Every global load is UNCONDITIONAL (addresses clamped into the operand, validity kept as a 4-bit mask and applied
+    // when the registers go to LDS): a load behind a branch makes hipcc wait for it at the join, i.e. before the MFMAs
+    // it was meant to run under.
+    f32x4 ra[PA], rw[PW];
+    unsigned ma[PA], mw[PW];
+    auto load_rows = [&](const float* base, long ld, int row0, int rows, int k0, f32x4* dst, unsigned* msk, auto per) {   // [row][k]
 #pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            const int f = tid + 256 * j, r = f >> 2, k = k0 + (f & 3) * 4;
+        for (int j = 0; j < decltype(per)::value; ++j) {
+            const int f = tid + 256 * j, r = f / Q, k = k0 + (f % Q) * 4;
             int gr = row0 + r;
             gr = gr < rows ? gr : rows - 1;
-            const float* p = base + (size_t)gr * ld + k;
-            if (g.vec) {
-                dst[j] = k < kend ? *(const f32x4*)p : f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* p = base + (size_t)gr * ld;
+            if constexpr (VEC) {                      // K % 4 == 0: a float4 is wholly inside or wholly outside [kbeg, kend)
+                const bool ok = k < kend;
+                dst[j] = *(const f32x4*)(p + (ok ? k : kbeg));
+                msk[j] = ok ? 15u : 0u;
             } else {
+                unsigned m = 0;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) dst[j][e] = (k + e < kend) ? p[e] : 0.f;
+                for (int e = 0; e < 4; ++e) {
+                    const bool ok = k + e < kend;
+                    dst[j][e] = p[ok ? k + e : kend - 1];
+                    m |= (ok ? 1u : 0u) << e;
+                }
+                msk[j] = m;
             }
         }
     };
-    auto load_kn = [&](int k0, f32x4* dst) {                                                        // W[k][n]
+    auto load_kn = [&](int k0, f32x4* dst, unsigned* msk) {                                                     // W[k][n]
 #pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            const int f = tid + 256 * j, kr = f / (T / 4), n = n0 + (f % (T / 4)) * 4, k = k0 + kr;
-            const float* p = W + (size_t)k * g.ldw + n;
-            if (k < kend && g.vec && n + 3 < g.N) {
-                dst[j] = *(const f32x4*)p;
+        for (int j = 0; j < PW; ++j) {
+            const int f = tid + 256 * j, kr = f / (TN / 4), n = n0 + (f % (TN / 4)) * 4, k = k0 + kr;
+            const bool kok = k < kend;
+            const float* p = W + (size_t)(kok ? k : kend - 1) * g.ldw;
+            if (VEC && n + 3 < g.N) {                 // uniform per (thread, launch): N and n0 do not change in the K loop
+                dst[j] = *(const f32x4*)(p + n);
+                msk[j] = kok ? 15u : 0u;
             } else {
+                unsigned m = 0;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) dst[j][e] = (k < kend && n + e < g.N) ? p[e] : 0.f;
+                for (int e = 0; e < 4; ++e) {
+                    const bool ok = kok && n + e < g.N;
+                    dst[j][e] = p[n + e < g.N ? n + e : g.N - 1];
+                    m |= (ok ? 1u : 0u) << e;
+                }
+                msk[j] = m;
             }
         }
+    };
+    auto masked = [](f32x4 v, unsigned m) {
+        return f32x4{(m & 1u) ? v[0] : 0.f, (m & 2u) ? v[1] : 0.f, (m & 4u) ? v[2] : 0.f, (m & 8u) ? v[3] : 0.f};
     };
     auto store_lds = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < PER; ++j) {
+        for (int j = 0; j < PA; ++j) {
             const int f = tid + 256 * j;
-            *(f32x4*)&As[buf][(f >> 2) * LDR + (f & 3) * 4] = ra[j];
-            if constexpr (WKN) *(f32x4*)&Ws[buf][(f / (T / 4)) * LDN + (f % (T / 4)) * 4] = rw[j];
-            else *(f32x4*)&Ws[buf][(f >> 2) * LDR + (f & 3) * 4] = rw[j];
+            *(f32x4*)&As[buf][(f / Q) * LDR + (f % Q) * 4] = masked(ra[j], ma[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+            const int f = tid + 256 * j;
+            if constexpr (WKN) *(f32x4*)&Ws[buf][(f / (TN / 4)) * LDN + (f % (TN / 4)) * 4] = masked(rw[j], mw[j]);
+            else *(f32x4*)&Ws[buf][(f / Q) * LDR + (f % Q) * 4] = masked(rw[j], mw[j]);
         }
     };
     auto load_tile = [&](int k0) {
-        load_rows(A, g.lda, m0, g.M, k0, ra);
-        if constexpr (WKN) load_kn(k0, rw);
-        else load_rows(W, g.ldw, n0, g.N, k0, rw);
+        load_rows(A, g.lda, m0, g.M, k0, ra, ma, std::integral_constant<int, PA>{});
+        if constexpr (WKN) load_kn(k0, rw, mw);
+        else load_rows(W, g.ldw, n0, g.N, k0, rw, mw, std::integral_constant<int, PW>{});
     };
 
-    f32x16 acc[BLK][BLK];
+    f32x16 acc[BM][BN];
 #pragma unroll
-    for (int i = 0; i < BLK; ++i)
+    for (int i = 0; i < BM; ++i)
 #pragma unroll
-        for (int j = 0; j < BLK; ++j)
+        for (int j = 0; j < BN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int nk = (kend - kbeg + 15) / 16;
+    const int nk = (kend - kbeg + KT - 1) / KT;
     load_tile(kbeg);
     store_lds(0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) load_tile(kbeg + (kt + 1) * 16);
-        float a[BLK][8], w[BLK][8];
+        if (kt + 1 < nk) load_tile(kbeg + (kt + 1) * KT);
+        // the MFMA's two k slots take k = e (lanes 0-31) and k = HALF + e (lanes 32-63), the same mapping on both operands
+        float a[BM][HALF], w[BN][HALF];
 #pragma unroll
-        for (int i = 0; i < BLK; ++i) {
-            const float* pa = &As[cur][(wm * (T / 2) + i * 32 + l31) * LDR + hi * 8];
-            const f32x4 a0 = *(const f32x4*)pa, a1 = *(const f32x4*)(pa + 4);
+        for (int i = 0; i < BM; ++i) {
+            const float* pa = &As[cur][(wm * (TM / 2) + i * 32 + l31) * LDR + hi * HALF];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { a[i][e] = a0[e]; a[i][4 + e] = a1[e]; }
-            if constexpr (WKN) {
+            for (int q = 0; q < HALF / 4; ++q) {
+                const f32x4 v = *(const f32x4*)(pa + q * 4);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) w[i][e] = Ws[cur][(hi * 8 + e) * LDN + wn * (T / 2) + i * 32 + l31];
-            } else {
-                const float* pw = &Ws[cur][(wn * (T / 2) + i * 32 + l31) * LDR + hi * 8];
-                const f32x4 w0 = *(const f32x4*)pw, w1 = *(const f32x4*)(pw + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { w[i][e] = w0[e]; w[i][4 + e] = w1[e]; }
+                for (int e = 0; e < 4; ++e) a[i][q * 4 + e] = v[e];
             }
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
+        for (int i = 0; i < BN; ++i) {
+            if constexpr (WKN) {
 #pragma unroll
-            for (int i = 0; i < BLK; ++i)
+                for (int e = 0; e < HALF; ++e) w[i][e] = Ws[cur][(hi * HALF + e) * LDN + wn * (TN / 2) + i * 32 + l31];
+            } else {
+                const float* pw = &Ws[cur][(wn * (TN / 2) + i * 32 + l31) * LDR + hi * HALF];
 #pragma unroll
-                for (int j = 0; j < BLK; ++j)
+                for (int q = 0; q < HALF / 4; ++q) {
+                    const f32x4 v = *(const f32x4*)(pw + q * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[i][q * 4 + e] = v[e];
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < HALF; ++e)
+#pragma unroll
+            for (int i = 0; i < BM; ++i)
+#pragma unroll
+                for (int j = 0; j < BN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], w[j][e], acc[i][j], 0, 0, 0);
         if (kt + 1 < nk) store_lds(cur ^ 1);
         __syncthreads();
@@ -150,14 +197,14 @@ __global__ __launch_bounds__(256) void sgemm_mfma_kernel(SgemmArgs g) {
     if (g.splits > 1) {                 // raw partial sums; alpha / bias / activation / residual in the reduce kernel
         float* part = g.partial + (size_t)blockIdx.z * g.M * g.N;
 #pragma unroll
-        for (int j = 0; j < BLK; ++j) {
-            const int n = n0 + wn * (T / 2) + j * 32 + l31;
+        for (int j = 0; j < BN; ++j) {
+            const int n = n0 + wn * (TN / 2) + j * 32 + l31;
             if (n >= g.N) continue;
 #pragma unroll
-            for (int i = 0; i < BLK; ++i)
+            for (int i = 0; i < BM; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm * (T / 2) + i * 32 + (r >> 2) * 8 + hi * 4 + (r & 3);
+                    const int m = m0 + wm * (TM / 2) + i * 32 + (r >> 2) * 8 + hi * 4 + (r & 3);
                     if (m < g.M) part[(size_t)m * g.N + n] = acc[i][j][r];
                 }
         }
@@ -166,21 +213,31 @@ __global__ __launch_bounds__(256) void sgemm_mfma_kernel(SgemmArgs g) {
     float* out = g.out + (size_t)b * g.sO;
     const float* resid = g.resid ? g.resid + (size_t)b * g.sR : nullptr;
 #pragma unroll
-    for (int j = 0; j < BLK; ++j) {
-        const int n = n0 + wn * (T / 2) + j * 32 + l31;
-        if (n >= g.N) continue;
-        const float bias = g.bias ? g.bias[n] : 0.f;
+    for (int j = 0; j < BN; ++j) {
+        const int n = n0 + wn * (TN / 2) + j * 32 + l31;
+        const bool nok = n < g.N;
+        const int nn = nok ? n : g.N - 1;
+        const float bias = g.bias ? g.bias[nn] : 0.f;
 #pragma unroll
-        for (int i = 0; i < BLK; ++i)
+        for (int i = 0; i < BM; ++i) {
+            const int mb = m0 + wm * (TM / 2) + i * 32 + hi * 4;
+            float rv[16];
+            if (resid) {                              // all 16 residual loads in flight before the first is used
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + (r >> 2) * 8 + (r & 3);
+                    rv[r] = resid[(size_t)(m < g.M ? m : g.M - 1) * g.ldr + nn];
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * (T / 2) + i * 32 + (r >> 2) * 8 + hi * 4 + (r & 3);
-                if (m >= g.M) continue;
+                const int m = mb + (r >> 2) * 8 + (r & 3);
                 float v = acc[i][j][r] * g.alpha + bias;
                 v = act_apply(v, g.act);
-                if (resid) v += resid[(size_t)m * g.ldr + n];
-                out[(size_t)m * g.ldo + n] = v;
+                if (resid) v += rv[r];
+                if (nok && m < g.M) out[(size_t)m * g.ldo + n] = v;
             }
+        }
     }
 }
 
@@ -381,19 +438,22 @@ int ap_sgemm(const float* A, long lda, long strideA, const float* W, long ldw, l
                     0, 1, K, nullptr};
     const bool al16 = (((uintptr_t)A | (uintptr_t)W) & 15) == 0 && lda % 4 == 0 && ldw % 4 == 0 && strideA % 4 == 0 && strideW % 4 == 0;
     g.vec = al16 && (w_is_kn || K % 4 == 0) ? 1 : 0;
-    // tile: 128 x 128 only when that still gives every CU two workgroups; else 64 x 64
-    auto wgs = [&](int t) { return (long)((M + t - 1) / t) * ((N + t - 1) / t) * batch; };
-    const int T = (M > 64 && N > 64 && wgs(128) >= 512) ? 128 : 64;
+    // tile (M x N): 128 x 128 when that still gives every CU two workgroups, else 64 x 64.  (A 128 x 64 tile was measured
+    // too: M = 4096, N = 1536, K = 384 went from 62.9 to 74.6 us -- two workgroups per CU instead of four cost more than
+    // the 25 % fewer operand bytes returned.)
+    auto wgs = [&](int tm, int tn) { return (long)((M + tm - 1) / tm) * ((N + tn - 1) / tn) * batch; };
+    int TM = 64, TN = 64;
+    if (M > 64 && N > 64 && wgs(128, 128) >= 512) { TM = 128; TN = 128; }
     // split-K: few output tiles over a long K (P V of the global / token-to-image attention, the late MLPs) would leave
     // most CUs idle behind serial K loops -> K chunks of >= 128 on separate workgroups, partial sums reduced in order
     int splits = 1;
-    if (wgs(T) < 256 && K >= 512) {
-        splits = (int)std::min<long>(std::min<long>((256 + wgs(T) - 1) / wgs(T), K / 128), 32);
+    if (wgs(TM, TN) < 256 && K >= 512) {
+        splits = (int)std::min<long>(std::min<long>((256 + wgs(TM, TN) - 1) / wgs(TM, TN), K / 128), 32);
         if (splits < 2) splits = 1;
     }
     hipStream_t s = (hipStream_t)stream;
     if (splits > 1) {
-        g.k_chunk = (int)ap::align_up((size_t)(K + splits - 1) / splits, 16);
+        g.k_chunk = (int)ap::align_up((size_t)(K + splits - 1) / splits, 32);
         splits = (K + g.k_chunk - 1) / g.k_chunk;
         g.splits = splits;
         const size_t need = (size_t)splits * batch * M * N * sizeof(float);
@@ -414,16 +474,19 @@ int ap_sgemm(const float* A, long lda, long strideA, const float* W, long ldw, l
         }
         g.partial = sc.first;
     }
-    const int gy = (M + T - 1) / T;
+    const int gy = (M + TM - 1) / TM;
     AP_REQUIRE(gy <= 65535 && (long)batch * splits <= 65535, "ap_sgemm: problem %d x %d x %d x %d too large", batch, M, N, K);
-    dim3 grid((N + T - 1) / T, gy, batch * splits);
-    if (T == 128) {
-        if (w_is_kn) ap::sgemm_mfma_kernel<128, true><<<grid, 256, 0, s>>>(g);
-        else ap::sgemm_mfma_kernel<128, false><<<grid, 256, 0, s>>>(g);
-    } else {
-        if (w_is_kn) ap::sgemm_mfma_kernel<64, true><<<grid, 256, 0, s>>>(g);
-        else ap::sgemm_mfma_kernel<64, false><<<grid, 256, 0, s>>>(g);
-    }
+    dim3 grid((N + TN - 1) / TN, gy, batch * splits);
+#define AP_SGEMM_LAUNCH(A_, B_, KN, VV) ap::sgemm_mfma_kernel<A_, B_, KN, VV><<<grid, 256, 0, s>>>(g)
+#define AP_SGEMM_TILE(A_, B_)                                                                              \
+    do {                                                                                                   \
+        if (w_is_kn) { if (g.vec) AP_SGEMM_LAUNCH(A_, B_, true, true); else AP_SGEMM_LAUNCH(A_, B_, true, false); }   \
+        else { if (g.vec) AP_SGEMM_LAUNCH(A_, B_, false, true); else AP_SGEMM_LAUNCH(A_, B_, false, false); }         \
+    } while (0)
+    if (TM == 128) AP_SGEMM_TILE(128, 128);
+    else AP_SGEMM_TILE(64, 64);
+#undef AP_SGEMM_TILE
+#undef AP_SGEMM_LAUNCH
     if (splits > 1)
         ap::splitk_reduce_kernel<<<ap::grid1((size_t)batch * M * N), 256, 0, s>>>(g, batch);
     AP_HIP_CHECK(hipGetLastError());

@@ -17,10 +17,15 @@ with tempfile.TemporaryDirectory() as tmp:
         slides.append(p)
     cases = [(["--feature-extractors", "vit_b_16,uni_v1", "--feature-precision", "bfloat16"], "bf16 two extractors", tmp),
              (["--feature-extractors", "vit_b_16", "--feature-precision", "float32"], "f32", tmp),
-             (["--feature-extractors", "vit_b_16,conch_v1", "--feature-precision", "float16", "--patch-size", "512"], "ps512", slides[0])]
+             (["--feature-extractors", "vit_b_16,conch_v1", "--feature-precision", "float16", "--patch-size", "512"], "ps512", slides[0]),
+             (["--feature-extractors", "vit_l_16", "--feature-precision", "float16", "--target-mag", "10", "--save-images",
+               "--visualize-grids", "--visualize-mask", "--visualize-contours"], "mag20->10 (512 reads, cv2 resize) + images + overlays", slides[1]),
+             (["--feature-extractors", "vit_b_16", "--feature-precision", "float16", "--no-fast-mode", "--step-size", "128",
+               "--target-mag", "5"], "mag20->5 (1024 reads), no-fast-mode, overlap", slides[1])]
     for k, (extra, label, target) in enumerate(cases):
         out = os.path.join(tmp, f"out{k}")
-        args = ["process", target, "-o", out, "--target-mag", "20"] + (["--patch-size", "256"] if "--patch-size" not in extra else []) + extra
+        args = ["process", target, "-o", out] + (["--target-mag", "20"] if "--target-mag" not in extra else []) + \
+            (["--patch-size", "256"] if "--patch-size" not in extra else []) + extra
         res = CliRunner().invoke(cli, args, catch_exceptions=False)
         good = res.exit_code == 0 and "failures: 0" in res.output
         shapes = {}

@@ -292,11 +292,11 @@ __global__ void cubic_kernel(const uint8_t* __restrict__ src, int n, int h, int 
 extern "C" int ap_cv2_resize_u8(const uint8_t* src, int n, int h, int w, uint8_t* dst, int oh, int ow, int interpolation,
                                 int flags, ap_stream_t stream) {
     using namespace ap;
-    AP_REQUIRE(src && dst, "ap_cv2_resize_u8: null pointer");
     AP_REQUIRE(n >= 0 && h > 0 && w > 0 && oh > 0 && ow > 0, "ap_cv2_resize_u8: bad shape");
     AP_REQUIRE(interpolation == AP_CV_INTER_LINEAR || interpolation == AP_CV_INTER_CUBIC || interpolation == AP_CV_INTER_AREA,
                "ap_cv2_resize_u8: unsupported interpolation %d", interpolation);
-    if (n == 0) return AP_OK;
+    if (n == 0) return AP_OK;                 // an empty batch has no buffers to check
+    AP_REQUIRE(src && dst, "ap_cv2_resize_u8: null pointer");
     const Tables* t = nullptr;
     const int rc = get_tables(h, w, oh, ow, interpolation, &t);
     if (rc != AP_OK) return rc;

@@ -81,6 +81,16 @@ enum GemmEpilogue {
     EPI_BIAS_GELU = 1,     // out[m][n] = T(gelu_erf(acc + bias[n]))
     EPI_BIAS_RESID = 2,    // resid[m][n] += (acc + bias[n]) * (gamma ? gamma[n] : 1)   (f32, in place)
     EPI_PATCH_EMBED = 3,   // tok[(m / P) * (P + 1) + 1 + m % P][n] = acc + bias[n] + pos[1 + m % P][n]
+    // ---- fused-LayerNorm family (16-bit residual stream, gemm256 only; see vit.cpp::run_blocks_fused)
+    // The A operand is the raw stream x (T); the weights carry the LayerNorm gain (W' = W * gamma), so
+    //   LN(x) W^T + b = rstd[m] * (sum_k x[m][k] W'[n][k] - mean[m] * colsum[n]) + bias'[n]
+    // with colsum[n] = sum_k W'[n][k], bias' = b + W beta and rowstats[m] = (rstd, -mean * rstd).
+    EPI_NORM_STORE = 4,    // out[m][n] = T(rstd[m] * acc + (-mean[m] rstd[m]) * colsum[n] + bias[n])
+    EPI_NORM_GELU = 5,     // ... = T(gelu(that))
+    // out[m][n] = T(out[m][n] + T(acc + bias[n]))  (residual add in place, T = f16 / bf16) and, per row and
+    // 64-column group, partial[m][n / 64] = (sum, sum of squares) of the NEW row values (f32): what the
+    // next fused-LayerNorm GEMM's rowstats are built from (launch_rowstats_finalize)
+    EPI_RESID_STATS = 6,
 };
 
 struct GemmArgs {
@@ -90,6 +100,9 @@ struct GemmArgs {
     const float* bias;
     const float* gamma;      // EPI_BIAS_STORE / EPI_BIAS_RESID: LayerScale (may be null)
     const float* pos;        // EPI_PATCH_EMBED: [P + 1, N]
+    const float* colsum;     // EPI_NORM_*: f32 [N]
+    const float* rowstats;   // EPI_NORM_*: f32 [M, 2] = (rstd, -mean * rstd)
+    float* partial;          // EPI_RESID_STATS: f32 [M, N / 64, 2]
     void* out; int ldo;      // T (STORE / GELU) or f32 (RESID / PATCH_EMBED)
     int P;                   // EPI_PATCH_EMBED: patches per image
     int ablate;              // gemm256 A/B twin only: timing ablation flags (results invalid when set)
@@ -139,6 +152,23 @@ int launch_attention_cls(int dtype, const void* q, const void* kv, int ld, int k
                          int tokens, int heads, int head_dim, hipStream_t stream);
 int launch_attn_pool(int dtype, const void* kv, const float* q, void* out, int n, int tokens, int heads,
                      hipStream_t stream);
+// ---- fused-LayerNorm path (16-bit residual stream) ---------------------------------------
+// tok f32 [rows, dim] (dense) -> x T [rows, dim] and rowstats f32 [rows, 2] = (rstd, -mean * rstd) of the ROUNDED row
+int launch_stream_init(int dtype, const float* tok, int rows, int dim, float eps, void* x, float* rowstats,
+                       hipStream_t stream);
+// partial f32 [rows, groups, 2] (sum, sum of squares per 64-column group) -> rowstats f32 [rows, 2]
+int launch_rowstats_finalize(const float* partial, int rows, int groups, int dim, float eps, float* rowstats,
+                             hipStream_t stream);
+// x T rows (row stride `stride` elements) -> dst f32 [rows, dim] dense
+int launch_stream_to_f32(int dtype, const void* x, long stride, int rows, int dim, float* dst, hipStream_t stream);
+// Weight folding (ap_vit_finalize).  w32: f32 [rows, ld] (zero padded beyond cols).
+//   fold_ln: wout T [rows, ld] = T(w32[n][k] * gamma[k]); colsum[n] = sum_k float(wout[n][k]);
+//            bias_out[n] = bias_in[n] + sum_k w32[n][k] * beta[k]
+//   fold_ls: wout T [rows, ld] = T(w32[n][k] * ls[n]);  bias_out[n] = bias_in[n] * ls[n]   (ls may be null: plain convert)
+int launch_fold_ln(int dtype, const float* w32, int rows, int cols, int ld, const float* gamma, const float* beta,
+                   const float* bias_in, void* wout, float* colsum, float* bias_out, hipStream_t stream);
+int launch_fold_ls(int dtype, const float* w32, int rows, int cols, int ld, const float* ls, const float* bias_in,
+                   void* wout, float* bias_out, hipStream_t stream);
 int launch_cls_init(float* tok, const float* cls, const float* pos, int n, int tokens, int dim,
                     hipStream_t stream);
 int launch_convert(int dtype, const float* src, void* dst, size_t count, hipStream_t stream);

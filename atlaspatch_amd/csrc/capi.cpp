@@ -23,7 +23,7 @@ void set_error(const char* fmt, ...) {
 
 extern "C" {
 
-int ap_abi_version(void) { return 9; }
+int ap_abi_version(void) { return 10; }
 
 const char* ap_last_error(void) { return ap::g_error; }
 
@@ -136,6 +136,34 @@ int ap_gemm(int dtype, int epilogue, const void* A, int lda, const void* W, int 
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K;
     g.bias = bias; g.gamma = gamma; g.out = out; g.ldo = ldo;
     return ap::launch_gemm_impl(dtype, epilogue, g, impl, variant, (hipStream_t)stream);
+}
+
+int ap_gemm_fused(int dtype, int epilogue, const void* A, int lda, const void* W, int ldw, int M, int N, int K,
+                  const float* bias, const float* colsum, const float* rowstats, float* partial, void* out, int ldo,
+                  ap_stream_t stream) {
+    AP_REQUIRE(A && W && bias && out, "ap_gemm_fused: null pointer");
+    AP_REQUIRE(dtype == AP_F16 || dtype == AP_BF16, "ap_gemm_fused: f16 / bf16 only");
+    int epi;
+    if (epilogue == AP_EPI_NORM) epi = ap::EPI_NORM_STORE;
+    else if (epilogue == AP_EPI_NORM_GELU) epi = ap::EPI_NORM_GELU;
+    else if (epilogue == AP_EPI_RESID_STATS) epi = ap::EPI_RESID_STATS;
+    else { ap::set_error("ap_gemm_fused: unknown epilogue %d", epilogue); return AP_ERR_INVALID; }
+    AP_REQUIRE(epi == ap::EPI_RESID_STATS ? partial != nullptr : (colsum && rowstats), "ap_gemm_fused: missing operand for epilogue %d", epilogue);
+    ap::GemmArgs g{};
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K;
+    g.bias = bias; g.colsum = colsum; g.rowstats = rowstats; g.partial = partial; g.out = out; g.ldo = ldo;
+    AP_REQUIRE(M > 0 && ap::gemm256_supports(dtype, epi, g), "ap_gemm_fused: unsupported problem (N %% 256, K %% 128, 16-byte strides)");
+    return ap::launch_gemm256(dtype, epi, g, 0, (hipStream_t)stream);
+}
+
+int ap_stream_init(int dtype, const float* tok, int rows, int dim, float eps, void* x, float* rowstats, ap_stream_t stream) {
+    AP_REQUIRE(tok && x && rowstats, "ap_stream_init: null pointer");
+    return ap::launch_stream_init(dtype, tok, rows, dim, eps, x, rowstats, (hipStream_t)stream);
+}
+
+int ap_rowstats_finalize(const float* partial, int rows, int groups, int dim, float eps, float* rowstats, ap_stream_t stream) {
+    AP_REQUIRE(partial && rowstats && groups > 0 && dim > 0, "ap_rowstats_finalize: bad arguments");
+    return ap::launch_rowstats_finalize(partial, rows, groups, dim, eps, rowstats, (hipStream_t)stream);
 }
 
 int ap_gemm_trace(long long* device_buf, int tiles_per_workgroup) {

@@ -247,6 +247,133 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, l
     }
 }
 
+
+// ---- fused-LayerNorm path (16-bit residual stream; vit.cpp::run_blocks_fused) -------------------------------
+// stream_init: the f32 token matrix the patch-embed GEMM wrote -> the T stream + the row statistics of the ROUNDED
+// row (what the first fused GEMM multiplies): two-pass mean / variance like the LayerNorm kernels.  One wave per row.
+template <typename T>
+__global__ __launch_bounds__(256) void stream_init_kernel(const float* __restrict__ tok, int rows, int dim, float eps,
+                                                          T* __restrict__ x, float* __restrict__ rowstats) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nvec = dim >> 2;
+    const f32x4* src = (const f32x4*)(tok + (size_t)row * dim);
+    T* dst = x + (size_t)row * dim;
+    f32x4 v[kMaxVec];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxVec; ++i) {
+        const int idx = lane + i * 64;
+        if (idx < nvec) {
+            f32x4 a = src[idx];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = (float)from_f32<T>(a[e]);
+            v[i] = a;
+            store_vec4<T>(dst + idx * 4, a);
+            s += (a[0] + a[1]) + (a[2] + a[3]);
+        }
+    }
+    const float mean = wave_sum(s) / (float)dim;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxVec; ++i) {
+        const int idx = lane + i * 64;
+        if (idx < nvec) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[i][e] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)dim + eps);
+    if (lane == 0) {
+        rowstats[2 * (size_t)row] = rstd;
+        rowstats[2 * (size_t)row + 1] = -mean * rstd;
+    }
+}
+
+// partial (sum, sum of squares) per 64-column group, written by the EPI_RESID_STATS epilogue -> (rstd, -mean * rstd).
+// Combined in double in a fixed order (deterministic); one thread per row.
+__global__ void rowstats_finalize_kernel(const float* __restrict__ partial, int rows, int groups, int dim, float eps,
+                                         float* __restrict__ rowstats) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    const float2* p = (const float2*)partial + (size_t)row * groups;
+    double s = 0.0, q = 0.0;
+    for (int g = 0; g < groups; ++g) {
+        const float2 v = p[g];
+        s += (double)v.x;
+        q += (double)v.y;
+    }
+    const double mean = s / dim;
+    double var = q / dim - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    rowstats[2 * (size_t)row] = (float)rstd;
+    rowstats[2 * (size_t)row + 1] = (float)(-mean * rstd);
+}
+
+template <typename T>
+__global__ void stream_to_f32_kernel(const T* __restrict__ x, long stride, int rows, int dim, float* __restrict__ dst) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per 4 elements
+    const int per = dim >> 2;
+    if (i >= (size_t)rows * per) return;
+    const int row = (int)(i / per), c = (int)(i - (size_t)row * per) * 4;
+    *(f32x4*)(dst + (size_t)row * dim + c) = load_vec4<T>(x + (size_t)row * stride + c);
+}
+
+__device__ __forceinline__ float block_sum256(float v, float* red) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float r = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    return r;
+}
+
+// one 256-thread workgroup per weight row n
+template <typename T>
+__global__ __launch_bounds__(256) void fold_ln_kernel(const float* __restrict__ w32, int cols, int ld,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ bias_in, T* __restrict__ wout,
+                                                      float* __restrict__ colsum, float* __restrict__ bias_out) {
+    __shared__ float red[4];
+    const int n = blockIdx.x;
+    const float* src = w32 + (size_t)n * ld;
+    T* dst = wout + (size_t)n * ld;
+    float cs = 0.f, bs = 0.f;
+    for (int k = threadIdx.x; k < ld; k += 256) {
+        float wf = 0.f;
+        if (k < cols) {
+            const float w = src[k];
+            wf = (float)from_f32<T>(w * gamma[k]);
+            bs += w * beta[k];
+        }
+        dst[k] = from_f32<T>(wf);
+        cs += wf;
+    }
+    cs = block_sum256(cs, red);
+    bs = block_sum256(bs, red);
+    if (threadIdx.x == 0) {
+        colsum[n] = cs;
+        bias_out[n] = bias_in[n] + bs;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fold_ls_kernel(const float* __restrict__ w32, int cols, int ld,
+                                                      const float* __restrict__ ls, const float* __restrict__ bias_in,
+                                                      T* __restrict__ wout, float* __restrict__ bias_out) {
+    const int n = blockIdx.x;
+    const float sc = ls ? ls[n] : 1.0f;
+    const float* src = w32 + (size_t)n * ld;
+    T* dst = wout + (size_t)n * ld;
+    for (int k = threadIdx.x; k < ld; k += 256) dst[k] = from_f32<T>(k < cols ? src[k] * sc : 0.f);
+    if (threadIdx.x == 0) bias_out[n] = bias_in[n] * sc;
+}
+
 template <typename TD, typename TO>
 int launch_ln_typed(float* x, long stride, const LnAdds& add, int rows, int dim,
                     const float* gamma, const float* beta, float eps, void* out, hipStream_t stream) {
@@ -343,6 +470,56 @@ int launch_layernorm(int dtype, const float* x, long stride, int rows, int dim, 
 int launch_layernorm_f32out(const float* x, long stride, int rows, int dim, const float* gamma,
                             const float* beta, float eps, float* out, hipStream_t stream) {
     return launch_layernorm(AP_F32, x, stride, rows, dim, gamma, beta, eps, out, stream);
+}
+
+int launch_stream_init(int dtype, const float* tok, int rows, int dim, float eps, void* x, float* rowstats,
+                       hipStream_t stream) {
+    AP_REQUIRE(dim % 4 == 0 && dim <= 64 * 4 * kMaxVec, "stream_init: unsupported dim %d", dim);
+    if (rows <= 0) return AP_OK;
+    dim3 grid((rows + 3) / 4), block(256);
+    if (dtype == AP_F16) stream_init_kernel<f16><<<grid, block, 0, stream>>>(tok, rows, dim, eps, (f16*)x, rowstats);
+    else if (dtype == AP_BF16) stream_init_kernel<bf16><<<grid, block, 0, stream>>>(tok, rows, dim, eps, (bf16*)x, rowstats);
+    else { set_error("stream_init: dtype %d (f16 / bf16 only)", dtype); return AP_ERR_INVALID; }
+    AP_HIP_CHECK(hipGetLastError());
+    return AP_OK;
+}
+
+int launch_rowstats_finalize(const float* partial, int rows, int groups, int dim, float eps, float* rowstats,
+                             hipStream_t stream) {
+    if (rows <= 0) return AP_OK;
+    rowstats_finalize_kernel<<<(rows + 255) / 256, 256, 0, stream>>>(partial, rows, groups, dim, eps, rowstats);
+    AP_HIP_CHECK(hipGetLastError());
+    return AP_OK;
+}
+
+int launch_stream_to_f32(int dtype, const void* x, long stride, int rows, int dim, float* dst, hipStream_t stream) {
+    AP_REQUIRE(dim % 4 == 0 && stride % 4 == 0, "stream_to_f32: dim / stride must be multiples of 4");
+    if (rows <= 0) return AP_OK;
+    const size_t total = (size_t)rows * (dim >> 2);
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (dtype == AP_F16) stream_to_f32_kernel<f16><<<blocks, 256, 0, stream>>>((const f16*)x, stride, rows, dim, dst);
+    else if (dtype == AP_BF16) stream_to_f32_kernel<bf16><<<blocks, 256, 0, stream>>>((const bf16*)x, stride, rows, dim, dst);
+    else { set_error("stream_to_f32: dtype %d (f16 / bf16 only)", dtype); return AP_ERR_INVALID; }
+    AP_HIP_CHECK(hipGetLastError());
+    return AP_OK;
+}
+
+int launch_fold_ln(int dtype, const float* w32, int rows, int cols, int ld, const float* gamma, const float* beta,
+                   const float* bias_in, void* wout, float* colsum, float* bias_out, hipStream_t stream) {
+    if (dtype == AP_F16) fold_ln_kernel<f16><<<rows, 256, 0, stream>>>(w32, cols, ld, gamma, beta, bias_in, (f16*)wout, colsum, bias_out);
+    else if (dtype == AP_BF16) fold_ln_kernel<bf16><<<rows, 256, 0, stream>>>(w32, cols, ld, gamma, beta, bias_in, (bf16*)wout, colsum, bias_out);
+    else { set_error("fold_ln: dtype %d (f16 / bf16 only)", dtype); return AP_ERR_INVALID; }
+    AP_HIP_CHECK(hipGetLastError());
+    return AP_OK;
+}
+
+int launch_fold_ls(int dtype, const float* w32, int rows, int cols, int ld, const float* ls, const float* bias_in,
+                   void* wout, float* bias_out, hipStream_t stream) {
+    if (dtype == AP_F16) fold_ls_kernel<f16><<<rows, 256, 0, stream>>>(w32, cols, ld, ls, bias_in, (f16*)wout, bias_out);
+    else if (dtype == AP_BF16) fold_ls_kernel<bf16><<<rows, 256, 0, stream>>>(w32, cols, ld, ls, bias_in, (bf16*)wout, bias_out);
+    else { set_error("fold_ls: dtype %d (f16 / bf16 only)", dtype); return AP_ERR_INVALID; }
+    AP_HIP_CHECK(hipGetLastError());
+    return AP_OK;
 }
 
 int launch_cls_init(float* tok, const float* cls, const float* pos, int n, int tokens, int dim,

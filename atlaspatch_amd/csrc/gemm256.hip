@@ -89,6 +89,48 @@ template <> __device__ __forceinline__ u32x2 pack4<bf16>(f32x4 v) {
     return __builtin_bit_cast(u32x2, h);
 }
 
+__device__ __forceinline__ float dpp_add(float v, float w) { return v + w; }
+#define AP_DPP_F32(V, CTRL) __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, (V)), (CTRL), 0xF, 0xF, true))
+// sum over the 8 lanes that share (lane >> 3): xor-1, xor-2 (quad permutes), mirror within 8 -- every lane gets the total
+__device__ __forceinline__ float sum8(float v) {
+    v += AP_DPP_F32(v, 0xB1);
+    v += AP_DPP_F32(v, 0x4E);
+    v += AP_DPP_F32(v, 0x141);
+    return v;
+}
+
+// EPI_RESID_STATS element step on 8 packed values: y = T(d + r) (d = the branch output already rounded to T, r = the
+// stream), s += sum(y), q += sum(y^2) in f32.
+template <typename T> __device__ __forceinline__ u32x4 resid_add_stats(u32x4 d, u32x4 r, float& s, float& q);
+template <> __device__ __forceinline__ u32x4 resid_add_stats<f16>(u32x4 d, u32x4 r, float& s, float& q) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    u32x4 y;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t dk = d[k], rk = r[k];     // (bit_cast of a vector-element lvalue reads element 0: copy first)
+        const h2 c = __builtin_bit_cast(h2, dk) + __builtin_bit_cast(h2, rk);           // v_pk_add_f16: correctly rounded
+        y[k] = __builtin_bit_cast(uint32_t, c);
+        s = __builtin_amdgcn_fdot2(c, h2{(_Float16)1.0f, (_Float16)1.0f}, s, false);
+        q = __builtin_amdgcn_fdot2(c, c, q, false);
+    }
+    return y;
+}
+template <> __device__ __forceinline__ u32x4 resid_add_stats<bf16>(u32x4 d, u32x4 r, float& s, float& q) {
+    u32x4 y;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float d0 = __builtin_bit_cast(float, d[k] << 16), d1 = __builtin_bit_cast(float, d[k] & 0xffff0000u);
+        const float r0 = __builtin_bit_cast(float, r[k] << 16), r1 = __builtin_bit_cast(float, r[k] & 0xffff0000u);
+        const bf16x4 c4 = {(bf16)(d0 + r0), (bf16)(d1 + r1), (bf16)0.0f, (bf16)0.0f};
+        const u32x2 cc = __builtin_bit_cast(u32x2, c4);
+        y[k] = cc[0];
+        const float c0 = __builtin_bit_cast(float, cc[0] << 16), c1 = __builtin_bit_cast(float, cc[0] & 0xffff0000u);
+        s += c0 + c1;
+        q = __builtin_fmaf(c1, c1, __builtin_fmaf(c0, c0, q));
+    }
+    return y;
+}
+
 // Two LDS-DMA loads of one staging unit (16 B per lane each): LDS rows [0, 64) and [64, 128) of the
 // unit slice owned by this wave.  base: wave-uniform global address, off0 / off1: per-lane byte
 // offsets, lds_dst: wave-uniform LDS byte address.  M0 is saved and restored (compiler-reserved).
@@ -137,6 +179,8 @@ template <typename T, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) char smem[kLdsBytes];
 
+    constexpr bool kNorm = EPI == EPI_NORM_STORE || EPI == EPI_NORM_GELU;
+    constexpr bool kRes = EPI == EPI_RESID_STATS;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -245,6 +289,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
     // epilogue has no bias pass; the next tile's bias is fetched while the current epilogue runs.
     f32x16 acc[2][4];         // [n block of 32][m block of 32]
     f32x4 nbias[2][4];
+    // fused-LayerNorm epilogues (EPI_NORM_*): the accumulators start from zero, and the CURRENT tile's bias (in nbias),
+    // column sums and row statistics are requested before the drain that opens its epilogue
+    f32x4 ncs[2][4];
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 rst[4];
+    u32x4 res[16];            // EPI_RESID_STATS: the wave's 128 x 64 window of the stream, row-major 16 B per lane
+    u32x2 pk[2][4][4];        //   and the accumulators rounded to T ([n block][m block][group of 4 n])
     // The bias loads are inline asm with hand-placed waits.  A load hipcc tracks that is still pending at the
     // tile-loop header makes its waitcnt pass put static `s_waitcnt vmcnt(0..4)` in front of the first MFMAs of
     // EVERY tile (the first-entry state is merged into the back edge).  The waits are FULL drains placed where only
@@ -273,9 +324,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[nb][mb][e] = nbias[nb][e >> 2][e & 3];
+                for (int e = 0; e < 16; ++e) acc[nb][mb][e] = kNorm ? 0.0f : nbias[nb][e >> 2][e & 3];
     };
-    {
+    if constexpr (!kNorm) {
         const float* bp0 = bias_ptr(0, hi);
         AP_BIAS_LD8(bp0);
         AP_BIAS_WAIT(0);
@@ -416,7 +467,74 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
         const int hi = lane_e >> 5, l31 = lane_e & 31;
-        {
+        const int id = tw.first + ti * tw.stride;
+        int tr, tc;
+        tw.rc(id, tr, tc);
+        const int m0 = tr * kBM + wr * 128, n0 = tc * kBN + wc * 64;
+        const int rrow = lane_e >> 3, rc = lane_e & 7;
+        // The fused-LayerNorm epilogues fetch their operands with PLAIN loads followed by an explicit s_waitcnt built with
+        // the compiler's own builtin: the waitcnt pass sees that instruction and knows nothing is pending afterwards, and
+        // no register of a load can be copied before the wait (an inline-asm load with a separate inline-asm wait lets the
+        // register allocator place such copies in between: seen as a run-to-run race).  vmcnt(0) = 0x0F70 on gfx9
+        // (expcnt / lgkmcnt fields left at their maxima).  Only loads are outstanding here.
+        if constexpr (kNorm) {
+            // THIS tile's bias, column sums and row statistics
+            __builtin_amdgcn_sched_barrier(0);
+            const float* bp = bias_ptr(ti, hi);
+            const float* cp = g.colsum + (bp - g.bias);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    nbias[nb][g4] = *(const f32x4*)(bp + nb * 32 + g4 * 8);
+                    ncs[nb][g4] = *(const f32x4*)(cp + nb * 32 + g4 * 8);
+                }
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                int m = m0 + mb * 32 + l31;
+                m = m < g.M ? m : g.M - 1;
+                rst[mb] = *(const f32x2*)(g.rowstats + 2 * (size_t)m);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            __builtin_amdgcn_sched_barrier(0);
+        } else if constexpr (kRes) {
+            // next tile's bias and this tile's window of the stream (16 B per lane and row: the layout the transposed
+            // stores use)
+            __builtin_amdgcn_sched_barrier(0);
+            const float* nbp = bias_ptr(ti + 1 < tw.count ? ti + 1 : ti, hi);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) nbias[nb][g4] = *(const f32x4*)(nbp + nb * 32 + g4 * 8);
+            auto res_ld = [&](int j) {
+                int m = m0 + (j >> 2) * 32 + (j & 3) * 8 + rrow;
+                m = m < g.M ? m : g.M - 1;
+                res[j] = *(const u32x4*)((const T*)g.out + (size_t)m * g.ldo + n0 + rc * 8);
+            };
+#pragma unroll
+            for (int j = 0; j < 8; ++j) res_ld(j);
+            __builtin_amdgcn_sched_barrier(0);
+            // The accumulators (bias included) are rounded to T between the two groups of loads: the first group and the
+            // bias land in the main loop's 64 fragment registers, the packing frees 64 more for the second group.
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[nb][mb][g4 * 4 + e];
+                        pk[nb][mb][g4] = pack4<T>(v);
+                    }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 8; j < 16; ++j) res_ld(j);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
             // next tile's bias (its accumulators start from it), then ONE drain: the stream staged so far (next
             // tile's first K-tiles) and the bias have landed; only loads are outstanding here
             const float* nbp = bias_ptr(ti + 1 < tw.count ? ti + 1 : ti, hi);
@@ -424,16 +542,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
             AP_BIAS_WAIT(0);
         }
         stamp(ti, 2);
-        const int id = tw.first + ti * tw.stride;
-        int tr, tc;
-        tw.rc(id, tr, tc);
-        const int m0 = tr * kBM + wr * 128, n0 = tc * kBN + wc * 64;
-        const bool has_gamma = EPI != EPI_BIAS_GELU && g.gamma != nullptr;
+        const bool has_gamma = (EPI == EPI_BIAS_STORE || EPI == EPI_BIAS_RESID) && g.gamma != nullptr;
         const float* gp = g.gamma + n0 + hi * 4;
 #ifdef AP_G256_ALT
         if (g.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(ti, 3); }
 #endif
-        const int rrow = lane_e >> 3, rc = lane_e & 7;
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
             if constexpr (EPI == EPI_BIAS_RESID) {
@@ -473,7 +586,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
                         f32x4 v;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = acc[nb][mb][g4 * 4 + e];
-                        if constexpr (EPI == EPI_BIAS_GELU) {
+                        if constexpr (kNorm) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                v[e] = __builtin_fmaf(rst[mb][0], v[e], __builtin_fmaf(rst[mb][1], ncs[nb][g4][e], nbias[nb][g4][e]));
+                        }
+                        if constexpr (EPI == EPI_BIAS_GELU || EPI == EPI_NORM_GELU) {
                             const f32x2_t lo = gelu_sigmoid_poly2(f32x2_t{v[0], v[1]}), hi2 = gelu_sigmoid_poly2(f32x2_t{v[2], v[3]});
                             v = f32x4{lo[0], lo[1], hi2[0], hi2[1]};
                         }
@@ -482,13 +600,24 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] *= ga[e];
                         }
-                        *(u32x2*)(scr + l31 * 128 + (((nb * 4 + g4) ^ (l31 & 7)) << 4) + hi * 8) = pack4<T>(v);
+                        if constexpr (kRes) *(u32x2*)(scr + l31 * 128 + (((nb * 4 + g4) ^ (l31 & 7)) << 4) + hi * 8) = pk[nb][mb][g4];
+                        else *(u32x2*)(scr + l31 * 128 + (((nb * 4 + g4) ^ (l31 & 7)) << 4) + hi * 8) = pack4<T>(v);
                     }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int row = i * 8 + rrow;
-                    const u32x4 v = *(const u32x4*)(scr + row * 128 + ((rc ^ (row & 7)) << 4));
+                    u32x4 v = *(const u32x4*)(scr + row * 128 + ((rc ^ (row & 7)) << 4));
                     const int m = m0 + mb * 32 + row;
+                    if constexpr (kRes) {
+                        float s = 0.f, q = 0.f;
+                        v = resid_add_stats<T>(v, res[mb * 4 + i], s, q);
+                        s = sum8(s);
+                        q = sum8(q);
+                        if (m < g.M && rc == 0) {
+                            f32x2 sq = {s, q};
+                            *(f32x2*)(g.partial + ((size_t)m * (g.N >> 6) + (n0 >> 6)) * 2) = sq;
+                        }
+                    }
                     if (m < g.M) *(u32x4*)((T*)g.out + (size_t)m * g.ldo + n0 + rc * 8) = v;
                 }
             }
@@ -520,6 +649,9 @@ int launch_typed(int epilogue, const GemmArgs& a, int num_cu, int variant, hipSt
         case EPI_BIAS_STORE: return launch_epi<T, EPI_BIAS_STORE>(a, num_cu, variant, stream);
         case EPI_BIAS_GELU: return launch_epi<T, EPI_BIAS_GELU>(a, num_cu, variant, stream);
         case EPI_BIAS_RESID: return launch_epi<T, EPI_BIAS_RESID>(a, num_cu, variant, stream);
+        case EPI_NORM_STORE: return launch_epi<T, EPI_NORM_STORE>(a, num_cu, variant, stream);
+        case EPI_NORM_GELU: return launch_epi<T, EPI_NORM_GELU>(a, num_cu, variant, stream);
+        case EPI_RESID_STATS: return launch_epi<T, EPI_RESID_STATS>(a, num_cu, variant, stream);
     }
     set_error("gemm256: unsupported epilogue %d", epilogue);
     return AP_ERR_INVALID;
@@ -538,7 +670,10 @@ extern int g_gemm_trace_tiles;
 
 bool AP_G256_FN(gemm256_supports)(int dtype, int epilogue, const GemmArgs& a) {
     if (dtype != AP_F16 && dtype != AP_BF16) return false;
-    if (epilogue != EPI_BIAS_STORE && epilogue != EPI_BIAS_GELU && epilogue != EPI_BIAS_RESID) return false;
+    if (epilogue != EPI_BIAS_STORE && epilogue != EPI_BIAS_GELU && epilogue != EPI_BIAS_RESID &&
+        epilogue != EPI_NORM_STORE && epilogue != EPI_NORM_GELU && epilogue != EPI_RESID_STATS) return false;
+    if ((epilogue == EPI_NORM_STORE || epilogue == EPI_NORM_GELU) && (!a.colsum || !a.rowstats)) return false;
+    if (epilogue == EPI_RESID_STATS && !a.partial) return false;
     if (a.N % kBN != 0 || a.K % 128 != 0 || a.K < 128) return false;
     if (((size_t)a.lda * 2) % 16 != 0 || ((size_t)a.ldw * 2) % 16 != 0) return false;
     if ((size_t)255 * a.lda * 2 + 128 > 0xffffffffull || (size_t)255 * a.ldw * 2 + 128 > 0xffffffffull) return false;

@@ -24,6 +24,7 @@ struct Param {
     int rows = 0, cols = 0, ld = 0;   // matrices converted to T: [rows, ld] (cols <= ld, zero padded)
     bool matrix = false;
     void* dev = nullptr;   // f32 vector or T matrix
+    float* dev32 = nullptr; // matrices, 16-bit compute types: the f32 upload [rows, ld], kept until ap_vit_finalize has folded it
     bool set = false;
 };
 
@@ -34,6 +35,12 @@ namespace ap {
 struct BlockParams {
     const float *ln1_w, *ln1_b, *qkv_b, *proj_b, *ln2_w, *ln2_b, *fc1_b, *fc2_b, *ls1, *ls2;
     const Param *qkv, *proj, *fc1, *fc2;
+};
+// Fused-LayerNorm path (16-bit compute types): the weights that consume a LayerNorm output carry its gain
+// (W' = T(W * gamma), colsum[n] = sum_k W'[n][k], bias' = b + W beta); the branch projections carry LayerScale.
+struct FusedBlock {
+    void *qkv_w = nullptr, *fc1_w = nullptr, *proj_w = nullptr, *fc2_w = nullptr;      // T [rows, ld] (ld of the plain Param)
+    float *qkv_cs = nullptr, *qkv_b = nullptr, *fc1_cs = nullptr, *fc1_b = nullptr, *proj_b = nullptr, *fc2_b = nullptr;
 };
 struct PoolParams {
     const float *ln_k_w, *ln_k_b, *kv_b, *q, *out_b, *ln_out_w, *ln_out_b;
@@ -52,7 +59,9 @@ struct ap_vit {
     const ap::Param* pe_w = nullptr;
     const float *pe_b = nullptr, *cls = nullptr, *pos = nullptr, *norm_w = nullptr, *norm_b = nullptr;
     // options (ap_vit_set_option; the defaults come from the environment once, at creation)
-    bool full_last_block = false, two_half_overlap = false;
+    bool full_last_block = false, two_half_overlap = false, f32_stream = false;
+    std::vector<ap::FusedBlock> fused;      // filled by ap_vit_finalize for f16 / bf16
+    std::vector<void*> fused_allocs;
     int device = 0;
     // optional per-launch HIP-event timing (ap_vit_profile_*): kind -> events of the last forwards
     bool profile = false;
@@ -109,6 +118,7 @@ const Param* find(const ap_vit* m, const std::string& name) {
 
 struct Workspace {
     float* tok; void* xn; void* qkv; void* att; void* hid; void* delta; void* delta2;
+    void* x16; float* rowstats; float* partial;      // fused-LayerNorm path: T stream [M, D], f32 [M, 2], f32 [M, D / 64, 2]
     size_t total;
 };
 
@@ -128,14 +138,27 @@ Workspace carve(const ap_vit* m, int n, char* base) {
     const size_t pe_bytes = (size_t)n * m->patches * m->kpe * es;
     if (pe_bytes > hid_bytes) hid_bytes = pe_bytes;
     const size_t o_hid = take(hid_bytes);
+    const bool has_fused = m->cfg.compute_dtype != AP_F32;
+    const size_t o_x16 = has_fused ? take(M * D * es) : 0;
+    const size_t o_rs = has_fused ? take(M * 2 * sizeof(float)) : 0;
+    const size_t o_part = has_fused ? take(M * (D / 64) * 2 * sizeof(float)) : 0;
+    w.x16 = has_fused ? base + o_x16 : nullptr;
+    w.rowstats = has_fused ? (float*)(base + o_rs) : nullptr;
+    w.partial = has_fused ? (float*)(base + o_part) : nullptr;
     w.tok = (float*)(base + o_tok); w.xn = base + o_xn; w.qkv = base + o_qkv;
     w.att = base + o_att; w.hid = base + o_hid; w.delta = base + o_delta; w.delta2 = base + o_delta2; w.total = off;
     return w;
 }
 
-int run_blocks(ap_vit* m, int n, const Workspace& w, float* out, hipStream_t stream) {
+// What the block loop leaves for the final LayerNorm: tok (f32, row stride tok_stride as seen from the CLS rows) plus at
+// most one branch output still to be added.
+struct StreamTail {
+    const void* pending = nullptr; const float* pending_ls = nullptr; long pending_stride = 0; long tok_stride = 0;
+};
+
+int patch_embed(ap_vit* m, int n, const Workspace& w, hipStream_t stream) {
     const ap_vit_config& c = m->cfg;
-    const int dt = c.compute_dtype, D = c.dim, M = n * m->tokens;
+    const int dt = c.compute_dtype, D = c.dim;
     int rc;
     // patch embedding: tok[img][1 + p] = pe_row @ W^T + b + pos[1 + p]
     {
@@ -150,6 +173,14 @@ int run_blocks(ap_vit* m, int n, const Workspace& w, float* out, hipStream_t str
           if ((rc = ap::launch_gemm(dt, ap::EPI_PATCH_EMBED, g, stream)) != AP_OK) return rc; }
         if ((rc = ap::launch_cls_init(w.tok, m->cls, m->pos, n, m->tokens, D, stream)) != AP_OK) return rc;
     }
+    return AP_OK;
+}
+
+// ---- block loop, f32 residual stream (float32 mode; AP_VIT_OPT_F32_STREAM for f16 / bf16)
+int blocks_f32_stream(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipStream_t stream) {
+    const ap_vit_config& c = m->cfg;
+    const int dt = c.compute_dtype, D = c.dim, M = n * m->tokens;
+    int rc;
     // Residual stream: tok (f32) is only ever touched by the add+LayerNorm kernel.  A branch GEMM
     // (proj, fc2) stores its output delta = acc + bias in T; LayerNorm launches fold it into the
     // stream in f32 (tok += delta * layer_scale) before normalising.  The stream is written back once
@@ -260,10 +291,135 @@ int run_blocks(ap_vit* m, int n, const Workspace& w, float* out, hipStream_t str
         pending = w.delta;
         pending_ls = bp.ls2;
     }
+    st.pending = pending; st.pending_ls = pending_ls;
+    st.tok_stride = (long)m->tokens * D;
+    st.pending_stride = cls_tail ? pending_stride : (long)m->tokens * D;
+    return AP_OK;
+}
+
+// ---- block loop, fused LayerNorm (f16 / bf16 default).  The residual stream x lives in HBM in T and is the A operand
+// of the qkv / fc1 GEMMs directly: their weights carry the LayerNorm gain and the epilogue applies the row statistics
+// (EPI_NORM_*); the proj / fc2 GEMMs add their result to x in place and emit per-row partial sums of the new row
+// (EPI_RESID_STATS) from which a tiny kernel builds the next statistics.  No standalone add+LayerNorm pass: per element
+// and block the stream costs 2 x (2 B read + 2 B written) inside GEMM epilogues instead of 22 B in two streaming passes.
+int blocks_fused(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipStream_t stream) {
+    const ap_vit_config& c = m->cfg;
+    const int dt = c.compute_dtype, D = c.dim, M = n * m->tokens, G = D / 64;
+    const size_t es = ap::dtype_size(dt);
+    int rc;
+    { ScopedTimer t(m, AP_PROF_LAYERNORM, stream);
+      if ((rc = ap::launch_stream_init(dt, w.tok, M, D, c.ln_eps, w.x16, w.rowstats, stream)) != AP_OK) return rc; }
+    const bool cls_tail = c.pool == AP_POOL_CLS && !m->full_last_block && D / c.heads == 64;
+    auto finalize_stats = [&]() -> int {
+        ScopedTimer t(m, AP_PROF_LAYERNORM, stream);
+        return ap::launch_rowstats_finalize(w.partial, M, G, D, c.ln_eps, w.rowstats, stream);
+    };
+    for (int i = 0; i < c.depth; ++i) {
+        const ap::BlockParams& bp = m->blocks[i];
+        const ap::FusedBlock& fb = m->fused[i];
+        if (i == c.depth - 1 && cls_tail) {
+            // ---- last block, CLS readout (see blocks_f32_stream): K and V of every token from the stream, then the CLS
+            // rows alone continue on the f32 path (their stream rows widened to f32, plain LayerNorm launches, unfolded
+            // weights on the 128x128 kernel).
+            {
+                ap::GemmArgs g{};
+                g.A = w.x16; g.lda = D; g.W = (const char*)fb.qkv_w + (size_t)D * bp.qkv->ld * es; g.ldw = bp.qkv->ld;
+                g.M = M; g.N = 2 * D; g.K = D; g.bias = fb.qkv_b + D; g.colsum = fb.qkv_cs + D; g.rowstats = w.rowstats;
+                g.out = (char*)w.qkv + (size_t)D * es; g.ldo = 3 * D;
+                ScopedTimer t(m, AP_PROF_GEMM_QKV, stream);
+                if ((rc = ap::launch_gemm_impl(dt, ap::EPI_NORM_STORE, g, 256, 0, stream)) != AP_OK) return rc;
+            }
+            ScopedTimer t(m, AP_PROF_CLS_TAIL, stream);
+            if ((rc = ap::launch_stream_to_f32(dt, w.x16, (long)m->tokens * D, n, D, w.tok, stream)) != AP_OK) return rc;
+            if ((rc = ap::launch_add2_layernorm(dt, dt, w.tok, D, nullptr, 0, nullptr, nullptr, 0, nullptr, /*store=*/0,
+                                                n, D, bp.ln1_w, bp.ln1_b, c.ln_eps, w.xn, stream)) != AP_OK) return rc;
+            char* q_cls = (char*)w.att;                                   // T [n, D]
+            char* a_cls = (char*)w.att + (size_t)n * D * es;              // T [n, D]
+            {
+                ap::GemmArgs g{};                                          // q for the CLS rows
+                g.A = w.xn; g.lda = D; g.W = bp.qkv->dev; g.ldw = bp.qkv->ld;
+                g.M = n; g.N = D; g.K = D; g.bias = bp.qkv_b; g.out = q_cls; g.ldo = D;
+                if ((rc = ap::launch_gemm_impl(dt, ap::EPI_BIAS_STORE, g, 128, 0, stream)) != AP_OK) return rc;
+            }
+            if ((rc = ap::launch_attention_cls(dt, q_cls, w.qkv, 3 * D, D, 2 * D, a_cls, n, m->tokens, c.heads,
+                                               D / c.heads, stream)) != AP_OK) return rc;
+            {
+                ap::GemmArgs g{};
+                g.A = a_cls; g.lda = D; g.W = bp.proj->dev; g.ldw = bp.proj->ld;
+                g.M = n; g.N = D; g.K = D; g.bias = bp.proj_b; g.out = w.delta2; g.ldo = D;
+                if ((rc = ap::launch_gemm_impl(dt, ap::EPI_BIAS_STORE, g, 128, 0, stream)) != AP_OK) return rc;
+            }
+            if ((rc = ap::launch_add2_layernorm(dt, dt, w.tok, D, nullptr, 0, nullptr, w.delta2, D, bp.ls1, /*store=*/1, n, D,
+                                                bp.ln2_w, bp.ln2_b, c.ln_eps, w.xn, stream)) != AP_OK) return rc;
+            {
+                ap::GemmArgs g{};
+                g.A = w.xn; g.lda = D; g.W = bp.fc1->dev; g.ldw = bp.fc1->ld;
+                g.M = n; g.N = c.mlp_dim; g.K = D; g.bias = bp.fc1_b; g.out = w.hid; g.ldo = c.mlp_dim;
+                if ((rc = ap::launch_gemm_impl(dt, ap::EPI_BIAS_GELU, g, 128, 0, stream)) != AP_OK) return rc;
+            }
+            {
+                ap::GemmArgs g{};
+                g.A = w.hid; g.lda = c.mlp_dim; g.W = bp.fc2->dev; g.ldw = bp.fc2->ld;
+                g.M = n; g.N = D; g.K = c.mlp_dim; g.bias = bp.fc2_b; g.out = w.delta; g.ldo = D;
+                if ((rc = ap::launch_gemm_impl(dt, ap::EPI_BIAS_STORE, g, 128, 0, stream)) != AP_OK) return rc;
+            }
+            st.pending = w.delta; st.pending_ls = bp.ls2; st.pending_stride = D; st.tok_stride = D;
+            return AP_OK;
+        }
+        {
+            ap::GemmArgs g{};
+            g.A = w.x16; g.lda = D; g.W = fb.qkv_w; g.ldw = bp.qkv->ld;
+            g.M = M; g.N = 3 * D; g.K = D; g.bias = fb.qkv_b; g.colsum = fb.qkv_cs; g.rowstats = w.rowstats;
+            g.out = w.qkv; g.ldo = 3 * D;
+            ScopedTimer t(m, AP_PROF_GEMM_QKV, stream);
+            if ((rc = ap::launch_gemm_impl(dt, ap::EPI_NORM_STORE, g, 256, 0, stream)) != AP_OK) return rc;
+        }
+        { ScopedTimer t(m, AP_PROF_ATTENTION, stream);
+          if ((rc = ap::launch_attention(dt, w.qkv, w.att, n, m->tokens, c.heads, D / c.heads, stream)) != AP_OK) return rc; }
+        {
+            ap::GemmArgs g{};
+            g.A = w.att; g.lda = D; g.W = fb.proj_w; g.ldw = bp.proj->ld;
+            g.M = M; g.N = D; g.K = D; g.bias = fb.proj_b; g.out = w.x16; g.ldo = D; g.partial = w.partial;
+            ScopedTimer t(m, AP_PROF_GEMM_PROJ, stream);
+            if ((rc = ap::launch_gemm_impl(dt, ap::EPI_RESID_STATS, g, 256, 0, stream)) != AP_OK) return rc;
+        }
+        if ((rc = finalize_stats()) != AP_OK) return rc;
+        {
+            ap::GemmArgs g{};
+            g.A = w.x16; g.lda = D; g.W = fb.fc1_w; g.ldw = bp.fc1->ld;
+            g.M = M; g.N = c.mlp_dim; g.K = D; g.bias = fb.fc1_b; g.colsum = fb.fc1_cs; g.rowstats = w.rowstats;
+            g.out = w.hid; g.ldo = c.mlp_dim;
+            ScopedTimer t(m, AP_PROF_GEMM_FC1, stream);
+            if ((rc = ap::launch_gemm_impl(dt, ap::EPI_NORM_GELU, g, 256, 0, stream)) != AP_OK) return rc;
+        }
+        {
+            ap::GemmArgs g{};
+            g.A = w.hid; g.lda = c.mlp_dim; g.W = fb.fc2_w; g.ldw = bp.fc2->ld;
+            g.M = M; g.N = D; g.K = c.mlp_dim; g.bias = fb.fc2_b; g.out = w.x16; g.ldo = D; g.partial = w.partial;
+            ScopedTimer t(m, AP_PROF_GEMM_FC2, stream);
+            if ((rc = ap::launch_gemm_impl(dt, ap::EPI_RESID_STATS, g, 256, 0, stream)) != AP_OK) return rc;
+        }
+        if (i + 1 < c.depth && (rc = finalize_stats()) != AP_OK) return rc;
+    }
+    // every block ran on the stream (attentional pooling, or AP_VIT_OPT_FULL_LAST_BLOCK): widen it for the final LayerNorm
+    if ((rc = ap::launch_stream_to_f32(dt, w.x16, D, M, D, w.tok, stream)) != AP_OK) return rc;
+    st.pending = nullptr; st.pending_ls = nullptr; st.pending_stride = 0; st.tok_stride = (long)m->tokens * D;
+    return AP_OK;
+}
+
+int run_blocks(ap_vit* m, int n, const Workspace& w, float* out, hipStream_t stream) {
+    const ap_vit_config& c = m->cfg;
+    const int dt = c.compute_dtype, D = c.dim, M = n * m->tokens;
+    int rc;
+    if ((rc = patch_embed(m, n, w, stream)) != AP_OK) return rc;
+    StreamTail st;
+    const bool fused = dt != AP_F32 && !m->f32_stream;
+    if ((rc = fused ? blocks_fused(m, n, w, st, stream) : blocks_f32_stream(m, n, w, st, stream)) != AP_OK) return rc;
+    const void* pending = st.pending;
+    const float* pending_ls = st.pending_ls;
     if (c.pool == AP_POOL_CLS)
         // final LayerNorm on the CLS row of every image (last fc2 output folded in first) -> out f32 [n, D]
-        return ap::launch_add_layernorm(dt, AP_F32, w.tok, (long)m->tokens * D, pending,
-                                        cls_tail ? pending_stride : (long)m->tokens * D, pending_ls,
+        return ap::launch_add_layernorm(dt, AP_F32, w.tok, st.tok_stride, pending, st.pending_stride, pending_ls,
                                         n, D, m->norm_w,
                                         m->norm_b, c.ln_eps, out, stream);
 
@@ -347,6 +503,7 @@ int ap_vit_create(const ap_vit_config* cfg, ap_vit** out) {
     AP_HIP_CHECK(hipGetDevice(&m->device));
     m->full_last_block = getenv("AP_VIT_FULL_LAST_BLOCK") != nullptr;     // defaults only; ap_vit_set_option changes them
     m->two_half_overlap = getenv("AP_VIT_OVERLAP") != nullptr;
+    m->f32_stream = getenv("AP_VIT_F32_STREAM") != nullptr;
     int rc = AP_OK;
     auto add = [&](const std::string& name, int rows, int cols, bool matrix) {
         if (rc == AP_OK) rc = alloc_param(m, name, rows, cols, matrix);
@@ -383,8 +540,11 @@ int ap_vit_create(const ap_vit_config* cfg, ap_vit** out) {
 
 void ap_vit_destroy(ap_vit* m) {
     if (!m) return;
-    for (auto& kv : m->params)
+    for (auto& kv : m->params) {
         if (kv.second.dev) (void)hipFree(kv.second.dev);
+        if (kv.second.dev32) (void)hipFree(kv.second.dev32);
+    }
+    for (void* p : m->fused_allocs) (void)hipFree(p);
     for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->ev_join) (void)hipEventDestroy(m->ev_join);
@@ -409,7 +569,12 @@ int ap_vit_set_param(ap_vit* m, const char* name, const float* host, size_t coun
         int rc = ap::launch_convert(m->cfg.compute_dtype, tmp, p.dev, (size_t)p.rows * p.ld, nullptr);
         if (rc != AP_OK) { (void)hipFree(tmp); return rc; }
         AP_HIP_CHECK(hipDeviceSynchronize());
-        AP_HIP_CHECK(hipFree(tmp));
+        if (p.dev32) { (void)hipFree(p.dev32); p.dev32 = nullptr; }
+        // 16-bit compute types: ap_vit_finalize folds the LayerNorm gains / LayerScale into the block weights from the
+        // f32 values (one rounding), so the upload is kept until then
+        const bool is_block = strncmp(name, "blocks.", 7) == 0;
+        if (m->cfg.compute_dtype != AP_F32 && is_block) p.dev32 = tmp;
+        else AP_HIP_CHECK(hipFree(tmp));
     }
     p.set = true;
     return AP_OK;
@@ -449,6 +614,47 @@ int ap_vit_finalize(ap_vit* m) {
         pp.out = find(m, "attn_pool.out.weight"); pp.out_b = vec("attn_pool.out.bias");
         pp.ln_out_w = vec("attn_pool.ln_out.weight"); pp.ln_out_b = vec("attn_pool.ln_out.bias");
     }
+    // ---- fused-LayerNorm weights (f16 / bf16): folded once from the f32 uploads, which are released afterwards
+    bool any32 = false;
+    for (auto& kv : m->params) any32 = any32 || kv.second.dev32 != nullptr;
+    if (m->cfg.compute_dtype != AP_F32 && !any32 && !m->fused.empty()) {
+        m->finalized = true;           // finalize called again without new uploads: the folded weights stand
+        return AP_OK;
+    }
+    for (void* p : m->fused_allocs) (void)hipFree(p);
+    m->fused_allocs.clear();
+    m->fused.clear();
+    if (m->cfg.compute_dtype != AP_F32) {
+        const int dt = m->cfg.compute_dtype, D = m->cfg.dim, H = m->cfg.mlp_dim;
+        const size_t es = ap::dtype_size(dt);
+        m->fused.resize(m->cfg.depth);
+        int rc = AP_OK;
+        auto dalloc = [&](size_t bytes) -> void* {
+            void* p = nullptr;
+            if (rc == AP_OK && hipMalloc(&p, bytes) != hipSuccess) { ap::set_error("vit_finalize: hipMalloc of %zu bytes failed", bytes); rc = AP_ERR_HIP; }
+            if (p) m->fused_allocs.push_back(p);
+            return p;
+        };
+        for (int i = 0; i < m->cfg.depth && rc == AP_OK; ++i) {
+            const ap::BlockParams& bp = m->blocks[i];
+            ap::FusedBlock& fb = m->fused[i];
+            for (const Param* p : {bp.qkv, bp.proj, bp.fc1, bp.fc2})
+                if (!p->dev32) { ap::set_error("vit_finalize: block %d: after a finalize, changing one block parameter needs all four block matrices uploaded again", i); return AP_ERR_STATE; }
+            fb.qkv_w = dalloc((size_t)3 * D * bp.qkv->ld * es); fb.qkv_cs = (float*)dalloc(3 * D * 4); fb.qkv_b = (float*)dalloc(3 * D * 4);
+            fb.fc1_w = dalloc((size_t)H * bp.fc1->ld * es); fb.fc1_cs = (float*)dalloc(H * 4); fb.fc1_b = (float*)dalloc(H * 4);
+            fb.proj_w = dalloc((size_t)D * bp.proj->ld * es); fb.proj_b = (float*)dalloc(D * 4);
+            fb.fc2_w = dalloc((size_t)D * bp.fc2->ld * es); fb.fc2_b = (float*)dalloc(D * 4);
+            if (rc != AP_OK) break;
+            if ((rc = ap::launch_fold_ln(dt, bp.qkv->dev32, 3 * D, D, bp.qkv->ld, bp.ln1_w, bp.ln1_b, bp.qkv_b, fb.qkv_w, fb.qkv_cs, fb.qkv_b, nullptr)) != AP_OK) break;
+            if ((rc = ap::launch_fold_ln(dt, bp.fc1->dev32, H, D, bp.fc1->ld, bp.ln2_w, bp.ln2_b, bp.fc1_b, fb.fc1_w, fb.fc1_cs, fb.fc1_b, nullptr)) != AP_OK) break;
+            if ((rc = ap::launch_fold_ls(dt, bp.proj->dev32, D, D, bp.proj->ld, bp.ls1, bp.proj_b, fb.proj_w, fb.proj_b, nullptr)) != AP_OK) break;
+            if ((rc = ap::launch_fold_ls(dt, bp.fc2->dev32, D, H, bp.fc2->ld, bp.ls2, bp.fc2_b, fb.fc2_w, fb.fc2_b, nullptr)) != AP_OK) break;
+        }
+        if (rc != AP_OK) return rc;
+        AP_HIP_CHECK(hipDeviceSynchronize());
+        for (auto& kv : m->params)
+            if (kv.second.dev32) { (void)hipFree(kv.second.dev32); kv.second.dev32 = nullptr; }
+    }
     m->finalized = true;
     return AP_OK;
 }
@@ -457,6 +663,7 @@ int ap_vit_set_option(ap_vit* m, int option, int value) {
     AP_REQUIRE(m, "vit_set_option: null handle");
     if (option == AP_VIT_OPT_FULL_LAST_BLOCK) m->full_last_block = value != 0;
     else if (option == AP_VIT_OPT_TWO_HALF_OVERLAP) m->two_half_overlap = value != 0;
+    else if (option == AP_VIT_OPT_F32_STREAM) m->f32_stream = value != 0;
     else { ap::set_error("vit_set_option: unknown option %d", option); return AP_ERR_INVALID; }
     return AP_OK;
 }

@@ -285,11 +285,13 @@ class HipViT:
                                                    _lib.current_stream_ptr(self.device)), "ap_vit_forward_chw")
         return out
 
-    OPTIONS = {"full_last_block": 0, "two_half_overlap": 1}
+    OPTIONS = {"full_last_block": 0, "two_half_overlap": 1, "f32_stream": 2}
 
     def set_option(self, name: str, on: bool) -> None:
         """``full_last_block``: the last block for every token instead of the CLS row only; ``two_half_overlap``: a
-        batch >= 512 as two halves on two streams.  Both leave the features unchanged (tested)."""
+        batch >= 512 as two halves on two streams.  Both leave the features unchanged (tested).  ``f32_stream``
+        (f16 / bf16): float32 residual stream with standalone add+LayerNorm launches instead of the fused-LayerNorm
+        dataflow (slower, closer to the fp32 path)."""
         _lib.check(self.lib.ap_vit_set_option(self._handle, self.OPTIONS[name], 1 if on else 0), "ap_vit_set_option")
 
     def profile(self, on: bool) -> None:

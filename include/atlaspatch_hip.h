@@ -181,9 +181,14 @@ int ap_vit_finalize(ap_vit* m);   /* checks every parameter was set */
 /* Options (defaults: off; the environment variables AP_VIT_FULL_LAST_BLOCK / AP_VIT_OVERLAP set the defaults once, when
  * the object is created -- nothing on the launch path reads the environment):
  *   AP_VIT_OPT_FULL_LAST_BLOCK    compute the last block for every token instead of the CLS row only (same features)
- *   AP_VIT_OPT_TWO_HALF_OVERLAP   run a batch >= 512 as two halves on two streams (same features) */
+ *   AP_VIT_OPT_TWO_HALF_OVERLAP   run a batch >= 512 as two halves on two streams (same features)
+ *   AP_VIT_OPT_F32_STREAM         f16 / bf16 only: keep the residual stream in float32 and normalise it with standalone
+ *                                 add+LayerNorm launches (round 1's dataflow; environment default AP_VIT_F32_STREAM).
+ *                                 The default for f16 / bf16 keeps the stream in the compute type -- what the reference's
+ *                                 own model.half() does -- with LayerNorm fused into the neighbouring GEMMs */
 #define AP_VIT_OPT_FULL_LAST_BLOCK 0
 #define AP_VIT_OPT_TWO_HALF_OVERLAP 1
+#define AP_VIT_OPT_F32_STREAM 2
 int ap_vit_set_option(ap_vit* m, int option, int value);
 
 size_t ap_vit_workspace_bytes(const ap_vit* m, int n);
@@ -238,6 +243,31 @@ int ap_vit_forward_chw(ap_vit* m, const void* x, int x_dtype, int n,
 int ap_gemm(int dtype, int epilogue, const void* A, int lda, const void* W, int ldw,
             int M, int N, int K, const float* bias, const float* gamma, void* out, int ldo,
             int impl, int variant, ap_stream_t stream);
+
+/* ---- fused-LayerNorm operators (what ap_vit_forward_* chains for f16 / bf16 unless AP_VIT_OPT_F32_STREAM is set) ----
+ * The pre-LN block of the reference's encoders (nn.LayerNorm -> nn.Linear, models/patch/vit.py / uni.py / conch.py via
+ * timm / torchvision Block.forward: x = x + ls1 * attn(norm1(x)); x = x + ls2 * mlp(norm2(x))) with the residual
+ * stream x kept in T and NO standalone LayerNorm pass:
+ *   LN(x) W^T + b  =  rstd[m] * (sum_k x[m][k] W'[n][k]  -  mean[m] * colsum[n]) + bias'[n]
+ * with W' = T(W * gamma) (the caller folds the LayerNorm gain into the weights), colsum[n] = sum_k W'[n][k],
+ * bias' = b + W beta and rowstats[m] = (rstd, -mean * rstd) of row m of x.
+ *   AP_EPI_NORM         out T [M, ldo] = rstd * acc + (-mean rstd) * colsum[n] + bias[n]
+ *   AP_EPI_NORM_GELU    out = gelu(that)
+ *   AP_EPI_RESID_STATS  out T [M, ldo] (in place) = T(out + T(acc + bias[n]))  -- the residual add -- and
+ *                       partial f32 [M, N / 64, 2] = per row and 64-column group (sum, sum of squares) of the NEW row;
+ *                       ap_rowstats_finalize turns them into the next rowstats (deterministic, fixed order, double).
+ * Persistent 256 x 256 kernel only: N % 256 == 0, K % 128 == 0; any M >= 1.  f16 / bf16.
+ * ap_stream_init: tok f32 [rows, dim] -> x T [rows, dim] + rowstats of the rounded rows (two-pass). */
+#define AP_EPI_NORM 4
+#define AP_EPI_NORM_GELU 5
+#define AP_EPI_RESID_STATS 6
+int ap_gemm_fused(int dtype, int epilogue, const void* A, int lda, const void* W, int ldw, int M, int N, int K,
+                  const float* bias, const float* colsum, const float* rowstats, float* partial,
+                  void* out, int ldo, ap_stream_t stream);
+int ap_stream_init(int dtype, const float* tok, int rows, int dim, float eps, void* x, float* rowstats,
+                   ap_stream_t stream);
+int ap_rowstats_finalize(const float* partial, int rows, int groups, int dim, float eps, float* rowstats,
+                         ap_stream_t stream);
 
 /* Diagnostics for the persistent kernel's instrumented twin (impl 257; the product kernel, impl 256, carries no
  * diagnostic code): when device_buf is non-null every later impl-257 launch records, per (workgroup, tile) with tile < tiles_per_workgroup, eight int64 stamps of the

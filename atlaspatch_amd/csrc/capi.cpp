@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <climits>
 #include <cstring>
+#include <cstdlib>
 #include <vector>
 #include <zlib.h>
 #include "ap_common.h"

@@ -587,9 +587,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = acc[nb][mb][g4 * 4 + e];
                         if constexpr (kNorm) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                v[e] = __builtin_fmaf(rst[mb][0], v[e], __builtin_fmaf(rst[mb][1], ncs[nb][g4][e], nbias[nb][g4][e]));
+                            // two values per instruction (v_pk_fma_f32): y = rstd * acc + (nmr * colsum + bias)
+                            const f32x2_t rs2 = {rst[mb][0], rst[mb][0]}, nm2 = {rst[mb][1], rst[mb][1]};
+                            const f32x2_t lo = __builtin_elementwise_fma(rs2, f32x2_t{v[0], v[1]},
+                                __builtin_elementwise_fma(nm2, f32x2_t{ncs[nb][g4][0], ncs[nb][g4][1]}, f32x2_t{nbias[nb][g4][0], nbias[nb][g4][1]}));
+                            const f32x2_t hi2 = __builtin_elementwise_fma(rs2, f32x2_t{v[2], v[3]},
+                                __builtin_elementwise_fma(nm2, f32x2_t{ncs[nb][g4][2], ncs[nb][g4][3]}, f32x2_t{nbias[nb][g4][2], nbias[nb][g4][3]}));
+                            v = f32x4{lo[0], lo[1], hi2[0], hi2[1]};
                         }
                         if constexpr (EPI == EPI_BIAS_GELU || EPI == EPI_NORM_GELU) {
                             const f32x2_t lo = gelu_sigmoid_poly2(f32x2_t{v[0], v[1]}), hi2 = gelu_sigmoid_poly2(f32x2_t{v[2], v[3]});

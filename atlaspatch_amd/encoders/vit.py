@@ -292,7 +292,8 @@ class HipViT:
         batch >= 512 as two halves on two streams.  Both leave the features unchanged (tested).  ``f32_stream``
         (f16 / bf16): float32 residual stream with standalone add+LayerNorm launches instead of the fused-LayerNorm
         dataflow (slower, closer to the fp32 path)."""
-        _lib.check(self.lib.ap_vit_set_option(self._handle, self.OPTIONS[name], 1 if on else 0), "ap_vit_set_option")
+        value = int(on) if not isinstance(on, bool) else (1 if on else 0)
+        _lib.check(self.lib.ap_vit_set_option(self._handle, self.OPTIONS[name], value), "ap_vit_set_option")
 
     def profile(self, on: bool) -> None:
         _lib.check(self.lib.ap_vit_profile_enable(self._handle, 1 if on else 0), "ap_vit_profile_enable")

@@ -408,13 +408,35 @@ def main():
         finally:
             ex.vit.set_option("full_last_block", False)
 
+    # ... and with the float32 residual stream + standalone add+LayerNorm launches (round 1's dataflow, option f32_stream)
+    f32s = None
+    fused = short != "f32" and not os.environ.get("AP_VIT_F32_STREAM")
+    if world == 1 and fused:
+        ex.vit.set_option("f32_stream", True)
+        try:
+            step(0, feats[:B])
+            torch.cuda.synchronize(device)
+            ex.vit.profile(True)
+            t1 = time.perf_counter()
+            for i in range(K):
+                step(i, feats[i * B:(i + 1) * B])
+            torch.cuda.synchronize(device)
+            dt1 = time.perf_counter() - t1
+            p1 = ex.vit.profile_read()
+            ex.vit.profile(False)
+            f32s = {"patches_per_s": round(K * B / dt1, 1), "kernel_ms_per_step": {k: round(v[0] / K, 4) for k, v in p1.items()}}
+        finally:
+            ex.vit.set_option("f32_stream", False)
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
 
     value = world * K * B / elapsed
-    # ---- roofline of the dominant kernel: the fc1 GEMM (gemm256_kernel<T, EPI_BIAS_GELU>), one shape per launch
+    # ---- roofline of the dominant kernel: the fc1 GEMM (gemm256_kernel<T, EPI_NORM_GELU>: LayerNorm statistics + GELU in
+    #      the epilogue; <T, EPI_BIAS_GELU> with the f32-stream dataflow), one shape per launch
+    fc1_tag = "Li5E" if fused else "Li1E"
     M = B * 197
     fc1_ms, fc1_n = prof["gemm_fc1"]
     flop_launch = 2.0 * M * 3072 * 768
@@ -430,8 +452,7 @@ def main():
     if short != "f32" and B == 2048 and tpath and os.path.exists(tpath):
         with open(tpath) as fh:
             for kname, rec in json.load(fh).items():
-                if "gemm256_kernel" in kname and ("Li1E" in kname or "EPI_BIAS_GELU" in kname or ", 1>" in kname) \
-                        and ("DF16_" in kname) == (short == "f16"):
+                if "gemm256_kernel" in kname and fc1_tag in kname and ("DF16_" in kname) == (short == "f16"):
                     traffic = rec["hbm_bytes_per_launch"]
     # MFMA-pipe utilisation and effective shader clock of the same kernel from the PMC pass of the same command
     # (SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE; tools/pmc_mfma.py -> profiles/): frac ~= mfma_util * clock / 2.4 GHz
@@ -440,7 +461,7 @@ def main():
     if short != "f32" and B == 2048 and mfiles:
         with open(mfiles[-1]) as fh:
             for kname, rec in json.load(fh).items():
-                if "gemm256_kernel" in kname and "Li1E" in kname and ("DF16_" in kname) == (short == "f16"):
+                if "gemm256_kernel" in kname and fc1_tag in kname and ("DF16_" in kname) == (short == "f16"):
                     pmc_mfma = {"mfma_util": round(rec["mfma_util"], 4),
                                 "effective_clock_GHz": round(rec.get("effective_clock_GHz", 0.0), 3),
                                 "source": os.path.basename(mfiles[-1])}
@@ -453,6 +474,11 @@ def main():
     pre_bytes = B * 150528.0 * (1.0 + eb)
     ln_blocks = 12 if full_last else 11          # the last block's LN2 runs on the CLS rows only (timed under cls_tail)
     ln_bytes = M * 768.0 * (ln_blocks * ((4 + eb + eb) + (4 + 2 * eb + 4 + eb)) + (0 if full_last else 4 + eb + eb) - eb)
+    if fused:
+        # fused dataflow: no add+LayerNorm pass.  What is timed under "layernorm" is the stream initialisation (f32 token
+        # matrix in, T stream + row statistics out) and the 2 * blocks - 1 statistic finalisations ([M, 12, 2] f32 partial
+        # sums in, [M, 2] out); the stream itself moves inside the proj / fc2 epilogues (2 B read + 2 B written per element)
+        ln_bytes = M * (768.0 * (4 + eb) + 8) + (23 if full_last else 22) * M * (12 * 8 + 8.0)
     hbm_kernels = {}
     for kind, nbytes in (("preproc", pre_bytes), ("layernorm", ln_bytes)):
         ms = prof[kind][0] / K
@@ -468,7 +494,9 @@ def main():
                                f"resident in HBM, ViT-B/16 (random-init), device batch {B}",
                    "tiles_per_step": B, "slide_tissue_tiles": int(n_slide), "grid_cells": cells,
                    "parallelism": f"slide-per-rank x{world}" + (" + RCCL all-gather of features" if world > 1 else "")},
-        "roofline": {"bound": "mfma", "kernel": ("gemm256_kernel<T,EPI_BIAS_GELU> (fc1: [B*197,768]x[768,3072], "
+        "roofline": {"bound": "mfma", "kernel": (("gemm256_kernel<T,EPI_NORM_GELU> (fc1 with the LayerNorm statistics applied "
+                                                          "in the epilogue: [B*197,768]x[768,3072], " if fused else
+                                                          "gemm256_kernel<T,EPI_BIAS_GELU> (fc1: [B*197,768]x[768,3072], ") +
                                                          "persistent 256x256-tile MFMA GEMM)") if short != "f32" else
                                                         ("gemm_kernel<float,EPI_BIAS_GELU> (fc1: [B*197,768]x[768,3072], "
                                                          "128x128-tile v_mfma_f32_32x32x2_f32 GEMM)"),
@@ -477,7 +505,8 @@ def main():
                      "traffic_source": (f"profiles/{os.path.basename(tpath)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                         "this command, committed; not measured in this run)") if traffic is not None else None,
                      "pmc": pmc_mfma,
-                     "algorithmic_bytes_per_launch": (M * 768 + 3072 * 768 + M * 3072) * (4.0 if short == "f32" else 2.0),
+                     "algorithmic_bytes_per_launch": (M * 768 + 3072 * 768 + M * 3072) * (4.0 if short == "f32" else 2.0) +
+                                                     (M * 8.0 + 3072 * 8.0 if fused else 0.0),
                      "avg_launch_ms": round(fc1_avg_s * 1e3, 4), "launches": fc1_n,
                      "algorithmic_flop_per_launch": flop_launch},
         "end_to_end_model_tflops": round(value * (FLOP_PER_PATCH_VIT_B16 if full_last else FLOP_PER_PATCH_EXECUTED) / 1e12 / world, 1),
@@ -485,6 +514,9 @@ def main():
                            "note": "last block: K/V for all tokens, the rest for the CLS row only (identical features); "
                                    "option full_last_block (AP_VIT_FULL_LAST_BLOCK=1 at start) computes it for every token",
                            "value_with_full_last_block": None if full_value is None else round(full_value, 1)},
+        "dataflow": ("fused_layernorm: residual stream in the compute type, LayerNorm folded into the qkv / fc1 GEMMs, residual "
+                     "add + row sums in the proj / fc2 epilogues" if fused else "f32 residual stream + add+LayerNorm launches"),
+        "f32_stream_dataflow": f32s,
         "kernel_ms_per_step": kernel_ms, "hbm_kernels": hbm_kernels,
         "coords": {"cells": cells, "rows": int(n_slide), "seconds": round(coords_s, 4),
                    "cells_per_s": round(cells / coords_s, 1)},

@@ -409,6 +409,58 @@ def gen_extract_batch(out_dir):
     np.savez_compressed(out_dir / "extract_batch.npz", **arrays)
 
 
+def gen_extract_batch_lowp(out_dir):
+    """G1b: the reference's own float16 / bfloat16 feature path -- PatchFeatureExtractor converts the whole module with
+    ``model.to(dtype)`` (models/patch/base.py:66) and feeds it ``batch.to(dtype)`` (:96-99) -- on the L12 model and the
+    five patches of G1.  These outputs are the envelope the build's 16-bit modes are held to: its error against the
+    fp32 path must not exceed the reference's own."""
+    import copy
+    import torch
+    from transformers import ViTConfig, ViTModel
+
+    torch.set_num_threads(8)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
+
+    def preprocess(pil):
+        arr = np.asarray(pil, dtype=np.uint8)[16:240, 16:240, :]
+        x = torch.from_numpy(arr.copy()).permute(2, 0, 1).to(torch.float32).div(255)
+        return x.sub(mean).div(std)
+
+    torch.manual_seed(0)
+    cfg = ViTConfig(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                    image_size=224, patch_size=16, layer_norm_eps=1e-6, hidden_act="gelu")
+    base = ViTModel(cfg, add_pooling_layer=False).eval()
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for n_, p in base.named_parameters():
+            if "layernorm" in n_ and n_.endswith("weight"):
+                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+            elif n_.endswith("bias") or "position_embeddings" in n_ or "cls_token" in n_:
+                p.copy_(0.02 * torch.randn(p.shape, generator=g))
+    arrays = {}
+    for tag, dt in (("f16", torch.float16), ("bf16", torch.bfloat16)):
+        model = copy.deepcopy(base)
+
+        def loader(device, dtype, _m=model):
+            return ref.custom.CustomEncoderComponents(
+                model=_m, preprocess=preprocess,
+                forward_fn=lambda x, _mm=_m: _mm(pixel_values=x).last_hidden_state[:, 0])
+
+        reg = ref.registry.PatchFeatureExtractorRegistry()
+        ref.custom.register_custom_encoder(registry=reg, name=f"hfvit_L12_{tag}", embedding_dim=768, loader=loader,
+                                           device=torch.device("cpu"), dtype=dt, num_workers=0)
+        ex = reg.create(f"hfvit_L12_{tag}")
+        assert next(ex.model.parameters()).dtype == dt
+        rng = np.random.default_rng(0)
+        patches = [rng.integers(0, 256, (256, 256, 3), dtype=np.uint8) for _ in range(5)]
+        feats = ex.extract_batch(patches, batch_size=32)
+        assert feats.dtype == np.float32 and feats.shape == (5, 768)
+        arrays[f"L12_n5_out_{tag}"] = feats
+        print(f"  reference extract_batch L12 n=5 in {tag}: |f|={np.abs(feats).mean():.4f}")
+    np.savez_compressed(out_dir / "extract_batch_lowp.npz", **arrays)
+
+
 def gen_features_h5(out_dir):
     """G5: features/<name> layout after the reference's own embed_all on a tiny synthetic slide."""
     import torch
@@ -531,4 +583,6 @@ if __name__ == "__main__":
         gen_features_h5(out_dir)
     if "extract" in which:
         gen_extract_batch(out_dir)
+    if "lowp" in which:
+        gen_extract_batch_lowp(out_dir)
     print("done")

@@ -86,6 +86,100 @@ def test_gemm_tile_seam_with_cold_bias(env, shape):
         assert torch.equal(out256, out128), f"launch {it}"
 
 
+# ----------------------------------------------------------------------------- fused-LayerNorm GEMM epilogues
+def _fused(env, dt, epi, A, W, bias, colsum, rowstats, partial, out):
+    _lib, lib, dev, stream = env
+    M, K = A.shape
+    p = lambda t: t.data_ptr() if t is not None else None
+    _lib.check(lib.ap_gemm_fused(_lib.torch_dtype_code(dt), epi, A.data_ptr(), A.stride(0), W.data_ptr(), W.stride(0),
+                                 M, W.shape[0], K, bias.data_ptr(), p(colsum), p(rowstats), p(partial), out.data_ptr(),
+                                 out.stride(0), stream), "ap_gemm_fused")
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(1, 768, 768), (197, 768, 768), (1000, 768, 3072), (256 * 40 + 77, 1024, 1024),
+                                   (348 * 197, 768, 768)])
+def test_gemm_resid_stats_epilogue(env, dt, shape):
+    """AP_EPI_RESID_STATS: x <- T(x + T(A W^T + b)) in place and per (row, 64-column group) the sum / sum of squares of
+    the NEW row; then ap_rowstats_finalize -> (rstd, -mean rstd).  Against torch on the same rounded operands: the stream
+    is exact up to the rounding of the f32 accumulator (one ulp of T at the branch's magnitude where the two round
+    differently), the partial sums are sums of the values actually stored (exact up to f32 summation order); ragged M,
+    M < 256, several tiles per workgroup; the same launch repeated is bit-identical."""
+    _lib, lib, dev, stream = env
+    M, N, K = shape
+    g = torch.Generator(device=dev).manual_seed(M + N + K)
+    A = torch.randn((M, K), device=dev, generator=g).to(dt)
+    W = (torch.randn((N, K), device=dev, generator=g) * 0.05).to(dt)
+    bias = torch.randn(N, device=dev, generator=g) * 0.1
+    x0 = (torch.randn((M, N), device=dev, generator=g) * 2.0 + 0.3).to(dt)
+    runs = []
+    for _ in range(3):
+        x = x0.clone()
+        part = torch.full((M, N // 64, 2), float("nan"), device=dev)
+        _fused(env, dt, 6, A, W, bias, None, None, part, x)
+        runs.append((x, part))
+    assert all(torch.equal(runs[0][0], r[0]) and torch.equal(runs[0][1], r[1]) for r in runs[1:])
+    x, part = runs[0]
+    branch = (A.float() @ W.float().t() + bias)
+    want = (x0.float() + branch.to(dt).float()).to(dt)
+    ulp = 2.0 ** -10 if dt == torch.float16 else 2.0 ** -7
+    # where the kernel's f32 accumulation order rounds the branch the other way (one ulp of the branch), x moves by that
+    # much or lands on a neighbouring value of T
+    assert bool(((x.float() - want.float()).abs() <= ulp * (branch.abs() + want.float().abs()) * 1.001 + 1e-6).all())
+    assert (x != want).float().mean().item() < 2e-3
+    xs = x.float().view(M, N // 64, 64)
+    assert torch.allclose(part[..., 0], xs.sum(-1), rtol=0, atol=2e-3)
+    assert torch.allclose(part[..., 1], (xs * xs).sum(-1), rtol=2e-6, atol=1e-3)
+    rs = torch.empty((M, 2), device=dev)
+    _lib.check(lib.ap_rowstats_finalize(part.data_ptr(), M, N // 64, N, 1e-6, rs.data_ptr(), stream), "ap_rowstats_finalize")
+    xf = x.double()
+    mean, rstd = xf.mean(-1), torch.rsqrt(xf.var(-1, unbiased=False) + 1e-6)
+    assert ((rs[:, 0].double() - rstd).abs() / rstd).max().item() < 2e-6
+    assert (rs[:, 1].double() + mean * rstd).abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float16, 1.5e-3), (torch.bfloat16, 1.2e-2)])
+@pytest.mark.parametrize("gelu", [False, True])
+@pytest.mark.parametrize("shape", [(1, 768, 768), (300, 2304, 768), (20000, 3072, 768), (348 * 197, 1536, 1024)])
+def test_gemm_norm_epilogue_equals_layernorm_then_linear(env, dt, tol, gelu, shape):
+    """AP_EPI_NORM / AP_EPI_NORM_GELU: rstd (x W'^T - mean colsum) + b' with W' = T(W gamma), b' = b + W beta equals
+    Linear(LayerNorm(x)) (+ GELU) computed by torch in float32 -- including rows with a mean far from zero, where the
+    rank-one mean correction cancels most of the accumulator.  Bound: rounding of the output to T plus the rounding of
+    W gamma to T (element-wise, relative to the output scale)."""
+    _lib, lib, dev, stream = env
+    M, N, K = shape
+    g = torch.Generator(device=dev).manual_seed(M + N + K + int(gelu))
+    x = torch.randn((M, K), device=dev, generator=g) * 1.5
+    x[: max(1, M // 4)] += 6.0                                  # rows with |mean| = 4 sigma
+    x[:, 7] += 40.0                                             # one massive channel
+    x = x.to(dt)
+    Wl = torch.randn((N, K), device=dev, generator=g) * 0.05
+    gamma = 1.0 + 0.2 * torch.randn(K, device=dev, generator=g)
+    beta = 0.1 * torch.randn(K, device=dev, generator=g)
+    b = 0.1 * torch.randn(N, device=dev, generator=g)
+    Wf = (Wl * gamma).to(dt)
+    colsum = Wf.float().sum(-1).contiguous()
+    bf = (b + Wl @ beta).contiguous()
+    stats = torch.empty((M, 2), device=dev)
+    x16 = torch.empty((M, K), device=dev, dtype=dt)
+    _lib.check(lib.ap_stream_init(_lib.torch_dtype_code(dt), x.float().contiguous().data_ptr(), M, K, 1e-6, x16.data_ptr(),
+                                  stats.data_ptr(), stream), "ap_stream_init")
+    assert torch.equal(x16, x)
+    outs = []
+    for _ in range(3):
+        out = torch.full((M, N), float("nan"), device=dev, dtype=dt)
+        _fused(env, dt, 5 if gelu else 4, x16, Wf, bf, colsum, stats, None, out)
+        outs.append(out)
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    want = torch.nn.functional.layer_norm(x.float(), (K,), gamma, beta, 1e-6) @ Wl.t() + b
+    if gelu:
+        want = torch.nn.functional.gelu(want)
+    err = ((outs[0].float() - want).abs() / (want.abs() + 0.05 * want.abs().max())).max().item()
+    assert err <= tol * 4, err          # element-wise statistic: ~4 x the norm-wise one
+    assert (torch.linalg.norm(outs[0].float() - want) / torch.linalg.norm(want)).item() <= tol
+
+
 def test_gemm_f32_exact_mfma(env):
     _lib, lib, dev, stream = env
     g = torch.Generator(device=dev).manual_seed(3)

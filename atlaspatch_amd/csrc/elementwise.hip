@@ -295,20 +295,30 @@ __global__ __launch_bounds__(256) void stream_init_kernel(const float* __restric
 }
 
 // partial (sum, sum of squares) per 64-column group, written by the EPI_RESID_STATS epilogue -> (rstd, -mean * rstd).
-// Combined in double in a fixed order (deterministic); one thread per row.
-__global__ void rowstats_finalize_kernel(const float* __restrict__ partial, int rows, int groups, int dim, float eps,
-                                         float* __restrict__ rowstats) {
-    const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= rows) return;
-    const float2* p = (const float2*)partial + (size_t)row * groups;
-    double s = 0.0, q = 0.0;
-    for (int g = 0; g < groups; ++g) {
-        const float2 v = p[g];
-        s += (double)v.x;
-        q += (double)v.y;
+// Eight lanes per row, one 16-byte load (two groups) per lane: a wave reads 8 rows x (groups * 8) contiguous bytes
+// (a thread per row with a 96-byte stride measured 36 us per call at 403 456 rows).  The lane sums are combined in a
+// fixed butterfly order (deterministic), the mean / variance arithmetic is done in double.
+__global__ __launch_bounds__(256) void rowstats_finalize_kernel(const float* __restrict__ partial, int rows, int groups, int dim,
+                                                                float eps, float* __restrict__ rowstats) {
+    const int l8 = threadIdx.x & 7;
+    int row = blockIdx.x * 32 + (threadIdx.x >> 3);
+    const bool live = row < rows;
+    if (!live) row = rows - 1;                                   // keep all lanes in the DPP reductions
+    const f32x4* p = (const f32x4*)(partial + (size_t)row * groups * 2);
+    float s = 0.f, q = 0.f;
+    for (int g2 = l8; g2 * 2 < groups; g2 += 8) {                // groups is even (dim % 128 == 0)
+        const f32x4 v = p[g2];
+        s += v[0] + v[2];
+        q += v[1] + v[3];
     }
-    const double mean = s / dim;
-    double var = q / dim - mean * mean;
+#define AP_DPP8(V, CTRL) __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, (V)), (CTRL), 0xF, 0xF, true))
+    s += AP_DPP8(s, 0xB1); q += AP_DPP8(q, 0xB1);
+    s += AP_DPP8(s, 0x4E); q += AP_DPP8(q, 0x4E);
+    s += AP_DPP8(s, 0x141); q += AP_DPP8(q, 0x141);
+#undef AP_DPP8
+    if (!live || l8 != 0) return;
+    const double mean = (double)s / dim;
+    double var = (double)q / dim - mean * mean;
     var = var > 0.0 ? var : 0.0;
     const double rstd = 1.0 / sqrt(var + (double)eps);
     rowstats[2 * (size_t)row] = (float)rstd;
@@ -487,7 +497,8 @@ int launch_stream_init(int dtype, const float* tok, int rows, int dim, float eps
 int launch_rowstats_finalize(const float* partial, int rows, int groups, int dim, float eps, float* rowstats,
                              hipStream_t stream) {
     if (rows <= 0) return AP_OK;
-    rowstats_finalize_kernel<<<(rows + 255) / 256, 256, 0, stream>>>(partial, rows, groups, dim, eps, rowstats);
+    AP_REQUIRE(groups > 0 && groups % 2 == 0, "rowstats_finalize: groups %d must be even", groups);
+    rowstats_finalize_kernel<<<(rows + 31) / 32, 256, 0, stream>>>(partial, rows, groups, dim, eps, rowstats);
     AP_HIP_CHECK(hipGetLastError());
     return AP_OK;
 }

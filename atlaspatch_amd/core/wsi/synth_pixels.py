@@ -118,8 +118,8 @@ def analytic_mask(spec: SynthSpec, thumb_max: int = 1024) -> np.ndarray:
     # sample each mask pixel at the level-0 coordinate of its centre
     cx = ((np.arange(mw, dtype=np.int64) * 2 + 1) * spec.width) // (2 * mw)
     cy = ((np.arange(mh, dtype=np.int64) * 2 + 1) * spec.height) // (2 * mh)
-    gx, gy = np.meshgrid(cx, cy)
-    return inside_any(gx >> UNIT_SHIFT, gy >> UNIT_SHIFT, spec.ellipses()).astype(np.float32)
+    # 1-D coordinate vectors broadcast inside inside_any: the per-axis squares are computed on W + H values instead of W x H
+    return inside_any((cx >> UNIT_SHIFT)[None, :], (cy >> UNIT_SHIFT)[:, None], spec.ellipses()).astype(np.float32)
 
 
 def thumbnail_size(w: int, h: int, max_side: int) -> tuple[int, int]:

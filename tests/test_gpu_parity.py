@@ -169,6 +169,34 @@ def test_lowp_error_not_above_the_references_own(dtype, tag, golden_dir):
     assert ours <= ref_err and ours_f32s <= ref_err, (tag, ref_err, ours, ours_f32s)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_fused_dataflow_with_large_row_means_and_massive_channels(dtype):
+    """The fused-LayerNorm dataflow multiplies the RAW 16-bit stream and subtracts mean * colsum afterwards: rows whose
+    mean is far from zero and channels two orders of magnitude above the rest (the 'massive activations' of trained ViTs)
+    are where that cancels most.  The position embedding of the seeded depth-12 model is shifted by +3 in every channel
+    and by +60 / -45 / +30 in three channels; features must stay inside the same bounds against the fp32 oracle (the
+    all-16-bit module the reference would run measures 1.3e-3 on this construction in a CPU emulation)."""
+    from atlaspatch_amd.encoders.vit import build_hip_vit_extractor
+    from oracle import vit_oracle
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    model = vit_oracle.make_hf_vit(layers=12)
+    sd = dict(model.state_dict())
+    boost = torch.full((768,), 3.0)
+    boost[[7, 300, 511]] += torch.tensor([60.0, -45.0, 30.0])
+    sd["embeddings.position_embeddings"] = sd["embeddings.position_embeddings"] + boost
+    ex = build_hip_vit_extractor(name="hfvit_massive", arch="vit_b_16", depth=12, state_dict=sd, device=_dev(), dtype=dtype,
+                                 source="hf")
+    rng = np.random.default_rng(41)
+    tiles = [rng.integers(0, 256, (256, 256, 3), dtype=np.uint8) for _ in range(9)]
+    want = vit_oracle.extract_batch(sd, tiles, heads=12, batch_size=32)
+    got = ex.extract_batch(tiles, batch_size=32)
+    ex.vit.set_option("f32_stream", True)
+    got_f32s = ex.extract_batch(tiles, batch_size=32)
+    ex.cleanup()
+    _check(got, want, dtype, "massive activations, fused")
+    _check(got_f32s, want, dtype, "massive activations, f32_stream", tol=TOL_F32S)
+
+
 # ----------------------------------------------------------------------------- BASELINE configs 3 / 5 at their real depth
 def _pil_resized(tiles, size, filt):
     from PIL import Image

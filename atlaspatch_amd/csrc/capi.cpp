@@ -24,7 +24,7 @@ void set_error(const char* fmt, ...) {
 
 extern "C" {
 
-int ap_abi_version(void) { return 10; }
+int ap_abi_version(void) { return 11; }
 
 const char* ap_last_error(void) { return ap::g_error; }
 
@@ -141,7 +141,7 @@ int ap_gemm(int dtype, int epilogue, const void* A, int lda, const void* W, int 
 
 int ap_gemm_fused(int dtype, int epilogue, const void* A, int lda, const void* W, int ldw, int M, int N, int K,
                   const float* bias, const float* colsum, const float* rowstats, float* partial, void* out, int ldo,
-                  ap_stream_t stream) {
+                  int impl, ap_stream_t stream) {
     AP_REQUIRE(A && W && bias && out, "ap_gemm_fused: null pointer");
     AP_REQUIRE(dtype == AP_F16 || dtype == AP_BF16, "ap_gemm_fused: f16 / bf16 only");
     int epi;
@@ -153,8 +153,9 @@ int ap_gemm_fused(int dtype, int epilogue, const void* A, int lda, const void* W
     ap::GemmArgs g{};
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K;
     g.bias = bias; g.colsum = colsum; g.rowstats = rowstats; g.partial = partial; g.out = out; g.ldo = ldo;
-    AP_REQUIRE(M > 0 && ap::gemm256_supports(dtype, epi, g), "ap_gemm_fused: unsupported problem (N %% 256, K %% 128, 16-byte strides)");
-    return ap::launch_gemm256(dtype, epi, g, 0, (hipStream_t)stream);
+    AP_REQUIRE(impl == 0 || impl == 128 || impl == 256, "ap_gemm_fused: impl %d (0 = pick, 128, 256)", impl);
+    AP_REQUIRE(M > 0 && (impl == 128 || ap::gemm256_supports(dtype, epi, g)), "ap_gemm_fused: unsupported problem (N %% 256, K %% 128, 16-byte strides)");
+    return ap::launch_gemm_impl(dtype, epi, g, impl, 0, (hipStream_t)stream);
 }
 
 int ap_stream_init(int dtype, const float* tok, int rows, int dim, float eps, void* x, float* rowstats, ap_stream_t stream) {

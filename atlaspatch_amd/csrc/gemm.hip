@@ -59,6 +59,69 @@ template <> __device__ __forceinline__ void store4<bf16>(bf16* p, f32x4 v) {
     *(bf16x4*)p = h;
 }
 
+// ---- fused-LayerNorm epilogues (twins of gemm256.hip's, bit for bit: a problem may be served by either kernel) ----
+// A lane holds 4 consecutive n of one row (two packed pairs); its partner lane ^ 32 holds the next 4.  The persistent
+// kernel sums a 16-byte chunk (8 columns) as ONE chain  s = dot2(c3, dot2(c2, dot2(c1, dot2(c0, 0))))  and then combines
+// the 8 chunks of a 64-column group as ((s0+s1)+(s2+s3)) + ((s4+s5)+(s6+s7)); here the chain starts on the lower lane,
+// crosses to the partner through one v_permlane32_swap and finishes there, and the tree is evaluated in that lane.
+template <typename T> __device__ __forceinline__ u32x2 resid_add4(u32x2 d, u32x2 r);
+template <> __device__ __forceinline__ u32x2 resid_add4<f16>(u32x2 d, u32x2 r) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    u32x2 y;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const uint32_t dk = d[k], rk = r[k];
+        y[k] = __builtin_bit_cast(uint32_t, (h2)(__builtin_bit_cast(h2, dk) + __builtin_bit_cast(h2, rk)));
+    }
+    return y;
+}
+template <> __device__ __forceinline__ u32x2 resid_add4<bf16>(u32x2 d, u32x2 r) {
+    u32x2 y;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float d0 = __builtin_bit_cast(float, d[k] << 16), d1 = __builtin_bit_cast(float, d[k] & 0xffff0000u);
+        const float r0 = __builtin_bit_cast(float, r[k] << 16), r1 = __builtin_bit_cast(float, r[k] & 0xffff0000u);
+        const bf16x4 c4 = {(bf16)(d0 + r0), (bf16)(d1 + r1), (bf16)0.0f, (bf16)0.0f};
+        y[k] = __builtin_bit_cast(u32x2, c4)[0];
+    }
+    return y;
+}
+template <typename T> __device__ __forceinline__ void stats_chain4(u32x2 y, float& s, float& q);
+template <> __device__ __forceinline__ void stats_chain4<f16>(u32x2 y, float& s, float& q) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const uint32_t yk = y[k];
+        const h2 c = __builtin_bit_cast(h2, yk);
+        s = __builtin_amdgcn_fdot2(c, h2{(_Float16)1.0f, (_Float16)1.0f}, s, false);
+        q = __builtin_amdgcn_fdot2(c, c, q, false);
+    }
+}
+template <> __device__ __forceinline__ void stats_chain4<bf16>(u32x2 y, float& s, float& q) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float c0 = __builtin_bit_cast(float, y[k] << 16), c1 = __builtin_bit_cast(float, y[k] & 0xffff0000u);
+        s += c0 + c1;
+        q = __builtin_fmaf(c1, c1, __builtin_fmaf(c0, c0, q));
+    }
+}
+// value of the partner lane (lane ^ 32)
+__device__ __forceinline__ float partner32(float v) {
+    float a = v, b = v;
+    asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));     // a = {lo, lo}, b = {hi, hi}
+    return (threadIdx.x & 32) ? a : b;
+}
+template <typename T> __device__ __forceinline__ u32x2 pack4t(f32x4 v);
+template <> __device__ __forceinline__ u32x2 pack4t<f16>(f32x4 v) {
+    f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+    return __builtin_bit_cast(u32x2, h);
+}
+template <> __device__ __forceinline__ u32x2 pack4t<bf16>(f32x4 v) {
+    bf16x4 h = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+    return __builtin_bit_cast(u32x2, h);
+}
+template <> __device__ __forceinline__ u32x2 pack4t<float>(f32x4) { return u32x2{0, 0}; }
+
 __device__ __forceinline__ void dma16(const char* gsrc, char* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
@@ -109,10 +172,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             const f32x4 b4 = *(const f32x4*)(g.bias + n0 + wave_n * 64 + nt * 32 + g4 * 8 + hi * 4);
+            constexpr bool kNormInit = EPI == EPI_NORM_STORE || EPI == EPI_NORM_GELU;     // (these start from zero)
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[nt][mt][g4 * 4 + e] = b4[e];
+                for (int e = 0; e < 4; ++e) acc[nt][mt][g4 * 4 + e] = kNormInit ? 0.0f : b4[e];
         }
 
     const int xr = (l31 >> 1) & 7;                                  // row-dependent chunk xor
@@ -165,6 +229,72 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     }
 
     // ---- epilogue: lane owns m = .. + l31 and, per (nt, g4), n = .. + 8*g4 + 4*hi + {0..3}
+    if constexpr (sizeof(T) == 2 && (EPI == EPI_NORM_STORE || EPI == EPI_NORM_GELU)) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int m = m0 + wave_m * 64 + mt * 32 + l31;
+            if (m >= g.M) continue;
+            const float rstd = g.rowstats[2 * (size_t)m], nmr = g.rowstats[2 * (size_t)m + 1];
+            const f32x2_t rs2 = {rstd, rstd}, nm2 = {nmr, nmr};
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int n = n0 + wave_n * 64 + nt * 32 + g4 * 8 + hi * 4;
+                    const f32x4 cs = *(const f32x4*)(g.colsum + n), bb = *(const f32x4*)(g.bias + n);
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[nt][mt][g4 * 4 + e];
+                    const f32x2_t lo = __builtin_elementwise_fma(rs2, f32x2_t{v[0], v[1]},
+                        __builtin_elementwise_fma(nm2, f32x2_t{cs[0], cs[1]}, f32x2_t{bb[0], bb[1]}));
+                    const f32x2_t hi2 = __builtin_elementwise_fma(rs2, f32x2_t{v[2], v[3]},
+                        __builtin_elementwise_fma(nm2, f32x2_t{cs[2], cs[3]}, f32x2_t{bb[2], bb[3]}));
+                    v = f32x4{lo[0], lo[1], hi2[0], hi2[1]};
+                    if constexpr (EPI == EPI_NORM_GELU) {
+                        const f32x2_t a = gelu_sigmoid_poly2(f32x2_t{v[0], v[1]}), b = gelu_sigmoid_poly2(f32x2_t{v[2], v[3]});
+                        v = f32x4{a[0], a[1], b[0], b[1]};
+                    }
+                    store4<T>((T*)g.out + (size_t)m * (size_t)g.ldo + n, v);
+                }
+        }
+        return;
+    }
+    if constexpr (sizeof(T) == 2 && EPI == EPI_RESID_STATS) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            int m = m0 + wave_m * 64 + mt * 32 + l31;
+            const bool live = m < g.M;
+            if (!live) m = g.M - 1;                              // every lane takes part in the lane exchanges
+            float cs8[8], cq8[8];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int n = n0 + wave_n * 64 + nt * 32 + g4 * 8 + hi * 4;
+                    T* px = (T*)g.out + (size_t)m * (size_t)g.ldo + n;
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[nt][mt][g4 * 4 + e];
+                    const u32x2 y = resid_add4<T>(pack4t<T>(v), *(const u32x2*)px);
+                    if (live) *(u32x2*)px = y;
+                    // chain: lower lane (columns 0-3 of the chunk) first, then the partner continues with columns 4-7
+                    float s = 0.f, q = 0.f;
+                    if (hi == 0) stats_chain4<T>(y, s, q);
+                    s = partner32(s);                            // upper lane now holds the lower lane's partial chain
+                    q = partner32(q);
+                    if (hi == 1) stats_chain4<T>(y, s, q);
+                    cs8[nt * 4 + g4] = s;
+                    cq8[nt * 4 + g4] = q;
+                }
+            if (live && hi == 1) {
+                const float s = ((cs8[0] + cs8[1]) + (cs8[2] + cs8[3])) + ((cs8[4] + cs8[5]) + (cs8[6] + cs8[7]));
+                const float q = ((cq8[0] + cq8[1]) + (cq8[2] + cq8[3])) + ((cq8[4] + cq8[5]) + (cq8[6] + cq8[7]));
+                typedef float f32x2v __attribute__((ext_vector_type(2)));
+                *(f32x2v*)(g.partial + ((size_t)m * (g.N >> 6) + ((n0 + wave_n * 64) >> 6)) * 2) = f32x2v{s, q};
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         const int m = m0 + wave_m * 64 + mt * 32 + l31;
@@ -232,6 +362,9 @@ int launch_typed(int epilogue, const GemmArgs& a, hipStream_t stream) {
         case EPI_BIAS_GELU: gemm_kernel<T, EPI_BIAS_GELU><<<grid, block, 0, stream>>>(a); break;
         case EPI_BIAS_RESID: gemm_kernel<T, EPI_BIAS_RESID><<<grid, block, 0, stream>>>(a); break;
         case EPI_PATCH_EMBED: gemm_kernel<T, EPI_PATCH_EMBED><<<grid, block, 0, stream>>>(a); break;
+        case EPI_NORM_STORE: gemm_kernel<T, EPI_NORM_STORE><<<grid, block, 0, stream>>>(a); break;
+        case EPI_NORM_GELU: gemm_kernel<T, EPI_NORM_GELU><<<grid, block, 0, stream>>>(a); break;
+        case EPI_RESID_STATS: gemm_kernel<T, EPI_RESID_STATS><<<grid, block, 0, stream>>>(a); break;
         default: set_error("gemm: unknown epilogue %d", epilogue); return AP_ERR_INVALID;
     }
     AP_HIP_CHECK(hipGetLastError());
@@ -248,7 +381,21 @@ int launch_gemm_impl(int dtype, int epilogue, const GemmArgs& a, int impl, int v
     AP_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem %d x %d x %d", a.M, a.N, a.K);
     AP_REQUIRE(impl == 0 || impl == 128 || impl == 256 || impl == 257, "gemm: unknown implementation %d", impl);
     if (impl == 257) return launch_gemm256_alt(dtype, epilogue, a, variant, stream);
-    if (impl == 256 || (impl == 0 && a.M >= 256 && gemm256_supports(dtype, epilogue, a)))
+    const bool fused_epi = epilogue == EPI_NORM_STORE || epilogue == EPI_NORM_GELU || epilogue == EPI_RESID_STATS;
+    AP_REQUIRE(!fused_epi || dtype != AP_F32, "gemm: the fused-LayerNorm epilogues are f16 / bf16 only");
+    AP_REQUIRE(!fused_epi || (epilogue == EPI_RESID_STATS ? a.partial != nullptr : (a.colsum && a.rowstats)),
+               "gemm: missing operand for the fused-LayerNorm epilogue %d", epilogue);
+    // Kernel choice (results are bit-identical either way).  The persistent 256 x 256 kernel needs about one tile per CU to
+    // pay: with few row tiles and a narrow N (proj / fc2 of a 32-tile extract_batch: 75 tiles for 256 CUs) the 128 x 128
+    // kernel's four times as many workgroups finish sooner.
+    static const int num_cu = [] {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }();
+    const long tiles256 = (long)((a.M + 255) / 256) * (a.N / 256);
+    const bool few_tiles = tiles256 * 2 <= num_cu && a.N % kTile == 0;
+    if (impl == 256 || (impl == 0 && a.M >= 256 && !few_tiles && gemm256_supports(dtype, epilogue, a)))
         return launch_gemm256(dtype, epilogue, a, variant, stream);
     const int kt = kRowBytes / (int)dtype_size(dtype);
     AP_REQUIRE(a.N % kTile == 0, "gemm: N=%d must be a multiple of %d", a.N, kTile);

@@ -327,7 +327,7 @@ int blocks_fused(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipStream
                 g.M = M; g.N = 2 * D; g.K = D; g.bias = fb.qkv_b + D; g.colsum = fb.qkv_cs + D; g.rowstats = w.rowstats;
                 g.out = (char*)w.qkv + (size_t)D * es; g.ldo = 3 * D;
                 ScopedTimer t(m, AP_PROF_GEMM_QKV, stream);
-                if ((rc = ap::launch_gemm_impl(dt, ap::EPI_NORM_STORE, g, 256, 0, stream)) != AP_OK) return rc;
+                if ((rc = ap::launch_gemm(dt, ap::EPI_NORM_STORE, g, stream)) != AP_OK) return rc;
             }
             ScopedTimer t(m, AP_PROF_CLS_TAIL, stream);
             if ((rc = ap::launch_stream_to_f32(dt, w.x16, (long)m->tokens * D, n, D, w.tok, stream)) != AP_OK) return rc;
@@ -372,7 +372,7 @@ int blocks_fused(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipStream
             g.M = M; g.N = 3 * D; g.K = D; g.bias = fb.qkv_b; g.colsum = fb.qkv_cs; g.rowstats = w.rowstats;
             g.out = w.qkv; g.ldo = 3 * D;
             ScopedTimer t(m, AP_PROF_GEMM_QKV, stream);
-            if ((rc = ap::launch_gemm_impl(dt, ap::EPI_NORM_STORE, g, 256, 0, stream)) != AP_OK) return rc;
+            if ((rc = ap::launch_gemm(dt, ap::EPI_NORM_STORE, g, stream)) != AP_OK) return rc;
         }
         { ScopedTimer t(m, AP_PROF_ATTENTION, stream);
           if ((rc = ap::launch_attention(dt, w.qkv, w.att, n, m->tokens, c.heads, D / c.heads, stream)) != AP_OK) return rc; }
@@ -381,7 +381,7 @@ int blocks_fused(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipStream
             g.A = w.att; g.lda = D; g.W = fb.proj_w; g.ldw = bp.proj->ld;
             g.M = M; g.N = D; g.K = D; g.bias = fb.proj_b; g.out = w.x16; g.ldo = D; g.partial = w.partial;
             ScopedTimer t(m, AP_PROF_GEMM_PROJ, stream);
-            if ((rc = ap::launch_gemm_impl(dt, ap::EPI_RESID_STATS, g, 256, 0, stream)) != AP_OK) return rc;
+            if ((rc = ap::launch_gemm(dt, ap::EPI_RESID_STATS, g, stream)) != AP_OK) return rc;
         }
         if ((rc = finalize_stats()) != AP_OK) return rc;
         {
@@ -390,14 +390,14 @@ int blocks_fused(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipStream
             g.M = M; g.N = c.mlp_dim; g.K = D; g.bias = fb.fc1_b; g.colsum = fb.fc1_cs; g.rowstats = w.rowstats;
             g.out = w.hid; g.ldo = c.mlp_dim;
             ScopedTimer t(m, AP_PROF_GEMM_FC1, stream);
-            if ((rc = ap::launch_gemm_impl(dt, ap::EPI_NORM_GELU, g, 256, 0, stream)) != AP_OK) return rc;
+            if ((rc = ap::launch_gemm(dt, ap::EPI_NORM_GELU, g, stream)) != AP_OK) return rc;
         }
         {
             ap::GemmArgs g{};
             g.A = w.hid; g.lda = c.mlp_dim; g.W = fb.fc2_w; g.ldw = bp.fc2->ld;
             g.M = M; g.N = D; g.K = c.mlp_dim; g.bias = fb.fc2_b; g.out = w.x16; g.ldo = D; g.partial = w.partial;
             ScopedTimer t(m, AP_PROF_GEMM_FC2, stream);
-            if ((rc = ap::launch_gemm_impl(dt, ap::EPI_RESID_STATS, g, 256, 0, stream)) != AP_OK) return rc;
+            if ((rc = ap::launch_gemm(dt, ap::EPI_RESID_STATS, g, stream)) != AP_OK) return rc;
         }
         if (i + 1 < c.depth && (rc = finalize_stats()) != AP_OK) return rc;
     }

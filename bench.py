@@ -314,6 +314,30 @@ def secondary_rates(device, ex, tiles, B):
                              "fc1_frac": round(tf / (MFMA_PEAK["f32"] / 1e12), 4),
                              "what": "exact-f32 MFMA (v_mfma_f32_32x32x2_f32) ViT-B/16, tiles resident in HBM"}
     ex32.cleanup()
+    # ---- (4b) SAM2 Hiera-T tissue segmentation of one 1024 x 1024 thumbnail (config 1's hot path; random weights: the
+    #      checkpoint is not available offline), float32 MFMA operator set replayed as a hipGraph
+    from atlaspatch_amd.services.sam2_hip import Sam2HipPredictor
+    from atlaspatch_amd.services.segmentation import random_sam2_state_dict
+    pred = Sam2HipPredictor(random_sam2_state_dict(0), device=str(device))
+    img = np.random.default_rng(0).integers(0, 256, (1024, 1024, 3), dtype=np.uint8)
+    pred.predict_image(img)                                   # captures the graph
+    torch.cuda.synchronize(device)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(10):
+        pred._graph.replay()
+    ev1.record()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        pred.predict_image(img)
+    host_ms = (time.perf_counter() - t0) / 5 * 1e3
+    rates["sam2_segmentation"] = {"ms_per_slide_device": round(ev0.elapsed_time(ev1) / 10, 3), "ms_per_slide_host_to_host": round(host_ms, 3),
+                                  "slides_per_s": round(1e3 / host_ms, 1),
+                                  "what": "SAM2.1 Hiera-T image encoder + box-prompted mask decoder on one 1024x1024 thumbnail "
+                                          "(services/segmentation.py:120-140), exact-f32 MFMA GEMMs, ~350 launches captured in one "
+                                          "hipGraph; host-to-host includes the PIL resize to 1024x1024, H2D and the mask D2H"}
+    pred.close()
     # ---- (5) the other two BASELINE encoders, kernel-only incl. their transform (device resize), f16
     os.environ["ATLASPATCH_RANDOM_INIT"] = "0"
     try:

@@ -256,14 +256,15 @@ int ap_gemm(int dtype, int epilogue, const void* A, int lda, const void* W, int 
  *   AP_EPI_RESID_STATS  out T [M, ldo] (in place) = T(out + T(acc + bias[n]))  -- the residual add -- and
  *                       partial f32 [M, N / 64, 2] = per row and 64-column group (sum, sum of squares) of the NEW row;
  *                       ap_rowstats_finalize turns them into the next rowstats (deterministic, fixed order, double).
- * Persistent 256 x 256 kernel only: N % 256 == 0, K % 128 == 0; any M >= 1.  f16 / bf16.
+ * impl: 0 = pick, 256 = the persistent 256 x 256 kernel (N % 256 == 0, K % 128 == 0; any M >= 1), 128 = the 128 x 128
+ * kernel (N % 128 == 0, K % 64 == 0); the two give the same bits (the statistics are summed in one fixed order).  f16 / bf16.
  * ap_stream_init: tok f32 [rows, dim] -> x T [rows, dim] + rowstats of the rounded rows (two-pass). */
 #define AP_EPI_NORM 4
 #define AP_EPI_NORM_GELU 5
 #define AP_EPI_RESID_STATS 6
 int ap_gemm_fused(int dtype, int epilogue, const void* A, int lda, const void* W, int ldw, int M, int N, int K,
                   const float* bias, const float* colsum, const float* rowstats, float* partial,
-                  void* out, int ldo, ap_stream_t stream);
+                  void* out, int ldo, int impl, ap_stream_t stream);
 int ap_stream_init(int dtype, const float* tok, int rows, int dim, float eps, void* x, float* rowstats,
                    ap_stream_t stream);
 int ap_rowstats_finalize(const float* partial, int rows, int groups, int dim, float eps, float* rowstats,

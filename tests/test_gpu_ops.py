@@ -87,13 +87,13 @@ def test_gemm_tile_seam_with_cold_bias(env, shape):
 
 
 # ----------------------------------------------------------------------------- fused-LayerNorm GEMM epilogues
-def _fused(env, dt, epi, A, W, bias, colsum, rowstats, partial, out):
+def _fused(env, dt, epi, A, W, bias, colsum, rowstats, partial, out, impl=256):
     _lib, lib, dev, stream = env
     M, K = A.shape
     p = lambda t: t.data_ptr() if t is not None else None
     _lib.check(lib.ap_gemm_fused(_lib.torch_dtype_code(dt), epi, A.data_ptr(), A.stride(0), W.data_ptr(), W.stride(0),
                                  M, W.shape[0], K, bias.data_ptr(), p(colsum), p(rowstats), p(partial), out.data_ptr(),
-                                 out.stride(0), stream), "ap_gemm_fused")
+                                 out.stride(0), impl, stream), "ap_gemm_fused")
     torch.cuda.synchronize()
 
 
@@ -121,6 +121,11 @@ def test_gemm_resid_stats_epilogue(env, dt, shape):
         runs.append((x, part))
     assert all(torch.equal(runs[0][0], r[0]) and torch.equal(runs[0][1], r[1]) for r in runs[1:])
     x, part = runs[0]
+    # the 128 x 128 kernel (what small problems are served by) gives the same stream AND the same partial sums, bit for bit
+    x128 = x0.clone()
+    part128 = torch.full((M, N // 64, 2), float("nan"), device=dev)
+    _fused(env, dt, 6, A, W, bias, None, None, part128, x128, impl=128)
+    assert torch.equal(x128, x) and torch.equal(part128, part)
     branch = (A.float() @ W.float().t() + bias)
     want = (x0.float() + branch.to(dt).float()).to(dt)
     ulp = 2.0 ** -10 if dt == torch.float16 else 2.0 ** -7
@@ -172,6 +177,9 @@ def test_gemm_norm_epilogue_equals_layernorm_then_linear(env, dt, tol, gelu, sha
         _fused(env, dt, 5 if gelu else 4, x16, Wf, bf, colsum, stats, None, out)
         outs.append(out)
     assert all(torch.equal(outs[0], o) for o in outs[1:])
+    out128 = torch.full((M, N), float("nan"), device=dev, dtype=dt)
+    _fused(env, dt, 5 if gelu else 4, x16, Wf, bf, colsum, stats, None, out128, impl=128)
+    assert torch.equal(out128, outs[0])                      # 128 x 128 twin: same bits
     want = torch.nn.functional.layer_norm(x.float(), (K,), gamma, beta, 1e-6) @ Wl.t() + b
     if gelu:
         want = torch.nn.functional.gelu(want)

@@ -27,9 +27,9 @@ for name, N, K in (("proj", 768, 768), ("fc2", 768, 3072), ("qkv", 2304, 768), (
     plain_epi = 1 if name == "fc1" else 0
     ms_plain = t(lambda: _lib.check(lib.ap_gemm(1, plain_epi, A.data_ptr(), K, W.data_ptr(), K, M, N, K, bias.data_ptr(), None, O.data_ptr(), N, 256, 0, sp()), "g"))
     if name in ("proj", "fc2"):
-        ms_f = t(lambda: _lib.check(lib.ap_gemm_fused(1, 6, A.data_ptr(), K, W.data_ptr(), K, M, N, K, bias.data_ptr(), None, None, part.data_ptr(), O.data_ptr(), N, sp()), "f"))
+        ms_f = t(lambda: _lib.check(lib.ap_gemm_fused(1, 6, A.data_ptr(), K, W.data_ptr(), K, M, N, K, bias.data_ptr(), None, None, part.data_ptr(), O.data_ptr(), N, 0, sp()), "f"))
     else:
-        ms_f = t(lambda: _lib.check(lib.ap_gemm_fused(1, 5 if name == "fc1" else 4, A.data_ptr(), K, W.data_ptr(), K, M, N, K, bias.data_ptr(), cs.data_ptr(), rs.data_ptr(), None, O.data_ptr(), N, sp()), "f"))
+        ms_f = t(lambda: _lib.check(lib.ap_gemm_fused(1, 5 if name == "fc1" else 4, A.data_ptr(), K, W.data_ptr(), K, M, N, K, bias.data_ptr(), cs.data_ptr(), rs.data_ptr(), None, O.data_ptr(), N, 0, sp()), "f"))
     out[name] = {"plain_ms": round(ms_plain, 4), "fused_ms": round(ms_f, 4), "plain_TF": round(flop / ms_plain / 1e9, 1), "fused_TF": round(flop / ms_f / 1e9, 1)}
     del A, W, O, part
 print(json.dumps({"M": M, "env": {k: v for k, v in os.environ.items() if k.startswith("AP_")}, **out}))

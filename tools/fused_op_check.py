@@ -20,7 +20,7 @@ def run(M, N, K, dt, seed=0):
     for rep in range(4):
         X = X0.clone(); part = torch.full((M, N // 64, 2), float("nan"), device=dev)
         _lib.check(lib.ap_gemm_fused(dt, 6, A.data_ptr(), K, W.data_ptr(), K, M, N, K, bias.data_ptr(), None, None, part.data_ptr(),
-                                     X.data_ptr(), N, sp()), "resid")
+                                     X.data_ptr(), N, 0, sp()), "resid")
         torch.cuda.synchronize(); outs.append((X, part))
     for X, part in outs[1:]:
         if not (torch.equal(X, outs[0][0]) and torch.equal(part, outs[0][1])):
@@ -48,7 +48,7 @@ def run(M, N, K, dt, seed=0):
         for rep in range(4):
             O = torch.empty((M, N2), dtype=tdt, device=dev)
             _lib.check(lib.ap_gemm_fused(dt, epi, x.data_ptr(), N, W2.data_ptr(), N, M, N2, N, b2.data_ptr(), cs.data_ptr(), rs.data_ptr(), None,
-                                         O.data_ptr(), N2, sp()), name)
+                                         O.data_ptr(), N2, 0, sp()), name)
             torch.cuda.synchronize(); outs.append(O)
         for O in outs[1:]:
             if not torch.equal(O, outs[0]):

@@ -81,10 +81,14 @@ SIGNATURES = {
                            C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.c_long,
                            C.c_void_p, C.c_long, C.c_long, C.c_void_p]),
     "ap_softmax_rows": (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]),
+    "ap_sattention_f32": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_long, C.c_void_p]),
     "ap_sam2_patchify": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p,
                                    C.c_void_p]),
     "ap_window_partition": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ap_window_unpartition": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "ap_window_unpartition_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                            C.c_void_p]),
     "ap_maxpool2x2": (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ap_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ap_add_rowvec": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),

@@ -176,6 +176,11 @@ int launch_convert(int dtype, const float* src, void* dst, size_t count, hipStre
 int launch_chw_to_patchrows(int x_dtype, int dtype, const void* x, int n, int S, int ps, void* dst,
                             int ld, hipStream_t stream);
 
+// fused float32 attention of the SAM2 trunk's image-wide blocks (sam2_attention.hip)
+bool sattention_supports(int heads, int tq, int tk, int d, long ldq, long ldk, long ldv, long ldo);
+int launch_sattention(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv, int batch, int heads, int tq,
+                      int tk, int d, float scale, float* out, long ldo, hipStream_t stream);
+
 // content statistics (content.hip): counts [n, 2] = (#gray < black_thresh, #(S < sat_thresh && V >= value_thresh))
 int tile_content_counts(const uint8_t* tiles, int n, int h, int w, int black_thresh, int sat_thresh,
                         int value_thresh, unsigned* counts, hipStream_t stream);

@@ -344,7 +344,8 @@ __global__ void window_partition_kernel(const float* x, int B, int H, int W, int
     win[i] = (y < H && xx < W) ? x[(((size_t)b * H + y) * W + xx) * C + c] : 0.f;
 }
 
-__global__ void window_unpartition_kernel(const float* win, int B, int H, int W, int C, int ws, int nwy, int nwx, float* x) {
+__global__ void window_unpartition_kernel(const float* win, const float* resid, int B, int H, int W, int C, int ws, int nwy, int nwx,
+                                          float* x) {
     const size_t total = (size_t)B * H * W * C;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -352,7 +353,8 @@ __global__ void window_unpartition_kernel(const float* win, int B, int H, int W,
     const int xx = (int)(r % W); r /= W;
     const int y = (int)(r % H); const int b = (int)(r / H);
     const int wy = y / ws, iy = y % ws, wx = xx / ws, ix = xx % ws;
-    x[i] = win[((((size_t)(b * nwy + wy) * nwx + wx) * ws + iy) * ws + ix) * C + c];
+    const float v = win[((((size_t)(b * nwy + wy) * nwx + wx) * ws + iy) * ws + ix) * C + c];
+    x[i] = resid ? resid[i] + v : v;
 }
 
 // in [B, H, W, C] with row stride ld_in (elements per pixel) -> out [B, H/2, W/2, C] dense
@@ -493,6 +495,11 @@ int ap_sgemm(const float* A, long lda, long strideA, const float* W, long ldw, l
     return AP_OK;
 }
 
+int ap_sattention_f32(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv, int batch, int heads, int tq,
+                      int tk, int d, float scale, float* out, long ldo, ap_stream_t stream) {
+    return ap::launch_sattention(q, ldq, k, ldk, v, ldv, batch, heads, tq, tk, d, scale, out, ldo, (hipStream_t)stream);
+}
+
 int ap_softmax_rows(float* x, long ld, int rows, int cols, ap_stream_t stream) {
     AP_REQUIRE(x && rows > 0 && cols > 0, "ap_softmax_rows: bad arguments");
     const dim3 grid((rows + 3) / 4);
@@ -529,7 +536,17 @@ int ap_window_unpartition(const float* win, int b, int h, int w, int c, int ws, 
     AP_REQUIRE(x && win && ws > 0, "ap_window_unpartition: bad arguments");
     const int nwy = (h + ws - 1) / ws, nwx = (w + ws - 1) / ws;
     ap::window_unpartition_kernel<<<ap::grid1((size_t)b * h * w * c), 256, 0, (hipStream_t)stream>>>(
-        win, b, h, w, c, ws, nwy, nwx, x);
+        win, nullptr, b, h, w, c, ws, nwy, nwx, x);
+    AP_HIP_CHECK(hipGetLastError());
+    return AP_OK;
+}
+
+int ap_window_unpartition_add(const float* win, const float* resid, int b, int h, int w, int c, int ws, float* x,
+                              ap_stream_t stream) {
+    AP_REQUIRE(x && win && resid && ws > 0, "ap_window_unpartition_add: bad arguments");
+    const int nwy = (h + ws - 1) / ws, nwx = (w + ws - 1) / ws;
+    ap::window_unpartition_kernel<<<ap::grid1((size_t)b * h * w * c), 256, 0, (hipStream_t)stream>>>(
+        win, resid, b, h, w, c, ws, nwy, nwx, x);
     AP_HIP_CHECK(hipGetLastError());
     return AP_OK;
 }

@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Optional
 
 import numpy as np
@@ -55,6 +56,7 @@ class Sam2HipPredictor:
         self.input_size = 1024
         self.plan, self.stage_ends = block_plan()
         self._graph = None
+        self.fused_attention = os.environ.get("ATLASPATCH_SAM2_UNFUSED_ATTENTION") in (None, "", "0")
         self._static_img = self._static_mask = None
         f = lambda t: t.detach().to(torch.float32).contiguous()
         sd = {k: f(v) for k, v in state_dict.items()}
@@ -158,8 +160,14 @@ class Sam2HipPredictor:
     def _attention(self, q, k, v, *, nb, heads, tq, tk, d, ldq, ldk, ldv):
         """q [nb*tq, ldq], k / v [nb*tk, ld*] with head h at column h*d  ->  [nb*tq, heads*d]."""
         out = self._buf(nb * tq, heads * d)
-        scores = self._buf(nb * heads, tq, tk)
         scale = 1.0 / math.sqrt(d)
+        if (self.fused_attention and d in (32, 64, 96) and nb <= 65535 and ldq % 4 == 0 and ldk % 4 == 0
+                and q.data_ptr() % 16 == 0 and k.data_ptr() % 16 == 0):
+            # one fused kernel for all windows and heads: the [nb, heads, tq, tk] score matrix never reaches memory
+            _lib.check(self.lib.ap_sattention_f32(q.data_ptr(), ldq, k.data_ptr(), ldk, v.data_ptr(), ldv, nb, heads, tq, tk, d,
+                                                  scale, out.data_ptr(), heads * d, self._stream()), "ap_sattention_f32")
+            return out
+        scores = self._buf(nb * heads, tq, tk)
         if nb == 1:                     # one image-wide attention: the heads are the batch (head h = column offset h * d)
             self._gemm(q, k, tk, d, m=tq, lda=ldq, ldw=ldk, out=scores, ldo=tk, batch=heads, sa=d, sw=d, so=tq * tk, alpha=scale)
             _lib.check(self.lib.ap_softmax_rows(scores.data_ptr(), tk, heads * tq, tk, self._stream()), "ap_softmax_rows")
@@ -214,16 +222,17 @@ class Sam2HipPredictor:
                 t_q = hh * ww
             a = self._attention(q, qkv[:, dout:], qkv[:, 2 * dout:], nb=nb, heads=heads, tq=t_q, tk=t_k, d=d,
                                 ldq=ldq, ldk=3 * dout, ldv=3 * dout)
-            a = self._gemm(a, g("attn.proj.weight"), dout, dout, bias=g("attn.proj.bias"))
             if qpool:
                 H, W = H // 2, W // 2
                 window = window // 2
+            # x = shortcut + attn: the residual add rides on the projection GEMM's epilogue (image-wide blocks) or on the
+            # window un-partition pass (windowed blocks)
             if window > 0:
-                un = self._buf(H * W, dout)
-                _lib.check(lib.ap_window_unpartition(a.data_ptr(), 1, H, W, dout, window, un.data_ptr(), st))
-                a = un
-            x2 = self._buf(H * W, dout)
-            _lib.check(lib.ap_add(x2.data_ptr(), shortcut.data_ptr(), a.data_ptr(), H * W * dout, st))
+                a = self._gemm(a, g("attn.proj.weight"), dout, dout, bias=g("attn.proj.bias"))
+                x2 = self._buf(H * W, dout)
+                _lib.check(lib.ap_window_unpartition_add(a.data_ptr(), shortcut.data_ptr(), 1, H, W, dout, window, x2.data_ptr(), st))
+            else:
+                x2 = self._gemm(a, g("attn.proj.weight"), dout, dout, bias=g("attn.proj.bias"), resid=shortcut)
             xn2 = self._ln(x2, H * W, dout, g("norm2.weight"), g("norm2.bias"), 1e-6)
             hid = self._gemm(xn2, g("mlp.layers.0.weight"), 4 * dout, dout, bias=g("mlp.layers.0.bias"), act=1)
             x = self._gemm(hid, g("mlp.layers.1.weight"), dout, 4 * dout, bias=g("mlp.layers.1.bias"), resid=x2)

@@ -300,6 +300,13 @@ int ap_sgemm(const float* A, long lda, long strideA, const float* W, long ldw, l
              int batch, int M, int N, int K, float alpha, const float* bias, int act,
              const float* resid, long ldr, long strideR, float* out, long ldo, long strideO, ap_stream_t stream);
 int ap_softmax_rows(float* x, long ld, int rows, int cols, ap_stream_t stream);     /* in place */
+/* Fused attention of the trunk (hieradet.py MultiScaleAttention -> F.scaled_dot_product_attention), image-wide blocks
+ * (batch = 1) and windowed blocks (batch = number of windows, window b owns rows b * tq .. of q / out and b * tk .. of k / v):
+ * out[b*tq + t][h*d + c] = sum_j softmax_j(scale * q[b*tq + t][h*d + :] . k[b*tk + j][h*d + :]) v[b*tk + j][h*d + c];
+ * float32, head h at column h * d; exact-f32 MFMA, online softmax, the scores never reach memory.  d in {32, 64, 96};
+ * any tq, tk >= 1; row strides multiples of 4 floats, q / k / out 16-byte aligned. */
+int ap_sattention_f32(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv, int batch, int heads,
+                      int tq, int tk, int d, float scale, float* out, long ldo, ap_stream_t stream);
 /* uint8 [h, w, 3] -> rows [(h/4)*(w/4), 147] of ((x/255) - mean) / std in (c, ky, kx) order: the im2col of
  * Hiera's PatchEmbed conv (7x7, stride 4, pad 3). */
 int ap_sam2_patchify(const uint8_t* image, int h, int w, const float mean[3], const float stdv[3], float* out,
@@ -308,6 +315,9 @@ int ap_sam2_patchify(const uint8_t* image, int h, int w, const float mean[3], co
  * zero padded / cropped. */
 int ap_window_partition(const float* x, int b, int h, int w, int c, int ws, float* win, ap_stream_t stream);
 int ap_window_unpartition(const float* win, int b, int h, int w, int c, int ws, float* x, ap_stream_t stream);
+/* x = resid + window_unpartition(win): the block's `x = shortcut + drop_path(attn(...))` in the same pass (hieradet.py MultiScaleBlock) */
+int ap_window_unpartition_add(const float* win, const float* resid, int b, int h, int w, int c, int ws, float* x,
+                              ap_stream_t stream);
 /* 2x2 stride-2 max pool on [b, h, w, c] whose pixels are ld_in elements apart -> dense [b, h/2, w/2, c] */
 int ap_maxpool2x2(const float* in, long ld_in, int b, int h, int w, int c, float* out, ap_stream_t stream);
 int ap_add(float* out, const float* a, const float* b, size_t n, ap_stream_t stream);

@@ -421,6 +421,36 @@ def test_sgemm_mfma_vs_torch(env, case):
     assert torch.isfinite(out).all() and err <= 2e-6 * scale * max(1.0, K ** 0.5 / 4), (err, scale)
 
 
+@pytest.mark.parametrize("case", [(1, 4, 4096, 4096, 96), (1, 2, 64, 128, 32), (3, 3, 160, 256, 64), (25, 4, 196, 196, 96),
+                                  (25, 8, 49, 196, 96), (64, 1, 64, 64, 96), (100, 2, 16, 64, 96), (1, 8, 9, 9, 32),
+                                  (7, 2, 4, 16, 96), (2, 1, 33, 1, 64)])
+def test_sattention_f32_vs_torch(env, case):
+    """ap_sattention_f32 (fused exact-f32 MFMA attention of the SAM2 trunk: image-wide blocks and batched windows, ragged
+    query / key counts, key tiles split over four waves and merged) against softmax(q k^T scale) v in float64; repeatable."""
+    import math
+    _lib, lib, dev, stream = env
+    nb, heads, tq, tk, d = case
+    g = torch.Generator(device=dev).manual_seed(nb * 7 + tq + tk + d)
+    ld = 3 * heads * d
+    qkv_q = torch.randn((nb * tq, ld), device=dev, generator=g) * 1.3
+    qkv_k = torch.randn((nb * tk, ld), device=dev, generator=g) * 1.3
+    q, k, v = qkv_q[:, :heads * d], qkv_k[:, heads * d:2 * heads * d], qkv_k[:, 2 * heads * d:]
+    scale = 1.0 / math.sqrt(d)
+    outs = []
+    for _ in range(3):
+        o = torch.full((nb * tq, heads * d), float("nan"), device=dev)
+        _lib.check(lib.ap_sattention_f32(q.data_ptr(), ld, k.data_ptr(), ld, v.data_ptr(), ld, nb, heads, tq, tk, d, scale,
+                                         o.data_ptr(), heads * d, stream), "ap_sattention_f32")
+        torch.cuda.synchronize()
+        outs.append(o)
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    qh = q.reshape(nb, tq, heads, d).permute(0, 2, 1, 3).double()
+    kh = k.reshape(nb, tk, heads, d).permute(0, 2, 1, 3).double()
+    vh = v.reshape(nb, tk, heads, d).permute(0, 2, 1, 3).double()
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * scale, -1) @ vh).permute(0, 2, 1, 3).reshape(nb * tq, heads * d).float()
+    assert (outs[0] - ref).abs().max().item() <= 2e-5
+
+
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16, torch.float32])
 def test_gelu_epilogue_deviation_from_erf_is_isolated_and_bounded(env, dt):
     """The f16 / bf16 GEMM epilogue evaluates GELU as x * sigmoid(x * (c0 + c1 t + c2 t^2)), t = min(x^2, 50) (a minimax fit of the

@@ -91,6 +91,10 @@ enum GemmEpilogue {
     // 64-column group, partial[m][n / 64] = (sum, sum of squares) of the NEW row values (f32): what the
     // next fused-LayerNorm GEMM's rowstats are built from (launch_rowstats_finalize)
     EPI_RESID_STATS = 6,
+    // patch embedding straight into the T stream: row m = img * P + p of the patch matrix lands in stream row
+    // img * (P + 1) + 1 + p as  T(pos16[1 + p][n] + T(acc + bias[n]))  together with that row's partial sums (the RESID_STATS
+    // epilogue with the "residual" read from the T copy of the position embedding and remapped output rows)
+    EPI_PATCH_STREAM = 7,
 };
 
 struct GemmArgs {
@@ -102,7 +106,8 @@ struct GemmArgs {
     const float* pos;        // EPI_PATCH_EMBED: [P + 1, N]
     const float* colsum;     // EPI_NORM_*: f32 [N]
     const float* rowstats;   // EPI_NORM_*: f32 [M, 2] = (rstd, -mean * rstd)
-    float* partial;          // EPI_RESID_STATS: f32 [M, N / 64, 2]
+    float* partial;          // EPI_RESID_STATS / EPI_PATCH_STREAM: f32 [rows, N / 64, 2]
+    const void* pos16;       // EPI_PATCH_STREAM: T [P + 1, N]
     void* out; int ldo;      // T (STORE / GELU) or f32 (RESID / PATCH_EMBED)
     int P;                   // EPI_PATCH_EMBED: patches per image
     int ablate;              // gemm256 A/B twin only: timing ablation flags (results invalid when set)
@@ -169,6 +174,9 @@ int launch_fold_ln(int dtype, const float* w32, int rows, int cols, int ld, cons
                    const float* bias_in, void* wout, float* colsum, float* bias_out, hipStream_t stream);
 int launch_fold_ls(int dtype, const float* w32, int rows, int cols, int ld, const float* ls, const float* bias_in,
                    void* wout, float* bias_out, hipStream_t stream);
+// fused path: stream rows of the class token, x[img * tokens] = T(cls + pos[0]), and their partial sums
+int launch_cls_stream(int dtype, const float* cls, const float* pos, int n, int tokens, int dim, void* x, float* partial,
+                      hipStream_t stream);
 int launch_cls_init(float* tok, const float* cls, const float* pos, int n, int tokens, int dim,
                     hipStream_t stream);
 int launch_convert(int dtype, const float* src, void* dst, size_t count, hipStream_t stream);

@@ -325,6 +325,23 @@ __global__ __launch_bounds__(256) void rowstats_finalize_kernel(const float* __r
     rowstats[2 * (size_t)row + 1] = (float)(-mean * rstd);
 }
 
+// class-token rows of the fused path: x[img * tokens][:] = T(cls + pos[0]) and the row's partial sums per 64-column group
+// (one wave per (image, group): lane = column).  Only this kernel ever produces these rows, so its summation order is theirs.
+template <typename T>
+__global__ __launch_bounds__(64) void cls_stream_kernel(const float* __restrict__ cls, const float* __restrict__ pos, int tokens,
+                                                        int dim, T* __restrict__ x, float* __restrict__ partial) {
+    const int img = blockIdx.x, grp = blockIdx.y, col = grp * 64 + threadIdx.x;
+    const size_t row = (size_t)img * tokens;
+    const T v = from_f32<T>(cls[col] + pos[col]);
+    x[row * dim + col] = v;
+    const float f = (float)v;
+    const float s = wave_sum(f), q = wave_sum(f * f);
+    if (threadIdx.x == 0) {
+        partial[(row * (dim >> 6) + grp) * 2] = s;
+        partial[(row * (dim >> 6) + grp) * 2 + 1] = q;
+    }
+}
+
 template <typename T>
 __global__ void stream_to_f32_kernel(const T* __restrict__ x, long stride, int rows, int dim, float* __restrict__ dst) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per 4 elements
@@ -490,6 +507,18 @@ int launch_stream_init(int dtype, const float* tok, int rows, int dim, float eps
     if (dtype == AP_F16) stream_init_kernel<f16><<<grid, block, 0, stream>>>(tok, rows, dim, eps, (f16*)x, rowstats);
     else if (dtype == AP_BF16) stream_init_kernel<bf16><<<grid, block, 0, stream>>>(tok, rows, dim, eps, (bf16*)x, rowstats);
     else { set_error("stream_init: dtype %d (f16 / bf16 only)", dtype); return AP_ERR_INVALID; }
+    AP_HIP_CHECK(hipGetLastError());
+    return AP_OK;
+}
+
+int launch_cls_stream(int dtype, const float* cls, const float* pos, int n, int tokens, int dim, void* x, float* partial,
+                      hipStream_t stream) {
+    AP_REQUIRE(dim % 64 == 0, "cls_stream: dim %d must be a multiple of 64", dim);
+    if (n <= 0) return AP_OK;
+    dim3 grid(n, dim / 64), block(64);
+    if (dtype == AP_F16) cls_stream_kernel<f16><<<grid, block, 0, stream>>>(cls, pos, tokens, dim, (f16*)x, partial);
+    else if (dtype == AP_BF16) cls_stream_kernel<bf16><<<grid, block, 0, stream>>>(cls, pos, tokens, dim, (bf16*)x, partial);
+    else { set_error("cls_stream: dtype %d (f16 / bf16 only)", dtype); return AP_ERR_INVALID; }
     AP_HIP_CHECK(hipGetLastError());
     return AP_OK;
 }

@@ -259,23 +259,31 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
         }
         return;
     }
-    if constexpr (sizeof(T) == 2 && EPI == EPI_RESID_STATS) {
+    if constexpr (sizeof(T) == 2 && (EPI == EPI_RESID_STATS || EPI == EPI_PATCH_STREAM)) {
+        constexpr bool kPatch = EPI == EPI_PATCH_STREAM;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             int m = m0 + wave_m * 64 + mt * 32 + l31;
             const bool live = m < g.M;
             if (!live) m = g.M - 1;                              // every lane takes part in the lane exchanges
+            size_t orow = (size_t)m;                             // output (stream) row
+            const T* srow = (const T*)g.out + (size_t)m * (size_t)g.ldo;        // where the "residual" comes from
+            if constexpr (kPatch) {                              // patch row m = img * P + p -> stream row img * (P + 1) + 1 + p
+                const int img = m / g.P, p = m - img * g.P;
+                orow = (size_t)m + img + 1;
+                srow = (const T*)g.pos16 + (size_t)(1 + p) * g.N;
+            }
             float cs8[8], cq8[8];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int n = n0 + wave_n * 64 + nt * 32 + g4 * 8 + hi * 4;
-                    T* px = (T*)g.out + (size_t)m * (size_t)g.ldo + n;
+                    T* px = (T*)g.out + orow * (size_t)g.ldo + n;
                     f32x4 v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[nt][mt][g4 * 4 + e];
-                    const u32x2 y = resid_add4<T>(pack4t<T>(v), *(const u32x2*)px);
+                    const u32x2 y = resid_add4<T>(pack4t<T>(v), *(const u32x2*)(srow + n));
                     if (live) *(u32x2*)px = y;
                     // chain: lower lane (columns 0-3 of the chunk) first, then the partner continues with columns 4-7
                     float s = 0.f, q = 0.f;
@@ -290,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
                 const float s = ((cs8[0] + cs8[1]) + (cs8[2] + cs8[3])) + ((cs8[4] + cs8[5]) + (cs8[6] + cs8[7]));
                 const float q = ((cq8[0] + cq8[1]) + (cq8[2] + cq8[3])) + ((cq8[4] + cq8[5]) + (cq8[6] + cq8[7]));
                 typedef float f32x2v __attribute__((ext_vector_type(2)));
-                *(f32x2v*)(g.partial + ((size_t)m * (g.N >> 6) + ((n0 + wave_n * 64) >> 6)) * 2) = f32x2v{s, q};
+                *(f32x2v*)(g.partial + (orow * (g.N >> 6) + ((n0 + wave_n * 64) >> 6)) * 2) = f32x2v{s, q};
             }
         }
         return;
@@ -365,6 +373,7 @@ int launch_typed(int epilogue, const GemmArgs& a, hipStream_t stream) {
         case EPI_NORM_STORE: gemm_kernel<T, EPI_NORM_STORE><<<grid, block, 0, stream>>>(a); break;
         case EPI_NORM_GELU: gemm_kernel<T, EPI_NORM_GELU><<<grid, block, 0, stream>>>(a); break;
         case EPI_RESID_STATS: gemm_kernel<T, EPI_RESID_STATS><<<grid, block, 0, stream>>>(a); break;
+        case EPI_PATCH_STREAM: gemm_kernel<T, EPI_PATCH_STREAM><<<grid, block, 0, stream>>>(a); break;
         default: set_error("gemm: unknown epilogue %d", epilogue); return AP_ERR_INVALID;
     }
     AP_HIP_CHECK(hipGetLastError());
@@ -381,9 +390,11 @@ int launch_gemm_impl(int dtype, int epilogue, const GemmArgs& a, int impl, int v
     AP_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem %d x %d x %d", a.M, a.N, a.K);
     AP_REQUIRE(impl == 0 || impl == 128 || impl == 256 || impl == 257, "gemm: unknown implementation %d", impl);
     if (impl == 257) return launch_gemm256_alt(dtype, epilogue, a, variant, stream);
-    const bool fused_epi = epilogue == EPI_NORM_STORE || epilogue == EPI_NORM_GELU || epilogue == EPI_RESID_STATS;
+    const bool fused_epi = epilogue == EPI_NORM_STORE || epilogue == EPI_NORM_GELU || epilogue == EPI_RESID_STATS ||
+                           epilogue == EPI_PATCH_STREAM;
     AP_REQUIRE(!fused_epi || dtype != AP_F32, "gemm: the fused-LayerNorm epilogues are f16 / bf16 only");
-    AP_REQUIRE(!fused_epi || (epilogue == EPI_RESID_STATS ? a.partial != nullptr : (a.colsum && a.rowstats)),
+    AP_REQUIRE(!fused_epi || (epilogue == EPI_RESID_STATS ? a.partial != nullptr :
+                              epilogue == EPI_PATCH_STREAM ? (a.partial && a.pos16 && a.P > 0) : (a.colsum && a.rowstats)),
                "gemm: missing operand for the fused-LayerNorm epilogue %d", epilogue);
     // Kernel choice (results are bit-identical either way).  The persistent 256 x 256 kernel needs about one tile per CU to
     // pay: with few row tiles and a narrow N (proj / fc2 of a 32-tile extract_batch: 75 tiles for 256 CUs) the 128 x 128

@@ -180,7 +180,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) char smem[kLdsBytes];
 
     constexpr bool kNorm = EPI == EPI_NORM_STORE || EPI == EPI_NORM_GELU;
-    constexpr bool kRes = EPI == EPI_RESID_STATS;
+    constexpr bool kPatch = EPI == EPI_PATCH_STREAM;
+    constexpr bool kRes = EPI == EPI_RESID_STATS || kPatch;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -208,6 +209,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
     }
     if (tw.count == 0) return;
     const int nk = g.K / 64;
+    const float inv_p = kPatch ? 1.0f / (float)g.P : 0.0f;
     // Start-time skew: equal tiles keep every CU in step, so all epilogues (the HBM write bursts)
     // would coincide.  Workgroup j of an XCD starts j / nwx of a tile period late; the early ones are
     // the ones that own one tile more.
@@ -510,7 +512,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
             auto res_ld = [&](int j) {
                 int m = m0 + (j >> 2) * 32 + (j & 3) * 8 + rrow;
                 m = m < g.M ? m : g.M - 1;
-                res[j] = *(const u32x4*)((const T*)g.out + (size_t)m * g.ldo + n0 + rc * 8);
+                if constexpr (kPatch) {                              // "residual" = the patch's position embedding row
+                    int q = (int)((float)m * inv_p);                 // m / P for m < 2^24 (float estimate, corrected)
+                    int p = m - q * g.P;
+                    p = p < 0 ? p + g.P : (p >= g.P ? p - g.P : p);
+                    res[j] = *(const u32x4*)((const T*)g.pos16 + (size_t)(1 + p) * g.N + n0 + rc * 8);
+                } else {
+                    res[j] = *(const u32x4*)((const T*)g.out + (size_t)m * g.ldo + n0 + rc * 8);
+                }
             };
 #pragma unroll
             for (int j = 0; j < 8; ++j) res_ld(j);
@@ -612,6 +621,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
                     const int row = i * 8 + rrow;
                     u32x4 v = *(const u32x4*)(scr + row * 128 + ((rc ^ (row & 7)) << 4));
                     const int m = m0 + mb * 32 + row;
+                    size_t orow = (size_t)m;
+                    if constexpr (kPatch) {                          // patch row -> stream row img * (P + 1) + 1 + p
+                        int q = (int)((float)m * inv_p);
+                        const int p = m - q * g.P;
+                        q = p < 0 ? q - 1 : (p >= g.P ? q + 1 : q);
+                        orow = (size_t)m + q + 1;
+                    }
                     if constexpr (kRes) {
                         float s = 0.f, q = 0.f;
                         v = resid_add_stats<T>(v, res[mb * 4 + i], s, q);
@@ -619,10 +635,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
                         q = sum8(q);
                         if (m < g.M && rc == 0) {
                             f32x2 sq = {s, q};
-                            *(f32x2*)(g.partial + ((size_t)m * (g.N >> 6) + (n0 >> 6)) * 2) = sq;
+                            *(f32x2*)(g.partial + (orow * (g.N >> 6) + (n0 >> 6)) * 2) = sq;
                         }
                     }
-                    if (m < g.M) *(u32x4*)((T*)g.out + (size_t)m * g.ldo + n0 + rc * 8) = v;
+                    if (m < g.M) *(u32x4*)((T*)g.out + orow * g.ldo + n0 + rc * 8) = v;
                 }
             }
         }
@@ -656,6 +672,7 @@ int launch_typed(int epilogue, const GemmArgs& a, int num_cu, int variant, hipSt
         case EPI_NORM_STORE: return launch_epi<T, EPI_NORM_STORE>(a, num_cu, variant, stream);
         case EPI_NORM_GELU: return launch_epi<T, EPI_NORM_GELU>(a, num_cu, variant, stream);
         case EPI_RESID_STATS: return launch_epi<T, EPI_RESID_STATS>(a, num_cu, variant, stream);
+        case EPI_PATCH_STREAM: return launch_epi<T, EPI_PATCH_STREAM>(a, num_cu, variant, stream);
     }
     set_error("gemm256: unsupported epilogue %d", epilogue);
     return AP_ERR_INVALID;
@@ -675,7 +692,9 @@ extern int g_gemm_trace_tiles;
 bool AP_G256_FN(gemm256_supports)(int dtype, int epilogue, const GemmArgs& a) {
     if (dtype != AP_F16 && dtype != AP_BF16) return false;
     if (epilogue != EPI_BIAS_STORE && epilogue != EPI_BIAS_GELU && epilogue != EPI_BIAS_RESID &&
-        epilogue != EPI_NORM_STORE && epilogue != EPI_NORM_GELU && epilogue != EPI_RESID_STATS) return false;
+        epilogue != EPI_NORM_STORE && epilogue != EPI_NORM_GELU && epilogue != EPI_RESID_STATS && epilogue != EPI_PATCH_STREAM)
+        return false;
+    if (epilogue == EPI_PATCH_STREAM && (!a.partial || !a.pos16 || a.P <= 0 || a.M >= (1 << 24))) return false;
     if ((epilogue == EPI_NORM_STORE || epilogue == EPI_NORM_GELU) && (!a.colsum || !a.rowstats)) return false;
     if (epilogue == EPI_RESID_STATS && !a.partial) return false;
     if (a.N % kBN != 0 || a.K % 128 != 0 || a.K < 128) return false;

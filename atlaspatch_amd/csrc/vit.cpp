@@ -62,6 +62,7 @@ struct ap_vit {
     bool full_last_block = false, two_half_overlap = false, f32_stream = false;
     std::vector<ap::FusedBlock> fused;      // filled by ap_vit_finalize for f16 / bf16
     std::vector<void*> fused_allocs;
+    void* pos16 = nullptr;                  // position embedding in the compute type (fused patch embedding), in fused_allocs
     int device = 0;
     // optional per-launch HIP-event timing (ap_vit_profile_*): kind -> events of the last forwards
     bool profile = false;
@@ -174,6 +175,24 @@ int patch_embed(ap_vit* m, int n, const Workspace& w, hipStream_t stream) {
         if ((rc = ap::launch_cls_init(w.tok, m->cls, m->pos, n, m->tokens, D, stream)) != AP_OK) return rc;
     }
     return AP_OK;
+}
+
+// fused path: the patch embedding writes the T stream and its partial sums directly (EPI_PATCH_STREAM), the class-token
+// rows come from a tiny kernel, one finalisation turns the partial sums into the first row statistics
+int patch_embed_stream(ap_vit* m, int n, const Workspace& w, hipStream_t stream) {
+    const ap_vit_config& c = m->cfg;
+    const int dt = c.compute_dtype, D = c.dim;
+    int rc;
+    ap::GemmArgs g{};
+    g.A = w.hid; g.lda = m->kpe; g.W = m->pe_w->dev; g.ldw = m->pe_w->ld;
+    g.M = n * m->patches; g.N = D; g.K = m->kpe;
+    g.bias = m->pe_b; g.pos16 = m->pos16; g.P = m->patches;
+    g.out = w.x16; g.ldo = D; g.partial = w.partial;
+    { ScopedTimer t(m, AP_PROF_GEMM_PATCH_EMBED, stream);
+      if ((rc = ap::launch_gemm(dt, ap::EPI_PATCH_STREAM, g, stream)) != AP_OK) return rc; }
+    ScopedTimer t(m, AP_PROF_LAYERNORM, stream);
+    if ((rc = ap::launch_cls_stream(dt, m->cls, m->pos, n, m->tokens, D, w.x16, w.partial, stream)) != AP_OK) return rc;
+    return ap::launch_rowstats_finalize(w.partial, n * m->tokens, D / 64, D, c.ln_eps, w.rowstats, stream);
 }
 
 // ---- block loop, f32 residual stream (float32 mode; AP_VIT_OPT_F32_STREAM for f16 / bf16)
@@ -307,8 +326,6 @@ int blocks_fused(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipStream
     const int dt = c.compute_dtype, D = c.dim, M = n * m->tokens, G = D / 64;
     const size_t es = ap::dtype_size(dt);
     int rc;
-    { ScopedTimer t(m, AP_PROF_LAYERNORM, stream);
-      if ((rc = ap::launch_stream_init(dt, w.tok, M, D, c.ln_eps, w.x16, w.rowstats, stream)) != AP_OK) return rc; }
     const bool cls_tail = c.pool == AP_POOL_CLS && !m->full_last_block && D / c.heads == 64;
     auto finalize_stats = [&]() -> int {
         ScopedTimer t(m, AP_PROF_LAYERNORM, stream);
@@ -411,9 +428,10 @@ int run_blocks(ap_vit* m, int n, const Workspace& w, float* out, hipStream_t str
     const ap_vit_config& c = m->cfg;
     const int dt = c.compute_dtype, D = c.dim, M = n * m->tokens;
     int rc;
-    if ((rc = patch_embed(m, n, w, stream)) != AP_OK) return rc;
-    StreamTail st;
     const bool fused = dt != AP_F32 && !m->f32_stream;
+    // K of the patch-embed GEMM is kpe (3 ps^2 padded to 64): the persistent kernel wants K % 128 == 0, the 128 x 128 one K % 64
+    if ((rc = fused ? patch_embed_stream(m, n, w, stream) : patch_embed(m, n, w, stream)) != AP_OK) return rc;
+    StreamTail st;
     if ((rc = fused ? blocks_fused(m, n, w, st, stream) : blocks_f32_stream(m, n, w, st, stream)) != AP_OK) return rc;
     const void* pending = st.pending;
     const float* pending_ls = st.pending_ls;
@@ -649,6 +667,10 @@ int ap_vit_finalize(ap_vit* m) {
             if ((rc = ap::launch_fold_ln(dt, bp.fc1->dev32, H, D, bp.fc1->ld, bp.ln2_w, bp.ln2_b, bp.fc1_b, fb.fc1_w, fb.fc1_cs, fb.fc1_b, nullptr)) != AP_OK) break;
             if ((rc = ap::launch_fold_ls(dt, bp.proj->dev32, D, D, bp.proj->ld, bp.ls1, bp.proj_b, fb.proj_w, fb.proj_b, nullptr)) != AP_OK) break;
             if ((rc = ap::launch_fold_ls(dt, bp.fc2->dev32, D, H, bp.fc2->ld, bp.ls2, bp.fc2_b, fb.fc2_w, fb.fc2_b, nullptr)) != AP_OK) break;
+        }
+        if (rc == AP_OK) {
+            m->pos16 = dalloc((size_t)m->tokens * D * es);
+            if (rc == AP_OK) rc = ap::launch_convert(dt, m->pos, m->pos16, (size_t)m->tokens * D, nullptr);
         }
         if (rc != AP_OK) return rc;
         AP_HIP_CHECK(hipDeviceSynchronize());

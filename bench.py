@@ -499,10 +499,11 @@ def main():
     ln_blocks = 12 if full_last else 11          # the last block's LN2 runs on the CLS rows only (timed under cls_tail)
     ln_bytes = M * 768.0 * (ln_blocks * ((4 + eb + eb) + (4 + 2 * eb + 4 + eb)) + (0 if full_last else 4 + eb + eb) - eb)
     if fused:
-        # fused dataflow: no add+LayerNorm pass.  What is timed under "layernorm" is the stream initialisation (f32 token
-        # matrix in, T stream + row statistics out) and the 2 * blocks - 1 statistic finalisations ([M, 12, 2] f32 partial
-        # sums in, [M, 2] out); the stream itself moves inside the proj / fc2 epilogues (2 B read + 2 B written per element)
-        ln_bytes = M * (768.0 * (4 + eb) + 8) + (23 if full_last else 22) * M * (12 * 8 + 8.0)
+        # fused dataflow: no add+LayerNorm pass and no stream initialisation pass (the patch-embed GEMM writes the T stream and
+        # its partial sums).  What is timed under "layernorm" are the statistic finalisations -- one after the patch
+        # embedding, two per fused block minus the last ([M, 12, 2] f32 partial sums in, [M, 2] out) -- and the class-token
+        # rows; the stream itself moves inside the proj / fc2 epilogues (2 B read + 2 B written per element)
+        ln_bytes = (24 if full_last else 23) * M * (12 * 8 + 8.0) + B * 768.0 * (8 + eb)
     hbm_kernels = {}
     for kind, nbytes in (("preproc", pre_bytes), ("layernorm", ln_bytes)):
         ms = prof[kind][0] / K

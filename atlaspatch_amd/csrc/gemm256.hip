@@ -38,6 +38,11 @@
 //  * accumulators start from the bias; epilogue: (GELU | *LayerScale) in registers, transposed through the wave's private LDS
 //    scratch (XOR-swizzled) so that global stores / the f32 residual read-modify-write are whole
 //    128-byte rows, 16 B per lane.
+//  * fused-LayerNorm epilogues (EPI_NORM_STORE / EPI_NORM_GELU / EPI_RESID_STATS / EPI_PATCH_STREAM, see ap_common.h): the A operand
+//    is the raw 16-bit residual stream; NORM applies the row statistics and the rank-one mean correction per element
+//    (accumulators start from zero there), RESID_STATS / PATCH_STREAM add the accumulator to the stream window (or to the
+//    position-embedding row) after the transposition, 16 bytes per lane, and emit per-row partial sums for the next
+//    statistics.  Their operands are fetched with plain loads + __builtin_amdgcn_s_waitcnt before the epilogue body.
 //  * XCD-aware tile order: block b runs on XCD b % 8; each XCD owns a contiguous range of tile ids
 //    (n fastest), its 32 workgroups take consecutive ids, so concurrently running tiles share
 //    activation panels and weight panels in that XCD's L2.

@@ -227,7 +227,7 @@ def secondary_rates(device, ex, tiles, B):
     from atlaspatch_amd.utils.h5 import h5
     rates = {}
     # ---- (1) PCIe-inclusive: tiles in host memory -> pinned ring -> HBM -> forward -> features back on the host
-    n_host = 4 * B
+    n_host = min(8 * B, tiles.shape[0])           # 8 batches: the pipeline's fill (one gather + one H2D before the first forward) is 1/8 of the run
     host = tiles[:n_host].cpu().numpy()
     coords = np.stack([np.arange(n_host), np.zeros(n_host), np.full(n_host, 256), np.full(n_host, 256),
                        np.zeros(n_host)], 1).astype(np.int32)

@@ -280,6 +280,21 @@ def test_operator_error_paths(env):
                        stream) == -1
     assert lib.ap_attention(1, x.data_ptr(), x.data_ptr(), 1, 4, 1, 32, stream) == -1     # head_dim != 64
     assert b"head_dim" in lib.ap_last_error()
+    # fused-LayerNorm operators: missing operands, float32, bad kernel choice, shapes the persistent kernel cannot take
+    h = torch.zeros((256, 256), device=dev, dtype=torch.float16)
+    f = torch.zeros(4096, device=dev)
+    args = (h.data_ptr(), 256, h.data_ptr(), 256, 256, 256, 256, f.data_ptr())
+    assert lib.ap_gemm_fused(1, 4, *args, None, None, None, h.data_ptr(), 256, 0, stream) == -1          # NORM without statistics
+    assert lib.ap_gemm_fused(1, 6, *args, None, None, None, h.data_ptr(), 256, 0, stream) == -1          # RESID without partial
+    assert lib.ap_gemm_fused(0, 6, *args, None, None, f.data_ptr(), h.data_ptr(), 256, 0, stream) == -1  # float32
+    assert lib.ap_gemm_fused(1, 9, *args, None, None, f.data_ptr(), h.data_ptr(), 256, 0, stream) == -1  # unknown epilogue
+    assert lib.ap_gemm_fused(1, 6, *args, None, None, f.data_ptr(), h.data_ptr(), 256, 64, stream) == -1  # unknown impl
+    assert lib.ap_gemm_fused(1, 6, h.data_ptr(), 256, h.data_ptr(), 256, 256, 128, 256, f.data_ptr(), None, None, f.data_ptr(),
+                             h.data_ptr(), 256, 256, stream) == -1                                       # N = 128 on the 256 kernel
+    assert lib.ap_rowstats_finalize(f.data_ptr(), 4, 3, 192, 1e-6, f.data_ptr(), stream) == -1           # odd group count
+    assert lib.ap_sattention_f32(f.data_ptr(), 48, f.data_ptr(), 48, f.data_ptr(), 48, 1, 1, 4, 4, 48, 0.1, f.data_ptr(), 48,
+                                 stream) == -1                                                            # d = 48
+    assert b"sattention" in lib.ap_last_error()
 
 
 def test_tile_content_counts_bit_exact_vs_cv2_restatement(env):

@@ -533,3 +533,47 @@ def test_detect_tissue_command_writes_mask_overlays(tmp_path):
     res = CliRunner().invoke(cli, ["detect-tissue", str(tmp_path), "-o", str(out), "--seg-batch-size", "2"], catch_exceptions=False)
     assert res.exit_code == 0 and "Created 2 mask overlay(s), failures: 0" in res.output
     assert sorted(p.name for p in (out / "visualization").iterdir()) == ["a_mask.png", "a_mask_bw.png", "b_mask.png", "b_mask_bw.png"]
+
+def test_h5_file_equals_the_file_the_references_writer_makes_with_real_h5py(tmp_path, golden_dir):
+    """G5b: tests/golden/reference_real.h5 was written by the reference's own H5PatchWriter (write_coords + append_features,
+    unmodified) under the REAL h5py of the image's conda interpreter (gen_golden_h5_real.py).  The build's writer, given the
+    same inputs, must produce the same file: every dataset's values read back equal, and -- through the real h5py when
+    that interpreter is present (it is in this image, here and on the GPU box) -- the same names, dtypes, shapes, chunk
+    shapes, max shapes, fill values and attribute names / types / values."""
+    import json
+    import os
+    import subprocess
+    from atlaspatch_amd.services.storage import H5PatchWriter
+    from atlaspatch_amd.utils.h5 import h5
+    inp = np.load(os.path.join(golden_dir, "reference_real_h5_inputs.npz"))
+    coords, feats = inp["coords"], inp["feats"]
+    n = coords.shape[0]
+    out = tmp_path / "ours.h5"
+    w = H5PatchWriter(chunk_rows=8, patch_size=256, patch_size_level0=512, level0_mag=40, target_mag=20,
+                      level0_wh=(100000, 90000), overlap=0, slide_stem="slide_A", wsi_path="/data/slide_A.svs",
+                      total_patches=None, extra_file_attrs={"mpp": 0.2528})
+    entries = [tuple(int(v) for v in row) + (None,) for row in coords]
+    total, _ = w.write_coords(out, entries, batch=10)
+    assert total == n
+    patches = [np.full((2, 2, 3), i, dtype=np.uint8) for i in range(n)]
+    wrote = w.append_features(output_path=out, entries=[e[:5] + (p,) for e, p in zip(entries, patches)], feature_name="tiny12",
+                              feature_fn=lambda batch: feats[[int(p[0, 0, 0]) for p in batch]],
+                              feature_attrs={"embedding_dim": 12, "source": "unit"}, feature_batch=7, expected_total=n)
+    assert wrote == n
+    ref_path = os.path.join(golden_dir, "reference_real.h5")
+    with h5.File(ref_path, "r") as fr, h5.File(str(out), "r") as fo:
+        assert sorted(fr.keys()) == sorted(fo.keys()) == ["coords", "features", "passports"]
+        assert np.array_equal(fr["coords"][:], fo["coords"][:]) and np.array_equal(fo["coords"][:], coords)
+        assert np.array_equal(fr["passports"][:], fo["passports"][:])
+        assert np.array_equal(fr["features"]["tiny12"][:], fo["features"]["tiny12"][:])
+        assert fo["features"]["tiny12"].dtype == np.float32 and fo["passports"].dtype == np.dtype("S160")
+    conda_py = "/opt/conda/bin/python3.9"
+    if not os.path.exists(conda_py):
+        pytest.skip("no interpreter with the real h5py here: values compared, structural dump skipped")
+    got = json.loads(subprocess.run([conda_py, os.path.join(golden_dir, "describe_h5_real.py"), str(out)], check=True,
+                                    capture_output=True, text=True).stdout)
+    with open(os.path.join(golden_dir, "reference_real_h5.json")) as fh:
+        want = json.load(fh)
+    got["file_attrs"].pop("creation_date", None)
+    assert got["datasets"] == want["datasets"]
+    assert got["file_attrs"] == want["file_attrs"]

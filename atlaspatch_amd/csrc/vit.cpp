@@ -63,6 +63,7 @@ struct ap_vit {
     std::vector<ap::FusedBlock> fused;      // filled by ap_vit_finalize for f16 / bf16
     std::vector<void*> fused_allocs;
     void* pos16 = nullptr;                  // position embedding in the compute type (fused patch embedding), in fused_allocs
+    bool fold_dirty = false;                // a parameter the folded weights depend on was set after the last finalize
     int device = 0;
     // optional per-launch HIP-event timing (ap_vit_profile_*): kind -> events of the last forwards
     bool profile = false;
@@ -595,6 +596,12 @@ int ap_vit_set_param(ap_vit* m, const char* name, const float* host, size_t coun
         else AP_HIP_CHECK(hipFree(tmp));
     }
     p.set = true;
+    if (m->finalized && m->cfg.compute_dtype != AP_F32 &&
+        (strncmp(name, "blocks.", 7) == 0 || strcmp(name, "pos_embed") == 0)) {
+        // the folded weights / the T copy of the position embedding are stale now: a forward needs a new ap_vit_finalize
+        m->fold_dirty = true;
+        m->finalized = false;
+    }
     return AP_OK;
 }
 
@@ -635,7 +642,7 @@ int ap_vit_finalize(ap_vit* m) {
     // ---- fused-LayerNorm weights (f16 / bf16): folded once from the f32 uploads, which are released afterwards
     bool any32 = false;
     for (auto& kv : m->params) any32 = any32 || kv.second.dev32 != nullptr;
-    if (m->cfg.compute_dtype != AP_F32 && !any32 && !m->fused.empty()) {
+    if (m->cfg.compute_dtype != AP_F32 && !any32 && !m->fused.empty() && !m->fold_dirty) {
         m->finalized = true;           // finalize called again without new uploads: the folded weights stand
         return AP_OK;
     }
@@ -657,7 +664,7 @@ int ap_vit_finalize(ap_vit* m) {
             const ap::BlockParams& bp = m->blocks[i];
             ap::FusedBlock& fb = m->fused[i];
             for (const Param* p : {bp.qkv, bp.proj, bp.fc1, bp.fc2})
-                if (!p->dev32) { ap::set_error("vit_finalize: block %d: after a finalize, changing one block parameter needs all four block matrices uploaded again", i); return AP_ERR_STATE; }
+                if (!p->dev32) { ap::set_error("vit_finalize: block %d: a block parameter (or pos_embed) changed after a finalize -- the LayerNorm / LayerScale folding needs the float32 values of all four matrices of every block again: upload qkv / proj / fc1 / fc2 weights before finalizing", i); return AP_ERR_STATE; }
             fb.qkv_w = dalloc((size_t)3 * D * bp.qkv->ld * es); fb.qkv_cs = (float*)dalloc(3 * D * 4); fb.qkv_b = (float*)dalloc(3 * D * 4);
             fb.fc1_w = dalloc((size_t)H * bp.fc1->ld * es); fb.fc1_cs = (float*)dalloc(H * 4); fb.fc1_b = (float*)dalloc(H * 4);
             fb.proj_w = dalloc((size_t)D * bp.proj->ld * es); fb.proj_b = (float*)dalloc(D * 4);
@@ -677,6 +684,7 @@ int ap_vit_finalize(ap_vit* m) {
         for (auto& kv : m->params)
             if (kv.second.dev32) { (void)hipFree(kv.second.dev32); kv.second.dev32 = nullptr; }
     }
+    m->fold_dirty = false;
     m->finalized = true;
     return AP_OK;
 }

@@ -176,7 +176,12 @@ void ap_vit_destroy(ap_vit* m);
  *   attn_pool.out.weight [P, P] | .bias [P]   attn_pool.ln_out.weight|bias [P]
  * Synchronous (copies before returning). */
 int ap_vit_set_param(ap_vit* m, const char* name, const float* host, size_t count);
-int ap_vit_finalize(ap_vit* m);   /* checks every parameter was set */
+/* Checks every parameter was set and, for f16 / bf16, builds the derived weights of the fused-LayerNorm dataflow from the
+ * float32 uploads (LayerNorm gain / LayerScale folded into the block matrices, column sums, folded biases, a T copy of
+ * pos_embed); the float32 copies are released afterwards.  Setting a blocks.* parameter or pos_embed later un-finalises the
+ * object: forwards return AP_ERR_STATE until ap_vit_finalize succeeds again, which needs the qkv / proj / fc1 / fc2
+ * matrices of every block uploaded again (AP_ERR_STATE otherwise) -- stale folded weights can never run. */
+int ap_vit_finalize(ap_vit* m);
 
 /* Options (defaults: off; the environment variables AP_VIT_FULL_LAST_BLOCK / AP_VIT_OVERLAP set the defaults once, when
  * the object is created -- nothing on the launch path reads the environment):

@@ -197,6 +197,43 @@ def test_fused_dataflow_with_large_row_means_and_massive_channels(dtype):
     _check(got_f32s, want, dtype, "massive activations, f32_stream", tol=TOL_F32S)
 
 
+def test_parameter_updates_after_finalize_cannot_leave_stale_folded_weights():
+    """The fused-LayerNorm path folds the LayerNorm gains (and LayerScale, and a T copy of pos_embed) into derived weights at
+    ap_vit_finalize.  Setting one of their inputs afterwards must not be able to run on stale folded weights: the forward
+    refuses until finalize is called again, finalize refuses until the four matrices of every block are uploaded again,
+    and after that the features equal those of a freshly built encoder with the changed parameter, bit for bit."""
+    import ctypes as C
+    from atlaspatch_amd import _lib
+    from atlaspatch_amd.encoders.vit import ARCHS, build_hip_vit_extractor, random_canonical_state_dict
+    arch = dict(ARCHS["vit_b_16"]); arch["depth"] = 2
+    sd = random_canonical_state_dict(arch, seed=12)
+    ex = build_hip_vit_extractor(name="t", arch=arch, state_dict=sd, source="canonical", device=_dev(), dtype=torch.float16,
+                                 expect_size=256)
+    rng = np.random.default_rng(8)
+    tiles = [rng.integers(0, 256, (256, 256, 3), dtype=np.uint8) for _ in range(3)]
+    before = ex.extract_batch(tiles)
+    lib, h = ex.vit.lib, ex.vit._handle
+    new_g = (sd["blocks.0.ln1.weight"] * 1.5 + 0.1).contiguous()
+    arr = new_g.numpy()
+    assert lib.ap_vit_set_param(h, b"blocks.0.ln1.weight", arr.ctypes.data_as(C.c_void_p), arr.size) == 0
+    with pytest.raises(_lib.HipLibraryError, match="finalize"):
+        ex.extract_batch(tiles)                                            # not finalised any more
+    assert lib.ap_vit_finalize(h) == -5 and b"upload" in lib.ap_last_error()   # AP_ERR_STATE: matrices needed again
+    for name, t in sd.items():
+        if name.startswith("blocks.") and name.endswith((".qkv.weight", ".proj.weight", ".fc1.weight", ".fc2.weight")):
+            a = np.ascontiguousarray(t.numpy())
+            assert lib.ap_vit_set_param(h, name.encode(), a.ctypes.data_as(C.c_void_p), a.size) == 0
+    assert lib.ap_vit_finalize(h) == 0
+    after = ex.extract_batch(tiles)
+    ex.cleanup()
+    sd2 = dict(sd); sd2["blocks.0.ln1.weight"] = new_g
+    ex2 = build_hip_vit_extractor(name="t2", arch=arch, state_dict=sd2, source="canonical", device=_dev(), dtype=torch.float16,
+                                  expect_size=256)
+    fresh = ex2.extract_batch(tiles)
+    ex2.cleanup()
+    assert np.array_equal(after, fresh) and not np.array_equal(after, before)
+
+
 # ----------------------------------------------------------------------------- BASELINE configs 3 / 5 at their real depth
 def _pil_resized(tiles, size, filt):
     from PIL import Image

@@ -26,6 +26,7 @@
 // Roofline: MFMA (4 * T * T * 64 flop per head; padded to 32-query x 64-key tiles);
 // HBM traffic = q, k, v read once + o written once.
 #include "ap_common.h"
+#include <cstdlib>
 
 namespace ap {
 namespace {
@@ -65,11 +66,12 @@ __device__ __forceinline__ void dma16(const char* base, uint32_t off, uint32_t l
         : "memory");
 }
 
-__device__ __forceinline__ u32x2 tr_read(uint32_t lds_addr) {
+template <int OFF> __device__ __forceinline__ u32x2 tr_read(uint32_t lds_addr) {       // immediate offset: no address VALU
     u32x2 v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_addr) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF) : "memory");
     return v;
 }
+template <int V> struct IntC { static constexpr int value = V; };
 
 // v_permlane32_swap exchanges the upper half of its first operand with the lower half of its second:
 // fed two copies of v it leaves {v.lo, v.lo} and {v.hi, v.hi}.  Inline asm on two distinct registers
@@ -92,16 +94,29 @@ __device__ __forceinline__ float half_swap_sum(float v) {
     return lo + hi;
 }
 
-template <typename T>
+// V2 = true: tile j + 3 is staged AFTER the barrier that opens iteration j (its buffer was last read in iteration
+// j - 1, which every wave has left by then), so one barrier per tile is enough; the output block goes through
+// LDS and leaves as whole 128-byte rows (16 B per lane) instead of 8-byte pieces at a row stride.
+template <typename T, bool V2>
 __global__ __launch_bounds__(kNW * 64, 4)
-void attention_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int tokens, int heads) {
+void attention_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int tokens, int heads, int parts, int units) {
     __shared__ __attribute__((aligned(16))) char smem[kNB * 2 * kTileBytes];     // [buf][K | V]
     using Frag = typename FMma<T>::Frag;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5, l31 = lane & 31;
-    const int img = blockIdx.x / heads, head = blockIdx.x - img * heads;
+    // V2, XCD-aware walk: workgroup b runs on XCD b % 8 (each XCD has its own L2), so the `parts` workgroups that
+    // share one (image, head) -- every one of them streams the head's whole K and V -- take consecutive slots of
+    // ONE XCD: they run side by side and K / V come from HBM once instead of `parts` times (785 tokens: 4 parts)
+    int unit = blockIdx.x, part = blockIdx.y;
+    if (V2) {
+        const int slot = blockIdx.x >> 3;
+        unit = (slot / parts) * 8 + (blockIdx.x & 7);
+        part = slot % parts;
+        if (unit >= units) return;
+    }
+    const int img = unit / heads, head = unit - img * heads;
     const int dim = heads * kHD;
     const uint32_t ldb = (uint32_t)(3 * dim) * 2;                         // row stride in bytes
     const char* base = (const char*)(qkv + (size_t)img * tokens * 3 * dim + head * kHD);
@@ -127,7 +142,11 @@ void attention_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int 
         if (j < nkv) stage(j);
 
     // ---- this wave's queries
-    const int qb = blockIdx.y * kNW + wave;
+    // V2: the 32-query blocks are dealt evenly to the parts (25 blocks -> 7, 6, 6, 6 instead of 8, 8, 8, 1)
+    const int nqb_all = (tokens + 31) / 32;
+    const int qcount = V2 ? nqb_all / parts + (part < nqb_all % parts) : kNW;
+    const int qb = V2 ? part * (nqb_all / parts) + (part < nqb_all % parts ? part : nqb_all % parts) + wave
+                      : part * kNW + wave;
     int qrow = qb * 32 + l31;
     const bool qvalid = qrow < tokens;
     if (!qvalid) qrow = tokens - 1;
@@ -164,7 +183,7 @@ void attention_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int 
 #pragma unroll
         for (int e = 0; e < 16; ++e) ot[it][e] = 0.f;
 
-    const bool active = qb * 32 < tokens;
+    const bool active = qb * 32 < tokens && wave < qcount;
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // Deferred rescale (log2 domain): the running max is only raised, and O / l only rescaled, when some
     // row of the wave grew by more than kDefer; otherwise P is taken against the old max and is bounded
@@ -215,56 +234,96 @@ void attention_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int 
                     for (int e = 0; e < 16; ++e) ot[it][e] *= alpha;
             }
         }
-        const float mb = m_run * c;
-        float psum = 0.f;
+        // exponent arguments and row sums two scores per instruction (v_pk_fma_f32 / v_pk_add_f32): the kernel is
+        // bound by the number of instructions its waves issue, not by any one pipe
+        const f32x2_t c2 = {c, c}, nmb2 = {-m_run * c, -m_run * c};
+        f32x2_t ps2 = {0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             if (kb == 1 && !full) break;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][r], c, -mb));    // one VALU op (the build uses -ffp-contract=off)
-                st[kb][r] = p;
-                psum += p;
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2_t a = __builtin_elementwise_fma(f32x2_t{st[kb][r], st[kb][r + 1]}, c2, nmb2);
+                const f32x2_t p = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+                ps2 += p;
+                st[kb][r] = p[0];
+                st[kb][r + 1] = p[1];
             }
         }
-        l_run += psum;
+        l_run += ps2[0] + ps2[1];
 
         // ---------------- O^T += V^T P^T
-#pragma unroll
-        for (int sp = 0; sp < 4; ++sp) {                                  // 16-key steps
-            if (sp >= 2 && !full) break;
+        const uint32_t v0 = bufa + va[0], v1 = bufa + va[1];
+        auto pv_step = [&](auto SP) {                                     // one 16-key step
+            constexpr int sp = decltype(SP)::value;
             Frag pf;
 #pragma unroll
             for (int e = 0; e < 8; ++e) pf[e] = (T)st[sp >> 1][(sp & 1) * 8 + e];
-            u32x2 v0a = tr_read(bufa + va[0] + sp * 16 * 128), v0b = tr_read(bufa + va[0] + sp * 16 * 128 + 8 * 128);
-            u32x2 v1a = tr_read(bufa + va[1] + sp * 16 * 128), v1b = tr_read(bufa + va[1] + sp * 16 * 128 + 8 * 128);
+            u32x2 v0a = tr_read<sp * 16 * 128>(v0), v0b = tr_read<sp * 16 * 128 + 8 * 128>(v0);
+            u32x2 v1a = tr_read<sp * 16 * 128>(v1), v1b = tr_read<sp * 16 * 128 + 8 * 128>(v1);
             // the loads' destinations count as written only from here on (hipcc does not track asm loads)
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v0a), "+v"(v0b), "+v"(v1a), "+v"(v1b) :: "memory");
             const u32x4 f0 = {v0a[0], v0a[1], v0b[0], v0b[1]}, f1 = {v1a[0], v1a[1], v1b[0], v1b[1]};
             ot[0] = FMma<T>::run(__builtin_bit_cast(Frag, f0), pf, ot[0]);
             ot[1] = FMma<T>::run(__builtin_bit_cast(Frag, f1), pf, ot[1]);
+        };
+        pv_step(IntC<0>{});
+        pv_step(IntC<1>{});
+        if (full) {
+            pv_step(IntC<2>{});
+            pv_step(IntC<3>{});
         }
     };
 
     for (int j = 0; j < nkv; ++j) {
-        if (j + kNB - 1 < nkv) stage(j + kNB - 1);
+        if (!V2 && j + kNB - 1 < nkv) stage(j + kNB - 1);
         // tile j has landed when at most the 2 loads of each younger staged tile are still in flight
-        const int ahead = nkv - 1 - j < kNB - 1 ? nkv - 1 - j : kNB - 1;
+        const int young = V2 ? kNB - 2 : kNB - 1;
+        const int ahead = nkv - 1 - j < young ? nkv - 1 - j : young;
         if (ahead >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else if (ahead == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else if (ahead == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        if (V2 && j + kNB - 1 < nkv) stage(j + kNB - 1);
         const char* buf = smem + (j % kNB) * 2 * kTileBytes;
         const uint32_t bufa = lds_base + (j % kNB) * 2 * kTileBytes;
 
         // A wave without queries (8th wave at T = 197) only stages and keeps the barriers; a tile whose
         // second 32-key block lies wholly past the end (keys 224..255 at T = 197) runs as a half tile.
         if (active) tile(buf, bufa, j, j * kKV + 32 < tokens);
-        __builtin_amdgcn_s_barrier();            // every wave is done with this buffer before it is restaged
+        if (!V2) __builtin_amdgcn_s_barrier();   // every wave is done with this buffer before it is restaged
     }
 
     const float inv = 1.0f / half_swap_sum(l_run);
+    if (V2) {
+        if (!active) return;
+        // buffer nkv % kNB is free (every wave has left iteration nkv - 2, nothing is staged any more); wave w
+        // owns 4 KiB of it: row = query, 16-byte chunk c at (c ^ (row & 7)) * 16
+        char* stg = smem + (nkv % kNB) * 2 * kTileBytes + wave * 4096;
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const T a = (T)(ot[it][g4 * 4 + 0] * inv), b = (T)(ot[it][g4 * 4 + 1] * inv);
+                const T cc = (T)(ot[it][g4 * 4 + 2] * inv), d = (T)(ot[it][g4 * 4 + 3] * inv);
+                u32x2 o;
+                o[0] = (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
+                o[1] = (uint32_t)__builtin_bit_cast(uint16_t, cc) | ((uint32_t)__builtin_bit_cast(uint16_t, d) << 16);
+                *(u32x2*)(stg + l31 * 128 + (((it * 4 + g4) ^ (l31 & 7)) << 4) + hi * 8) = o;
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (lane >> 3) + 8 * i, ch = lane & 7;
+            const u32x4 v = *(const u32x4*)(stg + row * 128 + ((ch ^ (row & 7)) << 4));
+            const int q = qb * 32 + row;
+            if (q < tokens) *(u32x4*)(out + ((size_t)img * tokens + q) * dim + head * kHD + ch * 8) = v;
+        }
+        return;
+    }
     if (qvalid && active) {
         T* op = out + ((size_t)img * tokens + qrow) * dim + head * kHD;
 #pragma unroll
@@ -294,9 +353,17 @@ int launch_attention_flash(int dtype, const void* qkv, void* out, int n, int tok
     AP_REQUIRE((size_t)tokens * 3 * heads * kHD * 2 < 0xffffffffull, "attention_flash: sequence too long");
     if (n <= 0) return AP_OK;
     const int nqb = (tokens + 31) / 32;
-    dim3 grid(n * heads, (nqb + kNW - 1) / kNW), block(kNW * 64);
-    if (dtype == AP_F16) attention_flash_kernel<f16><<<grid, block, 0, stream>>>((const f16*)qkv, (f16*)out, tokens, heads);
-    else attention_flash_kernel<bf16><<<grid, block, 0, stream>>>((const bf16*)qkv, (bf16*)out, tokens, heads);
+    const int parts = (nqb + kNW - 1) / kNW, units = n * heads;
+    dim3 grid(units, parts), block(kNW * 64);
+    dim3 grid2((unsigned)((units + 7) / 8 * 8 * parts));
+    static const bool v1 = [] { const char* e = getenv("AP_ATTN_IMPL"); return e && e[0] == '1'; }();
+    if (v1) {
+        if (dtype == AP_F16) attention_flash_kernel<f16, false><<<grid, block, 0, stream>>>((const f16*)qkv, (f16*)out, tokens, heads, parts, units);
+        else attention_flash_kernel<bf16, false><<<grid, block, 0, stream>>>((const bf16*)qkv, (bf16*)out, tokens, heads, parts, units);
+    } else {
+        if (dtype == AP_F16) attention_flash_kernel<f16, true><<<grid2, block, 0, stream>>>((const f16*)qkv, (f16*)out, tokens, heads, parts, units);
+        else attention_flash_kernel<bf16, true><<<grid2, block, 0, stream>>>((const bf16*)qkv, (bf16*)out, tokens, heads, parts, units);
+    }
     AP_HIP_CHECK(hipGetLastError());
     return AP_OK;
 }

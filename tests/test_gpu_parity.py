@@ -95,7 +95,11 @@ def _hf_extractor(layers, dtype, **kw):
 #   float16 / bfloat16 with option f32_stream (float32 residual stream + standalone add+LayerNorm launches):
 #             norm-wise 0.87e-3 at depth 12, 0.93e-3 at depth 24 (TOL_F32S)
 TOL = {torch.float32: 1e-3, torch.float16: 2.5e-3, torch.bfloat16: 2e-2}
-ETOL = {torch.float32: 1e-3, torch.float16: 3e-2, torch.bfloat16: 2.5e-1}
+ETOL = {torch.float32: 1e-3, torch.float16: 5e-2, torch.bfloat16: 2.5e-1}
+# the element-wise MAXIMUM is heavy tailed (one element of 25 000: 1.6e-2 .. 3.1e-2 across encoders and across two
+# equally accurate builds of the attention row sums), so it gets a loose bound and the 99.9th percentile of the same
+# statistic (measured: f16 <= 1.6e-2, bf16 <= 5.8e-2) carries the tight one
+ETOL_Q = {torch.float32: 1e-3, torch.float16: 2.5e-2, torch.bfloat16: 1e-1}
 TOL_F32S = {torch.float16: 1.5e-3, torch.bfloat16: 1.2e-2}
 
 
@@ -104,10 +108,15 @@ def _elem(a, b, floor=0.05):
     return float((np.abs(a - b) / (np.abs(b) + floor * np.abs(b).max())).max())
 
 
+def _elem_q(a, b, q=0.999, floor=0.05):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.quantile(np.abs(a - b) / (np.abs(b) + floor * np.abs(b).max()), q))
+
+
 def _check(got, want, dtype, what="", tol=None):
-    r, e = _rel(got, want), _elem(got, want)
-    print(f"PARITY {what} {str(dtype).split('.')[-1]}: norm-wise {r:.3e} element-wise {e:.3e}")
-    assert r <= (tol or TOL)[dtype] and e <= ETOL[dtype], (what, dtype, r, e)
+    r, e, eq = _rel(got, want), _elem(got, want), _elem_q(got, want)
+    print(f"PARITY {what} {str(dtype).split('.')[-1]}: norm-wise {r:.3e} element-wise max {e:.3e} q99.9 {eq:.3e}")
+    assert r <= (tol or TOL)[dtype] and e <= ETOL[dtype] and eq <= ETOL_Q[dtype], (what, dtype, r, e, eq)
     return r
 
 

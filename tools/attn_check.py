@@ -31,19 +31,19 @@ for dt, tol in ((torch.float16, 4e-3), (torch.bfloat16, 3e-2)):
         torch.cuda.synchronize()
         err = (out.float() - ref(qkv, n, T, H)).abs().max().item()
         print(f"{'ok  ' if err <= tol else 'FAIL'} {str(dt)[6:]:9s} spike n={n} T={T} H={H} max_abs_err={err:.3e}", flush=True)
-n, T, H = 1024, 197, 12
-qkv = (torch.randn((n * T, 3 * H * 64), device=dev, generator=g)).half()
-out = torch.empty((n * T, H * 64), device=dev, dtype=torch.float16)
-for _ in range(3):
-    lib.ap_attention(1, qkv.data_ptr(), out.data_ptr(), n, T, H, 64, stream)
-torch.cuda.synchronize()
-ts = []
-for r in range(5):
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(5):
+for (n, T, H) in ((1024, 197, 12), (256, 785, 12), (512, 197, 16)):
+    qkv = (torch.randn((n * T, 3 * H * 64), device=dev, generator=g)).half()
+    out = torch.empty((n * T, H * 64), device=dev, dtype=torch.float16)
+    for _ in range(3):
         lib.ap_attention(1, qkv.data_ptr(), out.data_ptr(), n, T, H, 64, stream)
-    e1.record(); torch.cuda.synchronize()
-    ts.append(e0.elapsed_time(e1) / 5)
-ms = sorted(ts)[2]
-print(f"AP_ATTN_IMPL={os.environ.get('AP_ATTN_IMPL', 'auto')}: f16 n=1024 T=197 H=12: {ms:.4f} ms  ({4 * T * T * 64 * H * n / ms / 1e9:.1f} TF/s, {4 * n * T * H * 64 * 2 / ms / 1e6:.0f} GB/s)")
+    torch.cuda.synchronize()
+    ts = []
+    for r in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            lib.ap_attention(1, qkv.data_ptr(), out.data_ptr(), n, T, H, 64, stream)
+        e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / 5)
+    ms = sorted(ts)[2]
+    print(f"AP_ATTN_IMPL={os.environ.get('AP_ATTN_IMPL', 'auto')}: f16 n={n} T={T} H={H}: {ms:.4f} ms  ({4 * T * T * 64 * H * n / ms / 1e9:.1f} TF/s, {4 * n * T * H * 64 * 2 / ms / 1e6:.0f} GB/s)")

@@ -26,7 +26,6 @@
 // Roofline: MFMA (4 * T * T * 64 flop per head; padded to 32-query x 64-key tiles);
 // HBM traffic = q, k, v read once + o written once.
 #include "ap_common.h"
-#include <cstdlib>
 
 namespace ap {
 namespace {
@@ -94,10 +93,7 @@ __device__ __forceinline__ float half_swap_sum(float v) {
     return lo + hi;
 }
 
-// V2 = true: tile j + 3 is staged AFTER the barrier that opens iteration j (its buffer was last read in iteration
-// j - 1, which every wave has left by then), so one barrier per tile is enough; the output block goes through
-// LDS and leaves as whole 128-byte rows (16 B per lane) instead of 8-byte pieces at a row stride.
-template <typename T, bool V2>
+template <typename T>
 __global__ __launch_bounds__(kNW * 64, 4)
 void attention_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int tokens, int heads, int parts, int units) {
     __shared__ __attribute__((aligned(16))) char smem[kNB * 2 * kTileBytes];     // [buf][K | V]
@@ -106,16 +102,12 @@ void attention_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5, l31 = lane & 31;
-    // V2, XCD-aware walk: workgroup b runs on XCD b % 8 (each XCD has its own L2), so the `parts` workgroups that
+    // XCD-aware walk: workgroup b runs on XCD b % 8 (each XCD has its own L2), so the `parts` workgroups that
     // share one (image, head) -- every one of them streams the head's whole K and V -- take consecutive slots of
     // ONE XCD: they run side by side and K / V come from HBM once instead of `parts` times (785 tokens: 4 parts)
-    int unit = blockIdx.x, part = blockIdx.y;
-    if (V2) {
-        const int slot = blockIdx.x >> 3;
-        unit = (slot / parts) * 8 + (blockIdx.x & 7);
-        part = slot % parts;
-        if (unit >= units) return;
-    }
+    const int slot = blockIdx.x >> 3;
+    const int unit = (slot / parts) * 8 + (blockIdx.x & 7), part = slot % parts;
+    if (unit >= units) return;
     const int img = unit / heads, head = unit - img * heads;
     const int dim = heads * kHD;
     const uint32_t ldb = (uint32_t)(3 * dim) * 2;                         // row stride in bytes
@@ -142,11 +134,10 @@ void attention_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int 
         if (j < nkv) stage(j);
 
     // ---- this wave's queries
-    // V2: the 32-query blocks are dealt evenly to the parts (25 blocks -> 7, 6, 6, 6 instead of 8, 8, 8, 1)
+    // the 32-query blocks are dealt evenly to the parts (25 blocks -> 7, 6, 6, 6 instead of 8, 8, 8, 1)
     const int nqb_all = (tokens + 31) / 32;
-    const int qcount = V2 ? nqb_all / parts + (part < nqb_all % parts) : kNW;
-    const int qb = V2 ? part * (nqb_all / parts) + (part < nqb_all % parts ? part : nqb_all % parts) + wave
-                      : part * kNW + wave;
+    const int qcount = nqb_all / parts + (part < nqb_all % parts);
+    const int qb = part * (nqb_all / parts) + (part < nqb_all % parts ? part : nqb_all % parts) + wave;
     int qrow = qb * 32 + l31;
     const bool qvalid = qrow < tokens;
     if (!qvalid) qrow = tokens - 1;
@@ -276,27 +267,24 @@ void attention_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int 
     };
 
     for (int j = 0; j < nkv; ++j) {
-        if (!V2 && j + kNB - 1 < nkv) stage(j + kNB - 1);
-        // tile j has landed when at most the 2 loads of each younger staged tile are still in flight
-        const int young = V2 ? kNB - 2 : kNB - 1;
-        const int ahead = nkv - 1 - j < young ? nkv - 1 - j : young;
-        if (ahead >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else if (ahead == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        // tile j has landed when at most the 2 loads of each younger staged tile (j + 1, j + 2) are still in flight
+        const int ahead = nkv - 1 - j < kNB - 2 ? nkv - 1 - j : kNB - 2;
+        if (ahead == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else if (ahead == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (V2 && j + kNB - 1 < nkv) stage(j + kNB - 1);
+        // ONE barrier per tile: tile j + 3 goes into the buffer of tile j - 1, which every wave has left by now
+        if (j + kNB - 1 < nkv) stage(j + kNB - 1);
         const char* buf = smem + (j % kNB) * 2 * kTileBytes;
         const uint32_t bufa = lds_base + (j % kNB) * 2 * kTileBytes;
 
         // A wave without queries (8th wave at T = 197) only stages and keeps the barriers; a tile whose
         // second 32-key block lies wholly past the end (keys 224..255 at T = 197) runs as a half tile.
         if (active) tile(buf, bufa, j, j * kKV + 32 < tokens);
-        if (!V2) __builtin_amdgcn_s_barrier();   // every wave is done with this buffer before it is restaged
     }
 
     const float inv = 1.0f / half_swap_sum(l_run);
-    if (V2) {
+    {
         if (!active) return;
         // buffer nkv % kNB is free (every wave has left iteration nkv - 2, nothing is staged any more); wave w
         // owns 4 KiB of it: row = query, 16-byte chunk c at (c ^ (row & 7)) * 16
@@ -322,26 +310,6 @@ void attention_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int 
             const int q = qb * 32 + row;
             if (q < tokens) *(u32x4*)(out + ((size_t)img * tokens + q) * dim + head * kHD + ch * 8) = v;
         }
-        return;
-    }
-    if (qvalid && active) {
-        T* op = out + ((size_t)img * tokens + qrow) * dim + head * kHD;
-#pragma unroll
-        for (int it = 0; it < 2; ++it)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                T* dst = op + it * 32 + g4 * 8 + hi * 4;
-                if constexpr (sizeof(T) == 2) {
-                    u32x2 o;
-                    {
-                        const T a = (T)(ot[it][g4 * 4 + 0] * inv), b = (T)(ot[it][g4 * 4 + 1] * inv);
-                        const T cc = (T)(ot[it][g4 * 4 + 2] * inv), d = (T)(ot[it][g4 * 4 + 3] * inv);
-                        o[0] = (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
-                        o[1] = (uint32_t)__builtin_bit_cast(uint16_t, cc) | ((uint32_t)__builtin_bit_cast(uint16_t, d) << 16);
-                    }
-                    *(u32x2*)dst = o;
-                }
-            }
     }
 }
 
@@ -354,16 +322,9 @@ int launch_attention_flash(int dtype, const void* qkv, void* out, int n, int tok
     if (n <= 0) return AP_OK;
     const int nqb = (tokens + 31) / 32;
     const int parts = (nqb + kNW - 1) / kNW, units = n * heads;
-    dim3 grid(units, parts), block(kNW * 64);
-    dim3 grid2((unsigned)((units + 7) / 8 * 8 * parts));
-    static const bool v1 = [] { const char* e = getenv("AP_ATTN_IMPL"); return e && e[0] == '1'; }();
-    if (v1) {
-        if (dtype == AP_F16) attention_flash_kernel<f16, false><<<grid, block, 0, stream>>>((const f16*)qkv, (f16*)out, tokens, heads, parts, units);
-        else attention_flash_kernel<bf16, false><<<grid, block, 0, stream>>>((const bf16*)qkv, (bf16*)out, tokens, heads, parts, units);
-    } else {
-        if (dtype == AP_F16) attention_flash_kernel<f16, true><<<grid2, block, 0, stream>>>((const f16*)qkv, (f16*)out, tokens, heads, parts, units);
-        else attention_flash_kernel<bf16, true><<<grid2, block, 0, stream>>>((const bf16*)qkv, (bf16*)out, tokens, heads, parts, units);
-    }
+    dim3 grid((unsigned)((units + 7) / 8 * 8 * parts)), block(kNW * 64);
+    if (dtype == AP_F16) attention_flash_kernel<f16><<<grid, block, 0, stream>>>((const f16*)qkv, (f16*)out, tokens, heads, parts, units);
+    else attention_flash_kernel<bf16><<<grid, block, 0, stream>>>((const bf16*)qkv, (bf16*)out, tokens, heads, parts, units);
     AP_HIP_CHECK(hipGetLastError());
     return AP_OK;
 }

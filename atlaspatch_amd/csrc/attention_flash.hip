@@ -20,8 +20,15 @@
 //     fall on four different 64-byte bank groups.
 // Online softmax per tile: m' = max(m, rowmax), O *= 2^((m - m') c), l = l * 2^((m - m') c) + rowsum
 // with c = log2(e) / 8 folded into the exponent; the rescale is deferred while no row of the wave grew
-// by more than 2^8 (the kernel is VALU-bound: 32 exp + ~200 other VALU per wave and tile against 16 MFMAs).  Keys past the end are staged from the last valid
-// row (finite data) and masked to -inf.
+// by more than 2^8.  Keys past the end are staged from the last valid row (finite data) and masked to -inf.
+// One workgroup barrier per key tile: tile j + 3 is staged right BEHIND the barrier that opens iteration j (its
+// buffer held tile j - 1, which every wave has left by then).  The output block is transposed through the
+// wave's 4 KiB of a free ring buffer and leaves as whole 128-byte rows (16 B per lane).  Workgroups that share a
+// head (more than 256 queries) are placed on one XCD so that its L2 serves their common K / V stream.
+//
+// What paces it (PMC + ablations): at head_dim 64 a wave issues ~170 VALU slots (33 v_exp at
+// ~5/3, 32 fma, 32 add, 16 cvt_pk, 24 max; packed f32 forms take two slots, so they save nothing) beside 16 MFMAs
+// of 8 slots each, and on one SIMD these slots add up rather than overlap: ~300 slots per 32 x 64 score block.
 //
 // Roofline: MFMA (4 * T * T * 64 flop per head; padded to 32-query x 64-key tiles);
 // HBM traffic = q, k, v read once + o written once.

@@ -363,13 +363,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product has no CPU fallback")
-    device = torch.device("cuda", local_rank)
+    # AP_BENCH_BACKEND=gloo + AP_BENCH_ONE_GPU=1: rehearsal of the N > 1 path on a one-GPU box (every rank on cuda:0,
+    # collectives through gloo); the line it prints is marked and is not a measurement
+    rehearsal = os.environ.get("AP_BENCH_BACKEND", "nccl") != "nccl"
+    device = torch.device("cuda", 0 if os.environ.get("AP_BENCH_ONE_GPU") else local_rank)
     torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group(backend=os.environ["AP_BENCH_BACKEND"])
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)
 
     from atlaspatch_amd.encoders.vit import build_hip_vit_extractor
 
@@ -514,7 +520,8 @@ def main():
     line = {
         "metric": "patches/sec embedded (256x256, ViT-B/16)", "value": round(value, 1), "unit": "patches/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": short, "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": short,
+        "data": "synthetic" if not rehearsal else "synthetic -- REHEARSAL of the N > 1 code path (ranks share one GPU, gloo): not a measurement",
         "config": {"workload": f"process: one synthetic {args.slide}x{args.slide} slide per rank, 256x256 tiles "
                                f"resident in HBM, ViT-B/16 (random-init), device batch {B}",
                    "tiles_per_step": B, "slide_tissue_tiles": int(n_slide), "grid_cells": cells,

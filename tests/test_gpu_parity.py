@@ -403,6 +403,59 @@ def test_coords_full_size_vs_oracle():
     assert np.array_equal(got, want)
 
 
+def _random_mask(rng, kind, h, w):
+    from scipy import ndimage
+    if kind == 0:                                   # smooth blobs with holes
+        f = ndimage.gaussian_filter(rng.standard_normal((h, w)), rng.uniform(2.0, 8.0))
+        m = f > np.quantile(f, rng.uniform(0.35, 0.7))
+    elif kind == 1:                                 # speckle: many tiny fragments and pinholes (8- vs 4-connectivity traps)
+        m = rng.random((h, w)) < rng.uniform(0.3, 0.7)
+    elif kind == 2:                                 # blobs minus speckle: ragged borders, one-pixel walls, nested islands
+        f = ndimage.gaussian_filter(rng.standard_normal((h, w)), 6.0)
+        m = (f > np.quantile(f, 0.4)) & (rng.random((h, w)) < 0.93)
+    elif kind == 3:                                 # checkerboard / diagonal lattices
+        yy, xx = np.mgrid[0:h, 0:w]
+        p = int(rng.integers(1, 4))
+        m = ((xx // p + yy // p) % 2 == 0) & (rng.random((h, w)) < 0.97)
+    else:                                           # tissue touching every border, with a hole
+        m = np.ones((h, w), bool)
+        m[h // 3: h // 2, w // 4: w // 2] = False
+        m[h // 3 + 2: h // 3 + 4, w // 4 + 2: w // 4 + 5] = True
+    return m.astype(np.float32)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_coords_and_contours_random_masks_vs_oracle(seed):
+    """Seeded random masks (blobs with holes, speckle, lattices, one-pixel walls, border-touching tissue) with random
+    slide geometry: contours (threshold on the GPU + border following in the library) and coordinate rows (device grid
+    scan / containment / compaction) equal the CPU oracle's, bit for bit, in the oracle's order."""
+    from atlaspatch_amd.services.extraction import coords_from_mask
+    from atlaspatch_amd.utils.contours import mask_to_contours
+    from oracle import coords_oracle
+    rng = np.random.default_rng(1000 + seed)
+    h, w = int(rng.integers(40, 160)), int(rng.integers(40, 160))
+    mask = _random_mask(rng, seed % 5, h, w)
+    thresh = float(rng.choice([0.0, 0.0005, 0.01]))
+    got_t, got_h = mask_to_contours(mask, tissue_area_thresh=thresh)
+    want_t, want_h = coords_oracle.mask_to_contours(mask, tissue_area_thresh=thresh)
+    assert len(got_t) == len(want_t) and [len(x) for x in got_h] == [len(x) for x in want_h]
+    for a, b in zip(got_t, want_t):
+        assert np.array_equal(np.asarray(a).reshape(-1, 2), np.asarray(b).reshape(-1, 2))
+    for hs, ws in zip(got_h, want_h):
+        for a, b in zip(hs, ws):
+            assert np.array_equal(np.asarray(a).reshape(-1, 2), np.asarray(b).reshape(-1, 2))
+    ps = int(rng.choice([224, 256, 512]))
+    src_mag, tgt_mag = [(20, 20), (40, 20), (40, 40), (20, 10)][int(rng.integers(0, 4))]
+    ds = [(1.0, 4.0, 16.0), (1.0, 2.0, 4.0001), (1.0, 4.00012, 16.00097)][int(rng.integers(0, 3))]
+    kw = dict(level0_wh=(int(rng.integers(6000, 22000)), int(rng.integers(6000, 22000))), downsamples=list(ds),
+              src_mag=src_mag, tgt_mag=tgt_mag, patch_size=ps,
+              step_size=None if seed % 3 else int(ps * rng.choice([0.5, 0.75])), tissue_thresh=thresh)
+    got, _ = coords_from_mask(mask, **kw)
+    want, _ = coords_oracle.coords_from_mask(mask, **kw)
+    assert got.dtype == np.int32 and got.shape == want.shape
+    assert np.array_equal(got, want)
+
+
 def test_synth_tiles_bit_exact():
     import ctypes as C
     from atlaspatch_amd import _lib

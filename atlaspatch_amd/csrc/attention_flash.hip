@@ -154,6 +154,12 @@ void attention_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int 
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const Frag*)(qp + kk * 16 + hi * 8);
     }
+    // The Q registers are "used" HERE, in front of the tile loop: hipcc's wait-count pass then puts its vmcnt(0) for
+    // these four loads at this point.  Without it the wait sits in front of their first real use -- the QK^T MFMAs
+    // INSIDE the loop (the pass cannot prove that an earlier iteration already waited) -- and, because the LDS-DMA
+    // stream is invisible to the pass, that vmcnt(0) drained every staged tile in every iteration: the tile staged
+    // a few instructions earlier was waited for at once and the three-tile prefetch never overlapped anything.
+    asm volatile("" :: "v"(qf[0]), "v"(qf[1]), "v"(qf[2]), "v"(qf[3]));
 
     // ---- fragment addresses inside a buffer
     const int xr = (l31 >> 1) & 7;

@@ -656,6 +656,27 @@ def test_device_resample_equals_pillow(filt, in_hw, out_hw):
         assert np.array_equal(got[i], want), (i, np.abs(got[i].astype(int) - want).max())
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_device_resample_random_shapes_equal_pillow(seed):
+    """Random shapes through ap_resample_u8, most of them on the LDS-staged kernel (row bytes a multiple of 16 in, of 4
+    out; bands of 8 .. 64 output rows, ragged last band, up- and down-scaling, one-row images), some on the two-kernel
+    path: bit-identical to PIL.Image.resize."""
+    from PIL import Image
+    from atlaspatch_amd.utils.resample import DeviceResampler
+    rng = np.random.default_rng(500 + seed)
+    filt = ["bicubic", "bilinear"][seed % 2]
+    pf = {"bicubic": Image.Resampling.BICUBIC, "bilinear": Image.Resampling.BILINEAR}[filt]
+    w = int(rng.integers(1, 24)) * 16 if seed % 4 else int(rng.integers(5, 300))
+    ow = int(rng.integers(1, 130)) * 4 if seed % 4 else int(rng.integers(5, 300))
+    h, oh = int(rng.integers(1, 400)), int(rng.integers(1, 500))
+    n = int(rng.integers(1, 8))
+    tiles = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    got = DeviceResampler((h, w), (oh, ow), filt, _dev())(torch.from_numpy(tiles).to(_dev())).cpu().numpy()
+    for i in range(n):
+        want = np.asarray(Image.fromarray(tiles[i]).resize((ow, oh), pf))
+        assert np.array_equal(got[i], want), (seed, (h, w), (oh, ow), filt, i)
+
+
 def test_uni_transform_device_resize_matches_host_pillow():
     """uni_v1's transform (Resize(224, bicubic) + CenterCrop + Normalize) through the device resize gives the
     same features as resizing with Pillow on the host first (bit-identical inputs -> bit-identical outputs),

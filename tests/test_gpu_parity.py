@@ -42,6 +42,39 @@ def test_preproc_chw_bit_exact(dtype):
                        ref.view(torch.int16 if dtype != torch.float32 else torch.int32))
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_preproc_random_geometry_bit_exact(seed):
+    """K1 on random tile sizes, crop windows, batch sizes and normalisation constants, both output layouts (CHW and
+    patch rows), all three output types: bit-identical to ((x / 255) - mean) / std in float32, rounded once."""
+    from atlaspatch_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(900 + seed)
+    dtype = [torch.float32, torch.float16, torch.bfloat16][seed % 3]
+    crop = int(rng.choice([224, 448, 112, 64]))
+    h, w = crop + int(rng.integers(0, 70)), crop + int(rng.integers(0, 70))
+    top, left = int(rng.integers(0, h - crop + 1)), int(rng.integers(0, w - crop + 1))
+    n = int(rng.integers(1, 7))
+    mean = [float(v) for v in (rng.uniform(0.3, 0.6, 3) if seed % 2 else MEAN)]
+    std = [float(v) for v in (rng.uniform(0.15, 0.35, 3) if seed % 2 else STD)]
+    src = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    x = torch.from_numpy(src)[:, top:top + crop, left:left + crop, :].permute(0, 3, 1, 2).to(torch.float32).div(255)
+    ref = x.sub(torch.tensor(mean, dtype=torch.float32).view(1, 3, 1, 1)).div(torch.tensor(std, dtype=torch.float32).view(1, 3, 1, 1))
+    bits = torch.int32 if dtype == torch.float32 else torch.int16
+    d_src = torch.from_numpy(src).to(_dev())
+    d_out = torch.empty((n, 3, crop, crop), dtype=dtype, device=_dev())
+    _lib.check(lib.ap_preproc_u8hwc_to_chw(d_src.data_ptr(), n, h, w, top, left, crop, crop, _lib.f3(mean), _lib.f3(std),
+                                           d_out.data_ptr(), _lib.torch_dtype_code(dtype), _lib.current_stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(d_out.cpu().view(bits), ref.to(dtype).view(bits))
+    g = crop // 16
+    rows = ref.unfold(2, 16, 16).unfold(3, 16, 16).permute(0, 2, 3, 1, 4, 5).reshape(n * g * g, 768).contiguous().to(dtype)
+    d_rows = torch.empty((n * g * g, 768), dtype=dtype, device=_dev())
+    _lib.check(lib.ap_preproc_u8hwc_to_patchrows(d_src.data_ptr(), n, h, w, top, left, crop, crop, 16, _lib.f3(mean), _lib.f3(std),
+                                                 d_rows.data_ptr(), 768, _lib.torch_dtype_code(dtype), _lib.current_stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(d_rows.cpu().view(bits), rows.view(bits))
+
+
 def test_preproc_golden_vector(golden_dir):
     import os
     from atlaspatch_amd import _lib

@@ -92,7 +92,18 @@ class HipViTFeatureExtractor(FeatureExtractor):
             raise ValueError(
                 f"{self.name}: the device preprocess implements the reference transform for "
                 f"{self.expect_size}x{self.expect_size} tiles only (got {shape0[1]}x{shape0[0]})")
-        return np.stack(arrs, axis=0)
+        # gathered straight into a grow-only PINNED buffer (what np.stack would cost, but the H2D copy that follows runs at
+        # the pinned rate instead of through the driver's staging buffer).  Safe to reuse: extract_batch ends with a
+        # synchronous D2H, so every copy out of this buffer has completed when the next call fills it.
+        n = len(arrs)
+        need = n * int(np.prod(shape0))
+        pin = getattr(self, "_pin", None)
+        if pin is None or pin.numel() < need:
+            self._pin = pin = torch.empty(need, dtype=torch.uint8).pin_memory()
+        view = pin[:need].view(n, *shape0).numpy()
+        for i, a in enumerate(arrs):
+            view[i] = a
+        return view
 
     def resized(self, tiles_u8: torch.Tensor) -> torch.Tensor:
         """The transform's leading ``Resize`` on a device batch uint8 [n, H, W, 3] (identity when absent)."""
@@ -130,7 +141,7 @@ class HipViTFeatureExtractor(FeatureExtractor):
         step = max(1, min(n, self.max_batch))
         out = torch.empty((n, self.embedding_dim), dtype=torch.float32, device=self.device)
         for s in range(0, n, step):
-            dev = host[s:s + step].to(self.device, non_blocking=False)
+            dev = host[s:s + step].to(self.device, non_blocking=True)      # pinned source (see _prepare)
             self.forward_device(dev, out[s:s + step])
         return out.cpu().numpy()
 

@@ -6,7 +6,7 @@ import numpy as np, torch
 from atlaspatch_amd import _lib
 dev = torch.device("cuda:0"); lib = _lib.load(); stream = _lib.current_stream_ptr(dev)
 g = torch.Generator(device=dev).manual_seed(0)
-M = 1024 * 197
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 1024 * 197
 CASES = (("qkv", 2304, 768, 0, 0), ("fc1", 3072, 768, 1, 0), ("fc1-store-epilogue", 3072, 768, 0, 0), ("fc1-rowmajor-walk", 3072, 768, 1, 12 << 16),
          ("fc1-N2304", 2304, 768, 1, 0), ("fc2", 768, 3072, 0, 0))
 for name, N, K, epi, variant in CASES:

@@ -286,6 +286,90 @@ def test_segment_and_get_coords_with_sam2_on_an_image_slide(tmp_path, monkeypatc
     assert np.array_equal(got, want)
 
 
+def test_process_on_a_slide_behind_a_stub_openslide(tmp_path, monkeypatch):
+    """The OpenSlide backend end to end (BASELINE config 1's code path; openslide-python itself is absent): a stub
+    ``openslide`` module with the library's interface (dimensions, level_count, level_downsamples, level_dimensions,
+    properties, read_region -> RGBA, get_thumbnail, close) serves a synthetic slide with CMU-1-like level
+    downsamples behind a ``.svs`` path.  ``process`` runs SAM2 segmentation (seeded random weights: the mask is
+    arbitrary), device coords, the tile ring through ``OpenSlideWSI.extract`` (read_region(...).convert("RGB")) and
+    the encoder.  Coords must equal the oracle's for the mask the segmenter produced; features must equal the
+    encoder's on the same tiles rendered directly."""
+    import types
+    from click.testing import CliRunner
+    from PIL import Image
+    from atlaspatch_amd.cli import cli
+    from atlaspatch_amd.core.config import SegmentationConfig
+    from atlaspatch_amd.core.wsi import openslide_wsi
+    from atlaspatch_amd.core.wsi.synth_pixels import SynthSpec, render_region
+    from atlaspatch_amd.encoders import build_default_registry
+    from atlaspatch_amd.services.segmentation import SAM2SegmentationService
+    from atlaspatch_amd.utils.h5 import h5
+    from oracle import coords_oracle
+
+    spec = SynthSpec(width=11000, height=8200, seed=77)
+    ds = (1.0, 4.0001, 16.00097)
+    calls = {"read_region": 0, "closed": 0}
+
+    class FakeOpenSlide:
+        def __init__(self, path):
+            assert str(path).endswith(".svs")
+            self.dimensions = (spec.width, spec.height)
+            self.level_count = len(ds)
+            self.level_downsamples = ds
+            self.level_dimensions = tuple((int(spec.width / d), int(spec.height / d)) for d in ds)
+            self.properties = {"openslide.mpp-x": "0.4990", "openslide.mpp-y": "0.4990", "aperio.AppMag": "20",
+                               "openslide.objective-power": "20", "openslide.vendor": "aperio"}
+
+        def read_region(self, location, level, size):
+            calls["read_region"] += 1
+            rgb = render_region(spec, int(location[0]), int(location[1]), int(size[0]), int(size[1]), int(level))
+            rgba = np.concatenate([rgb, np.full(rgb.shape[:2] + (1,), 255, np.uint8)], axis=2)
+            return Image.fromarray(rgba, "RGBA")
+
+        def get_thumbnail(self, size):
+            lv = self.level_count - 1
+            w, h = self.level_dimensions[lv]
+            im = self.read_region((0, 0), lv, (w, h))
+            im.thumbnail(size)
+            return im
+
+        def close(self):
+            calls["closed"] += 1
+
+    monkeypatch.setattr(openslide_wsi, "openslide", types.SimpleNamespace(OpenSlide=FakeOpenSlide))
+    monkeypatch.setenv("ATLASPATCH_RANDOM_INIT", "4")
+    path = tmp_path / "CMU-like.svs"
+    path.write_bytes(b"stub")
+    out = tmp_path / "out"
+    res = CliRunner().invoke(cli, ["process", str(path), "-o", str(out), "--patch-size", "256", "--target-mag", "20",
+                                   "--feature-extractors", "vit_b_16", "--feature-precision", "float32",
+                                   "--feature-num-workers", "4"], catch_exceptions=False)
+    assert res.exit_code == 0 and "failures: 0" in res.output, res.output
+    with h5.File(out / "patches" / "CMU-like.h5", "r") as f:
+        coords = f["coords"][:]
+        feats = f["features"]["vit_b_16"][:]
+        assert float(f.attrs["level0_magnification"]) == 20 and int(f.attrs["patch_size_level0"]) == 256
+    assert calls["read_region"] >= coords.shape[0] > 0 and calls["closed"] >= 1
+    # coords: the oracle on the mask the segmenter produces for this slide
+    seg = SAM2SegmentationService(SegmentationConfig(checkpoint_path=None, config_path=path, device="cuda"))
+    wsi = openslide_wsi.OpenSlideWSI(path=str(path))
+    wsi._ensure_loaded()
+    assert wsi.mpp == 0.499 and wsi.mag == 20 and wsi.ds == list(ds)
+    mask = seg.segment_thumbnail(wsi).data
+    seg.close()
+    want, _ = coords_oracle.coords_from_mask(mask, level0_wh=(spec.width, spec.height), downsamples=list(ds), src_mag=20,
+                                             tgt_mag=20, patch_size=256, step_size=None, tissue_thresh=0.0)
+    assert np.array_equal(coords, want)
+    assert (coords[:, 2] == 256).all() and (coords[:, 4] == 0).all()
+    # features: the same tiles rendered directly, through the encoder's boundary call
+    rows = np.linspace(0, coords.shape[0] - 1, 12).astype(int)
+    tiles = [render_region(spec, int(coords[r, 0]), int(coords[r, 1]), 256, 256, 0) for r in rows]
+    ex = build_default_registry(device="cuda", dtype=torch.float32).create("vit_b_16")      # same seed as the CLI run
+    direct = ex.extract_batch(tiles)
+    ex.cleanup()
+    assert np.allclose(feats[rows], direct, rtol=1e-5, atol=1e-6)
+
+
 def _mpp_csv(folder, name, mpp):
     p = folder / "mpp.csv"
     p.write_text(f"wsi,mpp\n{name},{mpp}\n")

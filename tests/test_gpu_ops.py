@@ -515,3 +515,22 @@ def test_cv2_resize_device_equals_oracle_on_random_shapes(env):
     # empty batch: nothing launched, nothing touched
     empty = torch.empty((0, 8, 8, 3), dtype=torch.uint8, device=dev)
     assert cv2_resize_device(empty, (4, 4), 1).shape == (0, 4, 4, 3)
+
+
+def test_cv2_resize_exact_halving_quad_kernel(env):
+    """The exact 2 x 2 shrink with four output pixels per thread (the 40x -> 20x tile path; taken when the output width
+    is a multiple of 4): batches of 1 .. 7 tiles, square and non-square, INTER_LINEAR (which OpenCV re-routes to the
+    2 x 2 average) and INTER_AREA, against the NumPy restatement bit for bit; an output width off the multiple of 4 runs
+    the one-pixel-per-thread kernel and must agree too."""
+    from atlaspatch_amd.utils.resample import cv2_resize_device
+    from oracle import cv2_resize as R
+    _lib, lib, dev, stream = env
+    rng = np.random.default_rng(77)
+    for (n, oh, ow) in ((1, 4, 4), (3, 20, 32), (5, 256, 256), (7, 52, 100), (2, 33, 8), (2, 16, 6)):
+        tiles = rng.integers(0, 256, (n, 2 * oh, 2 * ow, 3), dtype=np.uint8)
+        tiles[0, ::2] = 255                                           # rounding at .5: (255 + 255 + x + y + 2) >> 2
+        for interp in (1, 3):
+            got = cv2_resize_device(torch.from_numpy(tiles).to(dev), (ow, oh), interp).cpu().numpy()
+            for i in range(n):
+                assert np.array_equal(got[i], R.resize(tiles[i], (ow, oh), interp)), (n, oh, ow, interp, i)
+

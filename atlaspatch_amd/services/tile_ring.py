@@ -122,10 +122,18 @@ class TileRing:
         out_dev = [torch.empty((self.batch, out_dim), dtype=torch.float32, device=self.device)
                    for _ in range(self.slots)]
         compute = torch.cuda.current_stream(self.device)
-        nb = (n_total + self.batch - 1) // self.batch
+        # batch cuts: the first batches ramp up (batch / 8, / 4, / 2, then full batches) so that the first forward starts
+        # after an eighth of a slot has been decoded instead of a whole one -- on a 10 000-tile slide decoded at 20 k tiles/s
+        # that is 13 ms instead of 100 ms of idle GPU in front of 350 ms of work.  Features do not depend on the cuts.
+        bounds, lo, size = [], 0, max(1, min(self.batch, max(64, self.batch // 8)))
+        while lo < n_total:
+            hi = min(n_total, lo + size)
+            bounds.append((lo, hi))
+            lo, size = hi, min(self.batch, size * 2)
+        nb = len(bounds)
 
         def fill(slot: int, b: int):
-            lo, hi = b * self.batch, min(n_total, (b + 1) * self.batch)
+            lo, hi = bounds[b]
             base = self.host[slot].data_ptr()
             count = hi - lo
             chunk = max(1, -(-count // (4 * self.workers)))          # a few tasks per worker, not one per tile
@@ -174,7 +182,7 @@ class TileRing:
                     copied.record(self.copy_stream)
                 compute.wait_event(copied)
                 forward(self.dev[slot][:count], out_dev[slot][:count])
-                lo = b * self.batch
+                lo = bounds[b][0]
                 out_host[lo:lo + count].copy_(out_dev[slot][:count], non_blocking=True)
                 done = torch.cuda.Event()
                 done.record(compute)

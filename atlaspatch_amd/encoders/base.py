@@ -99,7 +99,7 @@ class HipViTFeatureExtractor(FeatureExtractor):
         need = n * int(np.prod(shape0))
         pin = getattr(self, "_pin", None)
         if pin is None or pin.numel() < need:
-            self._pin = pin = torch.empty(need, dtype=torch.uint8).pin_memory()
+            self._pin = pin = torch.empty(need, dtype=torch.uint8, pin_memory=True)
         view = pin[:need].view(n, *shape0).numpy()
         for i, a in enumerate(arrs):
             view[i] = a

@@ -140,7 +140,7 @@ class PatchExtractionService(ExtractionService):
         # tiles are read at their level size; cv2.resize(patch, (ps, ps)) (extraction.py:112-113) runs on the device
         rw, rh = int(coords[0, 2]), int(coords[0, 3])
         resized = (rw, rh) != (ps, ps)
-        host = torch.empty((batch, rh, rw, 3), dtype=torch.uint8).pin_memory()
+        host = torch.empty((batch, rh, rw, 3), dtype=torch.uint8, pin_memory=True)
         view = host.numpy()
         writers = futures.ThreadPoolExecutor(max_workers=max(2, min(8, __import__("os").cpu_count() or 4)),
                                              thread_name_prefix="patch-img") if img_dir is not None else None

@@ -77,7 +77,7 @@ class TileRing:
         self.ps = int(patch_size)
         self.th, self.tw = (int(tile_hw[0]), int(tile_hw[1])) if tile_hw is not None else (self.ps, self.ps)
         self.slots = max(2, int(slots))
-        self.host = [torch.empty((self.batch, self.th, self.tw, 3), dtype=torch.uint8).pin_memory()
+        self.host = [torch.empty((self.batch, self.th, self.tw, 3), dtype=torch.uint8, pin_memory=True)
                      for _ in range(self.slots)]
         self.dev = [torch.empty((self.batch, self.th, self.tw, 3), dtype=torch.uint8, device=device)
                     for _ in range(self.slots)]
@@ -117,7 +117,7 @@ class TileRing:
             return np.empty((0, out_dim), dtype=np.float32)
         # grow-only pinned result buffer: re-pinning [N, D] for every slide costs more than the copy out of it
         if self._out_host is None or self._out_host.shape[0] < n_total or self._out_host.shape[1] != out_dim:
-            self._out_host = torch.empty((max(n_total, self.batch), out_dim), dtype=torch.float32).pin_memory()
+            self._out_host = torch.empty((max(n_total, self.batch), out_dim), dtype=torch.float32, pin_memory=True)
         out_host = self._out_host
         out_dev = [torch.empty((self.batch, out_dim), dtype=torch.float32, device=self.device)
                    for _ in range(self.slots)]

@@ -37,32 +37,59 @@ def _cpu_list(text: str) -> list:
     return out
 
 
-def _pin_order(device) -> list:
-    """Allowed CPUs ordered for pinning: the GPU's NUMA node first, one hardware thread per physical core first."""
-    import os
-    if not hasattr(os, "sched_getaffinity"):
-        return []
-    allowed = sorted(os.sched_getaffinity(0))
-    local = set(allowed)
+def _device_bdf(device) -> str | None:
+    """PCI address ``dddd:bb:dd.0`` of a torch device (torch exposes the three fields as integers)."""
     try:
-        bdf = torch.cuda.get_device_properties(device).pci_bus_id.lower()
-        with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as fh:
-            node = int(fh.read())
-        if node >= 0:
-            with open(f"/sys/devices/system/node/node{node}/cpulist") as fh:
-                local = set(_cpu_list(fh.read())) & set(allowed) or set(allowed)
-    except Exception:  # noqa: BLE001 -- no topology information: every allowed CPU counts as local
-        pass
+        p = torch.cuda.get_device_properties(device)
+        return f"{int(p.pci_domain_id):04x}:{int(p.pci_bus_id):02x}:{int(p.pci_device_id):02x}.0"
+    except (AttributeError, RuntimeError, AssertionError, TypeError, ValueError):
+        return None
+
+
+def _pin_order(device, *, sysfs: str = "/sys", allowed=None, bdf: str | None = None,
+               local_rank: int | None = None, local_world: int | None = None) -> list:
+    """CPUs this rank's decode threads are pinned to, in order of preference: the GPU's NUMA node first, one hardware
+    thread per physical core before any SMT sibling, all from the process's affinity mask.  Under a multi-rank launch
+    (LOCAL_RANK / LOCAL_WORLD_SIZE) every class is dealt round-robin over the local ranks, so the ranks of one node take
+    DISJOINT cores (eight ranks with the same mask would otherwise all pin to the same few cores).
+    ``sysfs`` / ``allowed`` / ``bdf`` / ``local_*`` are injectable for the host-logic test (fake sysfs tree)."""
+    import os
+    if allowed is None:
+        if not hasattr(os, "sched_getaffinity"):
+            return []
+        allowed = os.sched_getaffinity(0)
+    allowed = sorted(allowed)
+    if local_rank is None:
+        local_rank = int(os.environ.get("LOCAL_RANK", "0") or 0)
+    if local_world is None:
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1)
+    local_world = max(1, local_world)
+    local_rank = min(max(0, local_rank), local_world - 1)
+    local = set(allowed)
+    if bdf is None:
+        bdf = _device_bdf(device)
+    if bdf is not None:
+        try:
+            with open(f"{sysfs}/bus/pci/devices/{bdf}/numa_node") as fh:
+                node = int(fh.read())
+            if node >= 0:
+                with open(f"{sysfs}/devices/system/node/node{node}/cpulist") as fh:
+                    local = set(_cpu_list(fh.read())) & set(allowed) or set(allowed)
+        except (OSError, ValueError):       # no topology information: every allowed CPU counts as local
+            pass
     primary, sibling = [], []
     for cpu in allowed:
         try:
-            with open(f"/sys/devices/system/cpu/cpu{cpu}/topology/thread_siblings_list") as fh:
+            with open(f"{sysfs}/devices/system/cpu/cpu{cpu}/topology/thread_siblings_list") as fh:
                 first = min(_cpu_list(fh.read()))
-        except Exception:  # noqa: BLE001
+        except (OSError, ValueError):
             first = cpu
         (primary if first == cpu else sibling).append(cpu)
-    order = [c for c in primary if c in local] + [c for c in primary if c not in local] + \
-            [c for c in sibling if c in local] + [c for c in sibling if c not in local]
+    classes = ([c for c in primary if c in local], [c for c in primary if c not in local],
+               [c for c in sibling if c in local], [c for c in sibling if c not in local])
+    order = []
+    for cls in classes:
+        order += cls[local_rank::local_world]
     return order
 
 
@@ -88,8 +115,9 @@ class TileRing:
         self._lib = _lib.load()
         # decode threads pinned one per host core (north star: "tile decode on host cores pinned"): cores of the NUMA node
         # the GPU hangs off first (the pinned slots live there and the H2D DMA reads them from there), one hardware thread
-        # per physical core before any SMT sibling, all from the process's own affinity mask; the first core is left to the
-        # main thread that drives the streams.  ATLASPATCH_PIN_THREADS=0 disables.
+        # per physical core before any SMT sibling, all from the process's own affinity mask, dealt over the local ranks of a
+        # multi-rank launch (disjoint cores per rank); the first core is left to the main thread that drives the streams.
+        # ATLASPATCH_PIN_THREADS=0 disables.
         import itertools
         import os
         cores = _pin_order(device)

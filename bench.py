@@ -27,9 +27,37 @@ import numpy as np
 import torch
 
 FLOP_PER_PATCH_VIT_B16 = 35.126e9      # 33.695 GEMM (incl. 0.231 patch-embed) + 1.431 attention
-# Executed by this build: the last block computes K / V for every token but everything after that for the CLS row only
-# (the only row the readout uses): 2.908 GFLOP of that block shrink to 0.477.
-FLOP_PER_PATCH_EXECUTED = FLOP_PER_PATCH_VIT_B16 - 2.908e9 + 0.477e9
+OPENAI_CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+OPENAI_CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+# --encoder: the three encoders BASELINE.json's configs name (registered names of the reference: models/patch/vit.py:9-15,
+# uni.py:13-60, conch.py:20-64); `batch` = default device batch
+ENCODERS = {
+    "vit_b_16": {"label": "ViT-B/16", "batch": 2048},
+    "uni_v1": {"label": "UNI v1 (ViT-L/16 + LayerScale, Resize(224, bicubic) on the device)", "batch": 2048},
+    "conch_v1": {"label": "CONCH v1 visual tower (ViT-B/16 at 448 px = 785 tokens + attentional pooler, Resize(448, bicubic) "
+                          "on the device)", "batch": 256, "mean": OPENAI_CLIP_MEAN, "std": OPENAI_CLIP_STD},
+}
+
+
+def encoder_geometry(arch):
+    """Tokens and algorithmic FLOP per tile (2*M*N*K per linear, 4*T^2*D per attention): `model` = every
+    block for every token, `executed` = what this build runs (CLS-pooled encoders: the last block computes K / V for every
+    token and everything after that for the CLS row only -- DESIGN.md section 3 -- identical features)."""
+    T = 1 + (arch["image_size"] // arch["patch_size"]) ** 2
+    D, mlp, L = arch["dim"], arch["mlp_dim"], arch["depth"]
+    patch_embed = 2.0 * (T - 1) * D * 3 * arch["patch_size"] ** 2
+    block = 2.0 * T * (4 * D * D + 2 * D * mlp) + 4.0 * T * T * D
+    model = patch_embed + L * block
+    executed = model
+    if arch.get("pool") == "attn":
+        P = arch["pool_dim"]
+        model += 2.0 * T * D * 2 * P + 4.0 * T * P + 2.0 * P * P
+        executed = model
+    elif D // arch["heads"] == 64:
+        executed = model - block + 2.0 * T * D * 2 * D + 2.0 * (2 * D * D + 2 * D * mlp) + 4.0 * T * D
+    return {"tokens": T, "model": model, "executed": executed}
+
+
 MFMA_PEAK = {"f16": 2.5e15, "bf16": 2.5e15, "f32": 157.3e12}   # dense, MI355X_MICROARCH.md
 
 
@@ -38,15 +66,23 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=2048, help="tiles per step (device batch)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="tiles per step (device batch; default 2048, conch_v1 256 = its registered maximum)")
     ap.add_argument("--precision", default="float16", choices=["float16", "bfloat16", "float32"])
     ap.add_argument("--slide", type=int, default=None,
                     help="synthetic slide side in pixels (default: 40000 = BASELINE config 2 at N = 1, "
                          "100000 = config 4 for N > 1)")
+    ap.add_argument("--encoder", default="vit_b_16", choices=sorted(ENCODERS),
+                    help="registered encoder of the forward (vit_b_16 = configs 2 / 4, uni_v1 = config 3, conch_v1 = config 5)")
+    ap.add_argument("--slide-seed", type=int, default=1234, help="rank r embeds the synthetic slide of seed SLIDE_SEED + r")
+    ap.add_argument("--dump-features", default=None,
+                    help="rank 0 saves the float32 feature matrix of the timed steps (the gathered [N*K*B, D] matrix for N > 1) "
+                         "as .npy -- used by the N > 1 rehearsal test")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the secondary rates (ring / end-to-end / boundary / f32 / uni_v1 / conch_v1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=192, help="patches timed on the CPU oracle")
+    ap.add_argument("--cpu-sample", type=int, default=0,
+                    help="patches timed on the CPU oracle (default: 192 vit_b_16, 64 uni_v1, 32 conch_v1 = 10-20 s)")
     return ap.parse_args()
 
 
@@ -59,11 +95,19 @@ def slide_tiles(device, side, seed, count):
 
     spec = SynthSpec(width=side, height=side, seed=seed)
     mask = analytic_mask(spec)
+    kw = dict(level0_wh=(side, side), downsamples=list(spec.downsamples), src_mag=spec.mag, tgt_mag=spec.mag,
+              patch_size=256, step_size=None, tissue_thresh=0.0)
     t0 = time.perf_counter()
-    coords, geom = coords_from_mask(mask, level0_wh=(side, side), downsamples=list(spec.downsamples),
-                                    src_mag=spec.mag, tgt_mag=spec.mag, patch_size=256, step_size=None,
-                                    tissue_thresh=0.0)
-    coords_s = time.perf_counter() - t0
+    coords, geom = coords_from_mask(mask, **kw)             # cold: first use of the kernels + allocations in this process
+    cold_s = time.perf_counter() - t0
+    warm = []
+    for _ in range(10):                                     # warm, repeated: what every later slide of a run pays
+        t0 = time.perf_counter()
+        again, _ = coords_from_mask(mask, **kw)
+        warm.append(time.perf_counter() - t0)
+    assert np.array_equal(again, coords)
+    coords_stats = {"cold_seconds": round(cold_s, 5), "warm_seconds_median": round(float(np.median(warm)), 5),
+                    "warm_seconds_min": round(min(warm), 5), "warm_repeats": len(warm)}
     cells = int(math.ceil(side / 256) ** 2)
     n_slide = coords.shape[0]
     reps = int(math.ceil(count / max(1, n_slide)))
@@ -75,33 +119,65 @@ def slide_tiles(device, side, seed, count):
     _lib.check(lib.ap_synth_tiles(d_xy.data_ptr(), count, 256, 1, 0, side, side, spec.seed, d_ell.data_ptr(),
                                   d_ell.shape[0], tiles.data_ptr(), _lib.current_stream_ptr(device)))
     torch.cuda.synchronize(device)
-    return tiles, n_slide, cells, coords_s, coords
+    return tiles, n_slide, cells, coords_stats, coords
 
 
-def cpu_baseline(sample, seed):
-    """CPU oracle (torch fp32 restatement of the reference path) on a bounded sample."""
-    from atlaspatch_amd.encoders.vit import ARCHS, random_canonical_state_dict
+def cpu_oracle_forward(encoder, seed):
+    """The CPU oracle of one registered encoder on the same seeded weights the device path gets (torch fp32 restatement of
+    the reference path, oracle/vit_oracle.py): returns f(list of uint8 tiles) -> float32 [n, D]."""
+    from PIL import Image
+    from atlaspatch_amd.encoders.vit import ARCHS, TRANSFORM_RESIZE, random_attn_pool, random_canonical_state_dict
     from oracle import vit_oracle
 
-    arch = ARCHS["vit_b_16"]
+    arch = ARCHS[encoder]
     sd = random_canonical_state_dict(arch, seed=seed)
-    hf = {"embeddings.patch_embeddings.projection.weight": sd["patch_embed.weight"],
-          "embeddings.patch_embeddings.projection.bias": sd["patch_embed.bias"],
-          "embeddings.cls_token": sd["cls_token"].view(1, 1, -1),
-          "embeddings.position_embeddings": sd["pos_embed"][None],
-          "layernorm.weight": sd["norm.weight"], "layernorm.bias": sd["norm.bias"]}
-    for i in range(arch["depth"]):
-        p, b = f"layers.{i}.", f"blocks.{i}."
-        q, k, v = sd[b + "qkv.weight"].chunk(3, 0)
-        qb, kb, vb = sd[b + "qkv.bias"].chunk(3, 0)
-        hf.update({p + "layernorm_before.weight": sd[b + "ln1.weight"], p + "layernorm_before.bias": sd[b + "ln1.bias"],
-                   p + "attention.q_proj.weight": q, p + "attention.q_proj.bias": qb,
-                   p + "attention.k_proj.weight": k, p + "attention.k_proj.bias": kb,
-                   p + "attention.v_proj.weight": v, p + "attention.v_proj.bias": vb,
-                   p + "attention.o_proj.weight": sd[b + "proj.weight"], p + "attention.o_proj.bias": sd[b + "proj.bias"],
-                   p + "layernorm_after.weight": sd[b + "ln2.weight"], p + "layernorm_after.bias": sd[b + "ln2.bias"],
-                   p + "mlp.fc1.weight": sd[b + "fc1.weight"], p + "mlp.fc1.bias": sd[b + "fc1.bias"],
-                   p + "mlp.fc2.weight": sd[b + "fc2.weight"], p + "mlp.fc2.bias": sd[b + "fc2.bias"]})
+    if encoder == "vit_b_16":             # the HF-keyed forward the reference's own extract_batch outputs pin (golden G1)
+        hf = {"embeddings.patch_embeddings.projection.weight": sd["patch_embed.weight"],
+              "embeddings.patch_embeddings.projection.bias": sd["patch_embed.bias"],
+              "embeddings.cls_token": sd["cls_token"].view(1, 1, -1),
+              "embeddings.position_embeddings": sd["pos_embed"][None],
+              "layernorm.weight": sd["norm.weight"], "layernorm.bias": sd["norm.bias"]}
+        for i in range(arch["depth"]):
+            p, b = f"layers.{i}.", f"blocks.{i}."
+            q, k, v = sd[b + "qkv.weight"].chunk(3, 0)
+            qb, kb, vb = sd[b + "qkv.bias"].chunk(3, 0)
+            hf.update({p + "layernorm_before.weight": sd[b + "ln1.weight"], p + "layernorm_before.bias": sd[b + "ln1.bias"],
+                       p + "attention.q_proj.weight": q, p + "attention.q_proj.bias": qb,
+                       p + "attention.k_proj.weight": k, p + "attention.k_proj.bias": kb,
+                       p + "attention.v_proj.weight": v, p + "attention.v_proj.bias": vb,
+                       p + "attention.o_proj.weight": sd[b + "proj.weight"], p + "attention.o_proj.bias": sd[b + "proj.bias"],
+                       p + "layernorm_after.weight": sd[b + "ln2.weight"], p + "layernorm_after.bias": sd[b + "ln2.bias"],
+                       p + "mlp.fc1.weight": sd[b + "fc1.weight"], p + "mlp.fc1.bias": sd[b + "fc1.bias"],
+                       p + "mlp.fc2.weight": sd[b + "fc2.weight"], p + "mlp.fc2.bias": sd[b + "fc2.bias"]})
+        return lambda patches: vit_oracle.extract_batch(hf, patches, heads=arch["heads"], batch_size=32)
+    if encoder == "conch_v1":
+        pool = random_attn_pool(arch, seed)
+        trunk = {k: v for k, v in sd.items() if not k.startswith("attn_pool.")}
+        return lambda patches: np.concatenate([vit_oracle.conch_encode_image(
+            trunk, pool, patches[s:s + 8], heads=arch["heads"], depth=arch["depth"], pool_heads=arch["pool_heads"])
+            for s in range(0, len(patches), 8)], 0)
+    size, filt = TRANSFORM_RESIZE[encoder]      # timm / torchvision: Resize(size) with Pillow on the PIL tile, then centre crop
+
+    def forward(patches):
+        outs = []
+        for s in range(0, len(patches), 32):
+            arrs = []
+            for pch in patches[s:s + 32]:
+                img = Image.fromarray(np.asarray(pch))
+                w, h = img.size
+                if min(w, h) != size:
+                    nw, nh = (size, int(size * h / w)) if w <= h else (int(size * w / h), size)
+                    img = img.resize((nw, nh), Image.Resampling.BICUBIC if filt == "bicubic" else Image.Resampling.BILINEAR)
+                arrs.append(np.asarray(img))
+            x = vit_oracle.preprocess_center_crop(np.stack(arrs, 0), crop=arch["image_size"])
+            outs.append(vit_oracle.vit_tokens_canonical(sd, x, heads=arch["heads"], depth=arch["depth"])[:, 0].numpy())
+        return np.concatenate(outs, 0)
+    return forward
+
+
+def cpu_baseline(encoder, sample, seed):
+    """CPU oracle (torch fp32 restatement of the reference path) on a bounded sample."""
+    forward = cpu_oracle_forward(encoder, seed)
     rng = np.random.default_rng(0)
     patches = [rng.integers(0, 256, (256, 256, 3), dtype=np.uint8) for _ in range(sample)]
     # torch's default (all physical cores) is far from the best setting for this batch-32 fp32 forward on a 2-socket
@@ -110,20 +186,22 @@ def cpu_baseline(sample, seed):
     # CPU path at its best, not at its default.
     default_threads = torch.get_num_threads()
     best, best_rate = default_threads, 0.0
+    probe = min(32, sample) if encoder == "vit_b_16" else min(8, sample)
     for th in sorted({t for t in (8, 16, 32, 64) if t <= (os.cpu_count() or 1)} | {min(default_threads, 64)}):
         torch.set_num_threads(th)
-        vit_oracle.extract_batch(hf, patches[:32], heads=arch["heads"], batch_size=32)    # warm-up at this count
+        if encoder == "vit_b_16":
+            forward(patches[:probe])                 # warm-up at this count
         t0 = time.perf_counter()
-        vit_oracle.extract_batch(hf, patches[:32], heads=arch["heads"], batch_size=32)
-        r = 32 / (time.perf_counter() - t0)
+        forward(patches[:probe])
+        r = probe / (time.perf_counter() - t0)
         if r > best_rate:
             best, best_rate = th, r
     torch.set_num_threads(best)
     t0 = time.perf_counter()
-    out = vit_oracle.extract_batch(hf, patches, heads=arch["heads"], batch_size=32)
+    out = forward(patches)
     dt = time.perf_counter() - t0
     torch.set_num_threads(default_threads)
-    return out, hf, patches, sample / dt, best
+    return out, patches, sample / dt, best
 
 
 def cpu_coords_baseline(side, seed):
@@ -354,8 +432,32 @@ def secondary_rates(device, ex, tiles, B):
     return rates
 
 
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this same command under torch.distributed.run
+    (one process per GPU, RCCL).  On a box with fewer than N devices the ranks share cuda:0 and the collectives go through
+    gloo -- a REHEARSAL of the N > 1 code path, marked as such in the line, never a measurement."""
+    import socket
+    import subprocess
+    env = dict(os.environ)
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        env["AP_BENCH_BACKEND"] = "gloo"
+        env["AP_BENCH_ONE_GPU"] = "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device: the product has no CPU fallback")
+        respawn_under_torchrun(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.slide is None:
         args.slide = 40000 if world == 1 else 100000
@@ -376,21 +478,30 @@ def main():
             dist.init_process_group(backend=os.environ["AP_BENCH_BACKEND"])
         else:
             dist.init_process_group(backend="nccl", device_id=device)
+        world = dist.get_world_size()             # the ranks the process group actually has
+        rank = dist.get_rank()
 
-    from atlaspatch_amd.encoders.vit import build_hip_vit_extractor
+    from atlaspatch_amd.encoders.vit import ARCHS, TRANSFORM_RESIZE, build_hip_vit_extractor
 
     dtype = {"float16": torch.float16, "bfloat16": torch.bfloat16, "float32": torch.float32}[args.precision]
     short = {"float16": "f16", "bfloat16": "bf16", "float32": "f32"}[args.precision]
-    ex = build_hip_vit_extractor(name="vit_b_16", arch="vit_b_16", device=device, dtype=dtype,
-                                 random_init_seed=0, max_batch=args.batch)
+    enc = ENCODERS[args.encoder]
+    arch = ARCHS[args.encoder]
+    if args.batch is None:
+        args.batch = enc["batch"]
+    geo = encoder_geometry(arch)
+    T, D, MLP = geo["tokens"], arch["dim"], arch["mlp_dim"]
+    ex = build_hip_vit_extractor(name=args.encoder, arch=args.encoder, device=device, dtype=dtype,
+                                 random_init_seed=0, max_batch=args.batch, resize=TRANSFORM_RESIZE[args.encoder],
+                                 expect_size=None, mean=enc.get("mean"), std=enc.get("std"))
     B, K, W = args.batch, args.steps, args.warmup
     pool_steps = min(K, 12)                       # distinct tile batches cycled through the timed steps
-    tiles, n_slide, cells, coords_s, dev_coords = slide_tiles(device, args.slide, 1234 + rank, pool_steps * B)
+    tiles, n_slide, cells, coords_stats, dev_coords = slide_tiles(device, args.slide, args.slide_seed + rank, pool_steps * B)
     feats = torch.empty((K * B, ex.embedding_dim), dtype=torch.float32, device=device)
 
     def step(i, dst):
         s = (i % pool_steps) * B
-        ex.vit.forward_u8(tiles[s:s + B], ex.mean, ex.std, dst)
+        ex.forward_device(tiles[s:s + B], dst)    # the transform's Resize (uni_v1 / conch_v1) + K1 + encoder
 
     gathered = None
     if dist is not None:
@@ -401,14 +512,18 @@ def main():
         dist.all_gather_into_tensor(gathered, feats)
     torch.cuda.synchronize(device)
     ex.vit.profile(True)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
+    ev[0].record()
     for i in range(K):
         step(i, feats[i * B:(i + 1) * B])
+    ev[1].record()
     if dist is not None:        # reassemble the feature matrix on every rank (north star): one all-gather
         dist.all_gather_into_tensor(gathered, feats)
+    ev[2].record()
     torch.cuda.synchronize(device)
     if dist is not None:
         dist.barrier()
@@ -416,16 +531,26 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = ex.vit.profile_read()
     ex.vit.profile(False)
+    per_rank = None
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        mine = {"rank": rank, "device": str(device), "slide_seed": args.slide_seed + rank,
+                "forward_ms": round(ev[0].elapsed_time(ev[1]), 3),
+                "patches_per_s": round(K * B / (ev[0].elapsed_time(ev[1]) * 1e-3), 1),
+                "all_gather_ms": round(ev[1].elapsed_time(ev[2]), 3)}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+    if args.dump_features and rank == 0:
+        np.save(args.dump_features, (gathered if dist is not None else feats).cpu().numpy())
 
     # Secondary, untimed-for-`value` measurement: the same K steps with the last block computed for every token
     # (option full_last_block), so the line shows what the CLS-only tail is worth.
     full_value = None
     full_last = bool(os.environ.get("AP_VIT_FULL_LAST_BLOCK"))      # the default the encoder object was created with
-    if world == 1 and not full_last:
+    cls_tail_possible = geo["executed"] != geo["model"]
+    if world == 1 and not full_last and cls_tail_possible:
         ex.vit.set_option("full_last_block", True)
         try:
             step(0, feats[:B])
@@ -467,9 +592,9 @@ def main():
     # ---- roofline of the dominant kernel: the fc1 GEMM (gemm256_kernel<T, EPI_NORM_GELU>: LayerNorm statistics + GELU in
     #      the epilogue; <T, EPI_BIAS_GELU> with the f32-stream dataflow), one shape per launch
     fc1_tag = "Li5E" if fused else "Li1E"
-    M = B * 197
+    M = B * T
     fc1_ms, fc1_n = prof["gemm_fc1"]
-    flop_launch = 2.0 * M * 3072 * 768
+    flop_launch = 2.0 * M * MLP * D
     fc1_avg_s = (fc1_ms / max(1, fc1_n)) * 1e-3
     achieved = flop_launch / fc1_avg_s / 1e12 if fc1_n else 0.0
     peak = MFMA_PEAK[short] / 1e12
@@ -479,7 +604,8 @@ def main():
     import glob
     tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))      # the latest round's PMC summary
     tpath = tfiles[-1] if tfiles else ""
-    if short != "f32" and B == 2048 and tpath and os.path.exists(tpath):
+    pmc_shape = short != "f32" and B == 2048 and args.encoder == "vit_b_16"      # the shape the committed PMC passes ran
+    if pmc_shape and tpath and os.path.exists(tpath):
         with open(tpath) as fh:
             for kname, rec in json.load(fh).items():
                 if "gemm256_kernel" in kname and fc1_tag in kname and ("DF16_" in kname) == (short == "f16"):
@@ -488,7 +614,7 @@ def main():
     # (SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE; tools/pmc_mfma.py -> profiles/): frac ~= mfma_util * clock / 2.4 GHz
     pmc_mfma = None
     mfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mfma_util.json")))
-    if short != "f32" and B == 2048 and mfiles:
+    if pmc_shape and mfiles:
         with open(mfiles[-1]) as fh:
             for kname, rec in json.load(fh).items():
                 if "gemm256_kernel" in kname and fc1_tag in kname and ("DF16_" in kname) == (short == "f16"):
@@ -497,19 +623,21 @@ def main():
                                 "source": os.path.basename(mfiles[-1])}
     kernel_ms = {k: round(v[0] / K, 4) for k, v in prof.items()}
     # the HBM-bound kernels of the path, same HIP-event timers, algorithmic bytes:
-    #   preprocess: reads the 224x224x3 u8 centre crop, writes the [196, 768] patch matrix in the compute dtype
+    #   preprocess: reads the S x S x 3 u8 centre crop, writes the [T - 1, 3 * 16 * 16] patch matrix in the compute dtype
     #   add+LayerNorm: per block LN1 (f32 stream + one pending branch in, normalised rows out; the first block has no
     #   pending branch) and LN2 (stream + two branches in, stream + normalised rows out); the final LN touches CLS rows only
     eb = 2.0 if short != "f32" else 4.0
-    pre_bytes = B * 150528.0 * (1.0 + eb)
-    ln_blocks = 12 if full_last else 11          # the last block's LN2 runs on the CLS rows only (timed under cls_tail)
-    ln_bytes = M * 768.0 * (ln_blocks * ((4 + eb + eb) + (4 + 2 * eb + 4 + eb)) + (0 if full_last else 4 + eb + eb) - eb)
+    L = arch["depth"]
+    pre_bytes = B * 3.0 * arch["image_size"] ** 2 * (1.0 + eb)
+    tail = cls_tail_possible and not full_last
+    ln_blocks = L - 1 if tail else L             # the last block's LN2 runs on the CLS rows only (timed under cls_tail)
+    ln_bytes = M * float(D) * (ln_blocks * ((4 + eb + eb) + (4 + 2 * eb + 4 + eb)) + (4 + eb + eb if tail else 0) - eb)
     if fused:
         # fused dataflow: no add+LayerNorm pass and no stream initialisation pass (the patch-embed GEMM writes the T stream and
         # its partial sums).  What is timed under "layernorm" are the statistic finalisations -- one after the patch
-        # embedding, two per fused block minus the last ([M, 12, 2] f32 partial sums in, [M, 2] out) -- and the class-token
+        # embedding, two per fused block minus the last ([M, D/64, 2] f32 partial sums in, [M, 2] out) -- and the class-token
         # rows; the stream itself moves inside the proj / fc2 epilogues (2 B read + 2 B written per element)
-        ln_bytes = (24 if full_last else 23) * M * (12 * 8 + 8.0) + B * 768.0 * (8 + eb)
+        ln_bytes = (2 * L - 1 if tail else 2 * L) * M * (D / 64 * 8 + 8.0) + B * float(D) * (8 + eb)
     hbm_kernels = {}
     for kind, nbytes in (("preproc", pre_bytes), ("layernorm", ln_bytes)):
         ms = prof[kind][0] / K
@@ -517,59 +645,87 @@ def main():
             hbm_kernels[kind] = {"algorithmic_bytes_per_step": nbytes, "ms_per_step": round(ms, 4),
                                  "achieved_GBps": round(nbytes / (ms * 1e-3) / 1e9, 1), "peak_GBps": 8000.0,
                                  "frac": round(nbytes / (ms * 1e-3) / 8e12, 4)}
+    shape = f"[B*{T},{D}]x[{D},{MLP}]"
+    flop_exec = geo["model"] if full_last else geo["executed"]
     line = {
-        "metric": "patches/sec embedded (256x256, ViT-B/16)", "value": round(value, 1), "unit": "patches/s",
+        "metric": f"patches/sec embedded (256x256, {'ViT-B/16' if args.encoder == 'vit_b_16' else args.encoder})",
+        "value": round(value, 1), "unit": "patches/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": short,
         "data": "synthetic" if not rehearsal else "synthetic -- REHEARSAL of the N > 1 code path (ranks share one GPU, gloo): not a measurement",
         "config": {"workload": f"process: one synthetic {args.slide}x{args.slide} slide per rank, 256x256 tiles "
-                               f"resident in HBM, ViT-B/16 (random-init), device batch {B}",
+                               f"resident in HBM, {enc['label']} (random-init), device batch {B}",
+                   "encoder": args.encoder,
                    "tiles_per_step": B, "slide_tissue_tiles": int(n_slide), "grid_cells": cells,
-                   "parallelism": f"slide-per-rank x{world}" + (" + RCCL all-gather of features" if world > 1 else "")},
-        "roofline": {"bound": "mfma", "kernel": (("gemm256_kernel<T,EPI_NORM_GELU> (fc1 with the LayerNorm statistics applied "
-                                                          "in the epilogue: [B*197,768]x[768,3072], " if fused else
-                                                          "gemm256_kernel<T,EPI_BIAS_GELU> (fc1: [B*197,768]x[768,3072], ") +
+                   "parallelism": f"slide-per-rank x{world}" + (" + RCCL all-gather of features" if world > 1 else ""),
+                   "gpus_requested": args.gpus, "ranks_in_process_group": world},
+        "roofline": {"bound": "mfma", "kernel": ((f"gemm256_kernel<T,EPI_NORM_GELU> (fc1 with the LayerNorm statistics applied "
+                                                          f"in the epilogue: {shape}, " if fused else
+                                                          f"gemm256_kernel<T,EPI_BIAS_GELU> (fc1: {shape}, ") +
                                                          "persistent 256x256-tile MFMA GEMM)") if short != "f32" else
-                                                        ("gemm_kernel<float,EPI_BIAS_GELU> (fc1: [B*197,768]x[768,3072], "
+                                                        (f"gemm_kernel<float,EPI_BIAS_GELU> (fc1: {shape}, "
                                                          "128x128-tile v_mfma_f32_32x32x2_f32 GEMM)"),
                      "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "TFLOP/s",
                      "frac": round(achieved / peak, 4), "traffic": traffic,
                      "traffic_source": (f"profiles/{os.path.basename(tpath)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                         "this command, committed; not measured in this run)") if traffic is not None else None,
                      "pmc": pmc_mfma,
-                     "algorithmic_bytes_per_launch": (M * 768 + 3072 * 768 + M * 3072) * (4.0 if short == "f32" else 2.0) +
-                                                     (M * 8.0 + 3072 * 8.0 if fused else 0.0),
+                     "algorithmic_bytes_per_launch": (M * D + MLP * D + M * MLP) * (4.0 if short == "f32" else 2.0) +
+                                                     (M * 8.0 + MLP * 8.0 if fused else 0.0),
                      "avg_launch_ms": round(fc1_avg_s * 1e3, 4), "launches": fc1_n,
                      "algorithmic_flop_per_launch": flop_launch},
-        "end_to_end_model_tflops": round(value * (FLOP_PER_PATCH_VIT_B16 if full_last else FLOP_PER_PATCH_EXECUTED) / 1e12 / world, 1),
-        "flop_per_patch": {"model": FLOP_PER_PATCH_VIT_B16, "executed": FLOP_PER_PATCH_VIT_B16 if full_last else FLOP_PER_PATCH_EXECUTED,
+        "end_to_end_model_tflops": round(value * flop_exec / 1e12 / world, 1),
+        "flop_per_patch": {"model": geo["model"], "executed": flop_exec,
                            "note": "last block: K/V for all tokens, the rest for the CLS row only (identical features); "
-                                   "option full_last_block (AP_VIT_FULL_LAST_BLOCK=1 at start) computes it for every token",
+                                   "option full_last_block (AP_VIT_FULL_LAST_BLOCK=1 at start) computes it for every token"
+                                   if cls_tail_possible else "every block for every token (attentional pooler reads all tokens)",
                            "value_with_full_last_block": None if full_value is None else round(full_value, 1)},
         "dataflow": ("fused_layernorm: residual stream in the compute type, LayerNorm folded into the qkv / fc1 GEMMs, residual "
                      "add + row sums in the proj / fc2 epilogues" if fused else "f32 residual stream + add+LayerNorm launches"),
         "f32_stream_dataflow": f32s,
         "kernel_ms_per_step": kernel_ms, "hbm_kernels": hbm_kernels,
-        "coords": {"cells": cells, "rows": int(n_slide), "seconds": round(coords_s, 4),
-                   "cells_per_s": round(cells / coords_s, 1)},
+        "coords": {"cells": cells, "rows": int(n_slide), **coords_stats,
+                   "cells_per_s": round(cells / coords_stats["warm_seconds_median"], 1),
+                   "what": "mask -> contours -> grid scan -> rows on the host, one slide; warm = median of 10 repeats after the "
+                           "first (cold) call"},
     }
+    if per_rank is not None:
+        line["per_rank"] = per_rank
+        line["all_gather"] = {"bytes_per_rank": int(K * B * ex.embedding_dim * 4), "ms_max_over_ranks": max(r["all_gather_ms"] for r in per_rank),
+                              "what": "one all_gather_into_tensor of every rank's float32 [K*B, D] block, inside the timed region"}
     if not args.no_cpu_baseline and world == 1:          # the CPU leg runs at N = 1 only
-        out_cpu, hf, patches, cpu_rate, cpu_threads = cpu_baseline(args.cpu_sample, seed=0)
+        sample = args.cpu_sample if args.cpu_sample else {"vit_b_16": 192, "uni_v1": 64, "conch_v1": 32}[args.encoder]
+        out_cpu, patches, cpu_rate, cpu_threads = cpu_baseline(args.encoder, sample, seed=0)
         # parity of the measured path against the CPU oracle on the same sample (reported, not timed)
-        got = ex.extract_batch(patches, batch_size=32)
-        rel = float(np.linalg.norm(got.astype(np.float64) - out_cpu) / np.linalg.norm(out_cpu))
+        relf = lambda got: float(np.linalg.norm(got.astype(np.float64) - out_cpu) / np.linalg.norm(out_cpu))
+        rel = relf(ex.extract_batch(patches, batch_size=32))
         line["cpu_baseline"] = {"value": round(cpu_rate, 2), "unit": "patches/s",
                                 "cores": int(cpu_threads), "kind": "port",
-                                "sample": f"{args.cpu_sample} random 256x256 tiles, ViT-B/16 fp32, torch CPU oracle "
-                                          f"(oracle/vit_oracle.py), batch 32, at the fastest of 8/16/32/64 torch threads "
+                                "sample": f"{sample} random 256x256 tiles, {enc['label']} fp32, torch CPU oracle "
+                                          f"(oracle/vit_oracle.py), at the fastest of 8/16/32/64 torch threads "
                                           f"(host has {os.cpu_count()} hardware threads)",
                                 "rel_err_gpu_vs_cpu": rel}
-        cpu_coords, cpu_coords_s = cpu_coords_baseline(args.slide, 1234 + rank)
+        # ... and of the other modes of the same encoder on the same sample: the f32-stream dataflow, the exact-f32 mode
+        errs = {("fused_layernorm" if fused else "f32_stream") + "_" + short: rel}
+        if fused:
+            ex.vit.set_option("f32_stream", True)
+            try:
+                errs["f32_stream_" + short] = relf(ex.extract_batch(patches, batch_size=32))
+            finally:
+                ex.vit.set_option("f32_stream", False)
+        if short != "f32" and arch.get("pool") != "attn":          # conch_v1 is registered for f16 / bf16 only
+            ex32 = build_hip_vit_extractor(name=args.encoder, arch=args.encoder, device=device, dtype=torch.float32,
+                                           random_init_seed=0, max_batch=min(B, 256), resize=TRANSFORM_RESIZE[args.encoder],
+                                           expect_size=None, mean=enc.get("mean"), std=enc.get("std"))
+            errs["float32_mode"] = relf(ex32.extract_batch(patches, batch_size=32))
+            ex32.cleanup()
+        line["cpu_baseline"]["rel_err_by_mode"] = errs
+        cpu_coords, cpu_coords_s = cpu_coords_baseline(args.slide, args.slide_seed + rank)
         line["cpu_baseline"]["coords"] = {"cells_per_s": round(cells / cpu_coords_s, 1), "seconds": round(cpu_coords_s, 3),
                                           "cores": 1, "kind": "port",
                                           "sample": "the bench slide's mask through oracle/coords_oracle.py (NumPy)",
                                           "rows_equal_device_path": bool(np.array_equal(np.asarray(cpu_coords), np.asarray(dev_coords)))}
-    if not args.no_extras and world == 1:
+    if not args.no_extras and world == 1 and args.encoder == "vit_b_16":
         line["rates"] = {"kernel_only": {"patches_per_s": round(value, 1), "what": "= value"}}
         line["rates"].update(secondary_rates(device, ex, tiles, B))
     print(json.dumps(line), flush=True)

@@ -1,0 +1,75 @@
+"""bench.py's launch path: `--gpus N` without a launcher, `--encoder`, and the N > 1 branch (BASELINE configs 4 / 5:
+slide-per-rank + one all-gather of the feature blocks; reference story: README.md:527,628 = separate jobs per GPU,
+orchestration/runner.py:154-167 lock files)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "AP_BENCH_BACKEND",
+                                                            "AP_BENCH_ONE_GPU")}
+    res = subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + "\n" + res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_encoder_geometry_matches_the_surveyed_flop_counts():
+    """ViT-B/16 35.126 GFLOP per tile (33.695 GEMM + 1.431 attention), ViT-L/16 123.107, CONCH ~157."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from atlaspatch_amd.encoders.vit import ARCHS
+    g = bench.encoder_geometry(ARCHS["vit_b_16"])
+    assert g["tokens"] == 197 and abs(g["model"] / 1e9 - 35.126) < 1e-3 and abs(g["executed"] / 1e9 - 32.695) < 1e-3
+    g = bench.encoder_geometry(ARCHS["uni_v1"])
+    assert g["tokens"] == 197 and abs(g["model"] / 1e9 - 123.107) < 1e-3 and g["executed"] < g["model"]
+    g = bench.encoder_geometry(ARCHS["conch_v1"])
+    assert g["tokens"] == 785 and 156 < g["model"] / 1e9 < 160 and g["executed"] == g["model"]
+    assert set(bench.ENCODERS) == {"vit_b_16", "uni_v1", "conch_v1"}
+
+
+@pytest.mark.gpu
+def test_gpus_2_without_a_launcher_runs_two_ranks_and_gathers_both_feature_blocks(tmp_path):
+    """`python bench.py --gpus 2` (no torchrun in front): bench re-executes itself under torch.distributed.run with two
+    ranks; on a one-GPU box they share cuda:0 and the collective goes through gloo (marked as a rehearsal).  The matrix
+    the all-gather assembles must be the two single-rank matrices, rank 0's block first, bit for bit."""
+    common = ["--steps", "2", "--warmup", "1", "--batch", "64", "--slide", "12000", "--no-extras", "--no-cpu-baseline"]
+    both = _run(["--gpus", "2", "--dump-features", str(tmp_path / "g.npy")] + common)
+    assert both["n_gpus"] == 2 and both["config"]["ranks_in_process_group"] == 2 and both["config"]["gpus_requested"] == 2
+    assert [r["rank"] for r in both["per_rank"]] == [0, 1]
+    assert [r["slide_seed"] for r in both["per_rank"]] == [1234, 1235]
+    assert all(r["patches_per_s"] > 0 and r["all_gather_ms"] > 0 for r in both["per_rank"])
+    assert both["all_gather"]["bytes_per_rank"] == 2 * 64 * 768 * 4
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert "REHEARSAL" in both["data"]
+    gathered = np.load(tmp_path / "g.npy")
+    assert gathered.shape == (2 * 2 * 64, 768)
+    for r, seed in enumerate((1234, 1235)):
+        one = _run(["--gpus", "1", "--slide-seed", str(seed), "--dump-features", str(tmp_path / f"s{r}.npy")] + common)
+        assert one["n_gpus"] == 1 and "per_rank" not in one and one["data"] == "synthetic"
+        single = np.load(tmp_path / f"s{r}.npy")
+        assert single.shape == (2 * 64, 768) and np.isfinite(single).all() and np.abs(single).max() > 0
+        assert np.array_equal(gathered[r * 128:(r + 1) * 128], single), f"rank {r}'s block differs from its single-rank run"
+    assert not np.array_equal(gathered[:128], gathered[128:])          # the two ranks embedded different slides
+
+
+@pytest.mark.gpu
+def test_encoder_option_runs_conch_fp16_with_its_own_roofline_shape():
+    """Config 5's encoder (CONCH v1 visual tower, fp16, 785 tokens) has a bench line of its own."""
+    line = _run(["--encoder", "conch_v1", "--steps", "2", "--warmup", "1", "--batch", "32", "--slide", "12000", "--no-extras",
+                 "--cpu-sample", "4"])
+    assert line["config"]["encoder"] == "conch_v1" and "conch_v1" in line["metric"] and line["dtype"] == "f16"
+    assert "[B*785,768]x[768,3072]" in line["roofline"]["kernel"]
+    assert line["roofline"]["algorithmic_flop_per_launch"] == 2.0 * 32 * 785 * 3072 * 768
+    assert 0 < line["roofline"]["frac"] < 1 and line["value"] > 0
+    assert line["cpu_baseline"]["rel_err_gpu_vs_cpu"] < 3e-3

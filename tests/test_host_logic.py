@@ -577,3 +577,60 @@ def test_h5_file_equals_the_file_the_references_writer_makes_with_real_h5py(tmp_
     got["file_attrs"].pop("creation_date", None)
     assert got["datasets"] == want["datasets"]
     assert got["file_attrs"] == want["file_attrs"]
+
+
+def _fake_sysfs(root, *, nodes, smt, gpu_nodes):
+    """nodes: {node: [cpus]}; smt: {cpu: sibling}; gpu_nodes: {bdf: node}."""
+    for node, cpus in nodes.items():
+        d = root / "devices/system/node" / f"node{node}"
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(",".join(str(c) for c in cpus) + "\n")
+    for cpu, sib in smt.items():
+        d = root / "devices/system/cpu" / f"cpu{cpu}" / "topology"
+        d.mkdir(parents=True)
+        (d / "thread_siblings_list").write_text(f"{min(cpu, sib)},{max(cpu, sib)}\n")
+    for bdf, node in gpu_nodes.items():
+        d = root / "bus/pci/devices" / bdf
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text(f"{node}\n")
+
+
+def test_pin_order_is_numa_local_first_and_disjoint_across_local_ranks(tmp_path):
+    """The ring's decode threads (north star: 'tile decode on host cores pinned'): the GPU's NUMA node first, physical
+    cores before SMT siblings, and the ranks of one node take DISJOINT cores (every rank used to pin to the
+    same cores because the PCI address lookup raised and the counter started at 0 in every rank)."""
+    from atlaspatch_amd.services.tile_ring import _pin_order
+    # 2 sockets x 8 cores x 2 threads: cpus 0-7 / 8-15 are the cores, 16-23 / 24-31 their SMT siblings
+    nodes = {0: list(range(0, 8)) + list(range(16, 24)), 1: list(range(8, 16)) + list(range(24, 32))}
+    smt = {c: c + 16 for c in range(16)}
+    smt.update({c + 16: c for c in range(16)})
+    gpus = {"0000:05:00.0": 0, "0000:85:00.0": 1}
+    _fake_sysfs(tmp_path, nodes=nodes, smt=smt, gpu_nodes=gpus)
+    allowed = set(range(32))
+    kw = dict(sysfs=str(tmp_path), allowed=allowed)
+    one = _pin_order(None, bdf="0000:05:00.0", local_rank=0, local_world=1, **kw)
+    assert one == list(range(0, 8)) + list(range(8, 16)) + list(range(16, 24)) + list(range(24, 32))
+    other = _pin_order(None, bdf="0000:85:00.0", local_rank=0, local_world=1, **kw)
+    assert other[:8] == list(range(8, 16)) and other[8:16] == list(range(0, 8))
+    # four ranks, two per socket: the first cores each rank would take (1 + workers) never collide
+    orders = [_pin_order(None, bdf=b, local_rank=r, local_world=4, **kw)
+              for r, b in enumerate(["0000:05:00.0", "0000:05:00.0", "0000:85:00.0", "0000:85:00.0"])]
+    heads = [tuple(o[:2]) for o in orders]
+    assert heads == [(0, 4), (1, 5), (10, 14), (11, 15)]
+    flat = [c for h in heads for c in h]
+    assert len(set(flat)) == len(flat)
+    for o, node in zip(orders, (0, 0, 1, 1)):
+        assert set(o[:2]) <= set(nodes[node]) and len(set(o)) == len(o) == 8
+    assert not (set(orders[0]) & set(orders[1])) and not (set(orders[2]) & set(orders[3]))
+    # a restricted affinity mask is honoured; an unknown device falls back to "every allowed CPU is local"
+    assert _pin_order(None, bdf="0000:05:00.0", local_rank=0, local_world=1, sysfs=str(tmp_path), allowed={2, 3, 18, 9}) == [2, 3, 9, 18]
+    assert _pin_order(None, bdf="ffff:ff:1f.0", local_rank=0, local_world=1, **kw)[:16] == list(range(16))
+    # LOCAL_RANK / LOCAL_WORLD_SIZE from the launcher's environment
+    import os
+    old = {k: os.environ.get(k) for k in ("LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    os.environ.update(LOCAL_RANK="1", LOCAL_WORLD_SIZE="4")
+    try:
+        assert _pin_order(None, bdf="0000:05:00.0", **kw) == orders[1]
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)

@@ -107,6 +107,10 @@ SIGNATURES = {
                                  C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]),
     "ap_synth_tiles": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                  C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "ap_host_openslide_available": (C.c_int, []),
+    "ap_host_openslide_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "ap_host_openslide_read_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ap_host_openslide_close": (None, [C.c_void_p]),
 }
 
 

@@ -33,6 +33,7 @@ from .services.segmentation import AnalyticSegmentationService, SAM2Segmentation
 from .services.visualization import DefaultVisualizationService
 from .services.wsi_loader import DefaultWSILoader
 from .utils.features import parse_feature_list
+from .utils.stages import stage
 from .utils.params import get_wsi_files
 
 logging.basicConfig(level=logging.WARNING, format="%(asctime)s | %(levelname)s | %(name)s | %(message)s")
@@ -128,7 +129,8 @@ def _run_pipeline(*, wsi_path, output, patch_size, step_size, target_mag, device
                               mpp_resolver=CSVMPPResolver(app_cfg.processing.mpp_csv), wsi_loader=loader,
                               show_progress=not verbose, rank=rank, world_size=world)
     try:
-        results, failures = runner.run()
+        with stage("phase1_segment_and_coords"):
+            results, failures = runner.run()
     finally:
         segmenter.close()
     click.echo("Segmentation and patch coordinate extraction complete.")
@@ -138,7 +140,8 @@ def _run_pipeline(*, wsi_path, output, patch_size, step_size, target_mag, device
         units = len(results) * len(app_cfg.features.extractors)
         bar = tqdm(total=units, desc="Feature embedding", disable=verbose or units == 0)
         try:
-            failures.extend(service.embed_all(results, wsi_loader=loader, progress=bar))
+            with stage("phase2_embed_all"):
+                failures.extend(service.embed_all(results, wsi_loader=loader, progress=bar))
         finally:
             bar.close()
         if world > 1 and os.environ.get("ATLASPATCH_GATHER_FEATURES"):
@@ -149,10 +152,16 @@ def _run_pipeline(*, wsi_path, output, patch_size, step_size, target_mag, device
             # every slide assigned to this rank whose H5 is on disk -- also those a --skip-existing rerun found complete
             # (they never enter `results`); slides without a usable feature set are skipped inside, never raised on
             from .core.paths import patch_h5_path
-            mine = [p for p in (patch_h5_path(s, app_cfg.output, app_cfg.extraction) for s in runner.discover_slides())
-                    if p.exists()]
-            gather_run_features(mine, [e.lower() for e in app_cfg.features.extractors], app_cfg.output.output_root,
-                                device=dev, cache=service.feature_blocks)
+            # ... except slides that FAILED in this run (segmentation, coords or embedding): an H5 left by an earlier run would
+            # otherwise contribute stale features with nothing in index.json to show it
+            failed = {Path(slide.path).resolve() for slide, _ in failures}
+            mine = [p for s, p in ((s, patch_h5_path(s, app_cfg.output, app_cfg.extraction)) for s in runner.discover_slides())
+                    if p.exists() and Path(s.path).resolve() not in failed]
+            try:
+                gather_run_features(mine, [e.lower() for e in app_cfg.features.extractors], app_cfg.output.output_root,
+                                    device=dev, cache=service.feature_blocks)
+            finally:
+                service.feature_blocks.clear()          # the per-slide float32 matrices are not needed past the gather
     return results, failures
 
 

@@ -97,6 +97,7 @@ class OpenSlideWSI(IWSI):
             raise RuntimeError("openslide-python is not installed; the OpenSlide backend is unavailable")
         super().__init__(path=path, mpp=mpp)
         self._slide = None
+        self._native = None            # ap_openslide handle of the batched native reader; False = not available
 
     def _setup(self) -> None:
         self._slide = openslide.OpenSlide(self.path)
@@ -128,6 +129,36 @@ class OpenSlideWSI(IWSI):
             return np.array(region)
         raise ValueError(f"Invalid mode: {mode}")
 
+    def read_tiles_into(self, rows, dst_ptr: int, tile_side: int) -> bool:
+        """Optional IWSI capability (native batched host read): the tiles of ``rows`` (x, y, rw, rh, lv) are read by
+        libopenslide itself and converted to RGB into consecutive ``tile_side^2 * 3``-byte slots at ``dst_ptr`` in ONE call
+        outside the interpreter lock (``ap_host_openslide_read_tiles``) -- the same pixels as ``extract`` =
+        ``read_region(...).convert("RGB")`` (openslide_wsi.py:184-205).  False when libopenslide does not resolve or the
+        rows are not one level / one square size: the ring then reads tile by tile through openslide-python."""
+        import ctypes as C
+        import os
+        from ... import _lib
+        self._ensure_loaded()
+        if not rows:
+            return True
+        if self._native is False or os.environ.get("ATLASPATCH_OPENSLIDE_NATIVE", "1") == "0":
+            return False
+        lv0 = int(rows[0][4])
+        if any(int(r[2]) != tile_side or int(r[3]) != tile_side or int(r[4]) != lv0 for r in rows):
+            return False
+        lib = _lib.load()
+        if self._native is None:
+            handle = C.c_void_p()
+            code = lib.ap_host_openslide_open(str(self.path).encode(), C.byref(handle))
+            if code != _lib.AP_OK:         # no libopenslide on this host (or it cannot open what openslide-python opened)
+                self._native = False
+                return False
+            self._native = handle
+        xy = np.ascontiguousarray([[r[0], r[1]] for r in rows], dtype=np.int64)
+        _lib.check(lib.ap_host_openslide_read_tiles(self._native, xy.ctypes.data, len(rows), lv0, tile_side, tile_side, dst_ptr),
+                   "ap_host_openslide_read_tiles")
+        return True
+
     def get_size(self, lv: int = 0) -> Tuple[int, int]:
         self._ensure_loaded()
         if lv < 0 or lv >= self.nlvl:
@@ -139,6 +170,10 @@ class OpenSlideWSI(IWSI):
         return self._slide.get_thumbnail(max_hw).convert("RGB")
 
     def cleanup(self) -> None:
+        if self._native not in (None, False):
+            from ... import _lib
+            _lib.load().ap_host_openslide_close(self._native)
+        self._native = None
         if self._slide is not None:
             try:
                 self._slide.close()

@@ -172,6 +172,10 @@ class SynthWSI(IWSI):
         if code == _lib.AP_ERR_UNSUPPORTED:                # no usable libjpeg on this host: per-tile Pillow decode
             self._jpeg_native = False
             return False
+        if code == _lib.AP_ERR_INVALID:
+            # a tile the native decoder refuses (wrong size, or libjpeg WARNED: truncated / corrupt stream): this chunk goes
+            # through the per-tile Pillow path, which raises or decodes exactly as the reference's reader would
+            return False
         _lib.check(code, "ap_host_decode_jpeg_tiles")
         return True
 

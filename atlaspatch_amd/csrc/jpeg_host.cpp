@@ -140,7 +140,12 @@ void on_error(void* cinfo) {
     snprintf(e->text, sizeof(e->text), "%s", buf);
     longjmp(e->jb, 1);
 }
-void on_message(void*, int) {}
+// libjpeg reports recoverable stream damage (premature end of data, bad Huffman code, ...) as WARNINGS (msg_level < 0):
+// it injects a fake EOI / grey blocks and carries on.  Pillow raises on such a tile ("image file is truncated"), so a
+// damaged tile must fail here too instead of being embedded as grey pixels: count the warnings, check after decoding.
+void on_message(void* cinfo, int msg_level) {
+    if (msg_level < 0) ((jpeg_decompress_struct*)cinfo)->err->num_warnings++;
+}
 
 Api g_api;
 std::once_flag g_once;
@@ -180,7 +185,12 @@ int decode_one(const Api& api, const unsigned char* data, size_t size, int want_
         api.read_scanlines(&c, rows, nrows);
     }
     api.finish(&c);
+    const long warnings = err.pub.num_warnings;
     api.destroy(&c);
+    if (warnings > 0) {
+        snprintf(why, why_cap, "libjpeg reported %ld warning(s): truncated or corrupt JPEG stream", warnings);
+        return -1;
+    }
     return 0;
 }
 

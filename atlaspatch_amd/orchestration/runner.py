@@ -30,6 +30,8 @@ from ..utils.features import missing_features
 from ..utils.h5 import h5
 from ..utils.params import get_wsi_files
 
+from ..utils.stages import stage
+
 logger = logging.getLogger("atlaspatch_amd.runner")
 
 
@@ -149,7 +151,8 @@ class ProcessingRunner:
                     tick()
                     continue
                 try:
-                    opened.append((slide, self.wsi_loader.open(slide), fd, lock_path))
+                    with stage("open_slide"):
+                        opened.append((slide, self.wsi_loader.open(slide), fd, lock_path))
                 except Exception as exc:  # noqa: BLE001
                     failures.append((slide, exc))
                     logger.error("Failed to open %s: %s", slide.path.name, exc)
@@ -159,8 +162,9 @@ class ProcessingRunner:
                 continue
             try:
                 wsis = [w for _, w, _, _ in opened]
-                masks = (self.segmentation.segment_batch(wsis) if len(wsis) > 1
-                         else [self.segmentation.segment_thumbnail(wsis[0])])
+                with stage("segmentation"):
+                    masks = (self.segmentation.segment_batch(wsis) if len(wsis) > 1
+                             else [self.segmentation.segment_thumbnail(wsis[0])])
             except Exception as exc:  # noqa: BLE001
                 for slide, wsi, fd, lock_path in opened:
                     failures.append((slide, exc))
@@ -171,9 +175,11 @@ class ProcessingRunner:
                 continue
             for (slide, wsi, fd, lock_path), mask in zip(opened, masks):
                 try:
-                    result = self.extractor.extract(wsi, mask.data, slide=slide)
+                    with stage("coords_and_h5"):
+                        result = self.extractor.extract(wsi, mask.data, slide=slide)
                     if self.visualizer is not None:
-                        self.visualizer.visualize(result, wsi=wsi, mask=mask.data)
+                        with stage("visualize"):
+                            self.visualizer.visualize(result, wsi=wsi, mask=mask.data)
                     results.append(result)
                 except Exception as exc:  # noqa: BLE001
                     failures.append((slide, exc))

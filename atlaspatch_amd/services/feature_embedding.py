@@ -27,6 +27,7 @@ from ..encoders.base import HipViTFeatureExtractor
 from ..encoders.custom import register_feature_extractors_from_module
 from ..encoders.registry import PatchFeatureExtractorRegistry
 from ..utils.features import get_existing_features
+from ..utils.stages import stage
 from .interfaces import FeatureEmbeddingService
 from .storage import H5PatchWriter, read_coords
 
@@ -188,13 +189,15 @@ class PatchFeatureEmbeddingService(FeatureEmbeddingService):
             attrs = {"name": extractor.name, "embedding_dim": extractor.embedding_dim}
             writer = self._writer(result, wsi)
             if isinstance(extractor, HipViTFeatureExtractor):
-                feats = self.embed_matrix(result, wsi, extractor)
+                with stage("embed_matrix"):
+                    feats = self.embed_matrix(result, wsi, extractor)
                 if self._keep_blocks:
                     self.feature_blocks[(str(result.h5_path), extractor.name.lower())] = feats
-                writer.append_feature_matrix(output_path=result.h5_path, feature_name=extractor.name,
-                                             features=feats, feature_attrs=attrs,
-                                             feature_batch=self.feature_cfg.batch_size,
-                                             expected_total=result.num_patches)
+                with stage("h5_features"):
+                    writer.append_feature_matrix(output_path=result.h5_path, feature_name=extractor.name,
+                                                 features=feats, feature_attrs=attrs,
+                                                 feature_batch=self.feature_cfg.batch_size,
+                                                 expected_total=result.num_patches)
             else:
                 writer.append_features(output_path=result.h5_path, entries=self._entries(wsi, result),
                                        feature_name=extractor.name,
@@ -241,8 +244,9 @@ class PatchFeatureEmbeddingService(FeatureEmbeddingService):
                 ring.device != extractor.device:
             if ring is not None:
                 ring.close()
-            self._ring = ring = TileRing(device=extractor.device, batch=batch, patch_size=ps, tile_hw=tile_hw,
-                                         slots=3, workers=max(1, self.feature_cfg.num_workers))
+            with stage("ring_build"):
+                self._ring = ring = TileRing(device=extractor.device, batch=batch, patch_size=ps, tile_hw=tile_hw,
+                                             slots=3, workers=max(1, self.feature_cfg.num_workers))
 
         def read(x, y, rw_, rh_, lv):
             return wsi.extract((x, y), lv=lv, wh=(rw_, rh_), mode="array")
@@ -286,7 +290,8 @@ class PatchFeatureEmbeddingService(FeatureEmbeddingService):
 
         for name in self.extractor_names:
             try:
-                extractor = self.registry.create(name)
+                with stage("encoder_create"):
+                    extractor = self.registry.create(name)
             except Exception as exc:  # noqa: BLE001
                 for res in results:
                     if name in todo.get(res.h5_path, ()):

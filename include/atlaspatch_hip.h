@@ -81,6 +81,22 @@ int ap_host_inflate_tiles(void* dst, const char* const* paths, int n, size_t byt
  * AP_ERR_INVALID for a tile that is not side x side or not decodable. */
 int ap_host_decode_jpeg_tiles(void* dst, const char* const* paths, int n, int side);
 
+/* The same for a slide OpenSlide can open (the reference's production tile source): core/wsi/openslide_wsi.py:184-205 reads
+ * one region per call in the interpreter -- openslide-python's read_region (premultiplied ARGB -> RGBA in its C helper, a
+ * PIL image) + .convert("RGB") + np.array.  ap_host_openslide_read_tiles reads n regions of w x h pixels at `level` with
+ * libopenslide's own openslide_read_region (thread-safe on one handle) and writes packed RGB into consecutive w*h*3-byte
+ * slots: un-premultiplied exactly as openslide-python does (alpha 255: as stored; 0 < alpha < 255: (uint8)(255 * c / alpha);
+ * alpha 0: the word's bytes as they lie, i.e. black for a premultiplied buffer), alpha dropped as PIL's RGBA -> RGB does.
+ * xy: HOST int64 [n, 2] level-0 coordinates of the regions' top-left corners (openslide's convention).
+ * libopenslide is resolved at first use by dlopen ($ATLASPATCH_LIBOPENSLIDE = explicit path, else libopenslide.so.1 /
+ * .so.0 / .so): ap_host_openslide_available() = 1 / 0; without it open returns AP_ERR_UNSUPPORTED and the caller keeps the
+ * per-tile openslide-python path.  The handle is independent of any openslide-python object on the same file. */
+typedef struct ap_openslide ap_openslide;
+int ap_host_openslide_available(void);
+int ap_host_openslide_open(const char* path, ap_openslide** out);
+int ap_host_openslide_read_tiles(ap_openslide* slide, const int64_t* xy, int n, int level, int w, int h, void* dst_rgb);
+void ap_host_openslide_close(ap_openslide* slide);
+
 /* Host twin of ap_synth_tiles (below): renders n square tiles of a synthetic slide into consecutive slots of a pinned
  * staging buffer, outside the interpreter lock -- the synthetic slide's "native decoder" behind the ring's batched read
  * hook, so the host -> ring -> HBM path can be driven at full rate on the 100 000 x 100 000 slide.  xy: HOST int32 [n, 2]

@@ -461,6 +461,135 @@ def gen_extract_batch_lowp(out_dir):
     np.savez_compressed(out_dir / "extract_batch_lowp.npz", **arrays)
 
 
+STRESS_BLOCKS = (2, 5, 8)
+STRESS_CHANNELS = (7, 300, 511)
+STRESS_GAIN = 50.0
+
+
+def gen_extract_batch_stress(out_dir):
+    """G1c: trained-like stress for the 16-bit modes, with the envelope taken from the REFERENCE's own 16-bit runs.
+
+    (a) "massive": the seeded depth-12 HF ViT of G1 with the fc2 rows of channels 7 / 300 / 511 scaled x50 in blocks 2, 5
+        and 8 -- those channels of the residual stream then carry activations two orders of magnitude above the rest
+        from block 2 on (the "massive activations" of trained ViTs), which is where a 16-bit residual stream and a
+        LayerNorm folded into the next GEMM lose most.
+    (b) "layerscale": a 24-block ViT-L/16 with LayerScale at UNI's init value 1e-5 (models/patch/uni.py:35), as a plain
+        torch module with timm's forward order (norm1 -> qkv -> sdpa -> proj -> ls1 -> + ; norm2 -> fc1 -> GELU -> fc2 ->
+        ls2 -> +), weights = atlaspatch_amd.encoders.vit.random_canonical_state_dict(ARCHS["uni_v1"], seed=31).
+    Both run through the reference's PatchFeatureExtractor.extract_batch in float32, float16 and bfloat16
+    (model.to(dtype), models/patch/base.py:66)."""
+    import copy
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from transformers import ViTConfig, ViTModel
+    from PIL import Image
+    from atlaspatch_amd.encoders.vit import ARCHS, random_canonical_state_dict
+
+    torch.set_num_threads(8)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
+
+    def crop_preprocess(pil):
+        arr = np.asarray(pil, dtype=np.uint8)[16:240, 16:240, :]
+        x = torch.from_numpy(arr.copy()).permute(2, 0, 1).to(torch.float32).div(255)
+        return x.sub(mean).div(std)
+
+    def uni_preprocess(pil):                     # timm: Resize(224, bicubic) + CenterCrop(224) + ToTensor + Normalize
+        arr = np.asarray(pil.resize((224, 224), Image.Resampling.BICUBIC), dtype=np.uint8)
+        x = torch.from_numpy(arr.copy()).permute(2, 0, 1).to(torch.float32).div(255)
+        return x.sub(mean).div(std)
+
+    def run(tag, base, preprocess, forward, dim, n_patches, arrays):
+        for dtag, dt in (("f32", torch.float32), ("f16", torch.float16), ("bf16", torch.bfloat16)):
+            model = copy.deepcopy(base)
+
+            def loader(device, dtype, _m=model):
+                return ref.custom.CustomEncoderComponents(model=_m, preprocess=preprocess, forward_fn=lambda x, _mm=_m: forward(_mm, x))
+
+            reg = ref.registry.PatchFeatureExtractorRegistry()
+            ref.custom.register_custom_encoder(registry=reg, name=f"{tag}_{dtag}", embedding_dim=dim, loader=loader,
+                                               device=torch.device("cpu"), dtype=dt, num_workers=0)
+            ex = reg.create(f"{tag}_{dtag}")
+            assert next(ex.model.parameters()).dtype == dt
+            rng = np.random.default_rng(77)
+            patches = [rng.integers(0, 256, (256, 256, 3), dtype=np.uint8) for _ in range(n_patches)]
+            feats = ex.extract_batch(patches, batch_size=32)
+            assert feats.dtype == np.float32 and feats.shape == (n_patches, dim) and np.isfinite(feats).all()
+            arrays[f"{tag}_{dtag}"] = feats
+            if dtag != "f32":
+                err = np.linalg.norm(feats - arrays[f"{tag}_f32"]) / np.linalg.norm(arrays[f"{tag}_f32"])
+                print(f"  reference {tag} in {dtag}: own error vs its f32 run {err:.3e}")
+
+    arrays = {}
+    # ---- (a)
+    torch.manual_seed(0)
+    cfg = ViTConfig(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                    image_size=224, patch_size=16, layer_norm_eps=1e-6, hidden_act="gelu")
+    base = ViTModel(cfg, add_pooling_layer=False).eval()
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for n_, p in base.named_parameters():
+            if "layernorm" in n_ and n_.endswith("weight"):
+                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+            elif n_.endswith("bias") or "position_embeddings" in n_ or "cls_token" in n_:
+                p.copy_(0.02 * torch.randn(p.shape, generator=g))
+        sd = base.state_dict()
+        for blk in STRESS_BLOCKS:
+            key = next(k for k in sd if k.endswith("weight") and (f"layer.{blk}.output.dense" in k or f"layers.{blk}.mlp.fc2" in k))
+            sd[key][list(STRESS_CHANNELS), :] *= STRESS_GAIN
+    run("massive", base, crop_preprocess, lambda m, x: m(pixel_values=x).last_hidden_state[:, 0], 768, 5, arrays)
+
+    # ---- (b)
+    arch = ARCHS["uni_v1"]
+    csd = random_canonical_state_dict(arch, seed=31)
+
+    class Block(nn.Module):
+        def __init__(self, d, heads, mlp):
+            super().__init__()
+            self.heads = heads
+            self.norm1, self.norm2 = nn.LayerNorm(d, eps=1e-6), nn.LayerNorm(d, eps=1e-6)
+            self.qkv, self.proj = nn.Linear(d, 3 * d), nn.Linear(d, d)
+            self.fc1, self.fc2 = nn.Linear(d, mlp), nn.Linear(mlp, d)
+            self.ls1, self.ls2 = nn.Parameter(torch.ones(d)), nn.Parameter(torch.ones(d))
+
+        def forward(self, x):
+            n, t, d = x.shape
+            q, k, v = self.qkv(self.norm1(x)).reshape(n, t, 3, self.heads, d // self.heads).permute(2, 0, 3, 1, 4).unbind(0)
+            a = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(n, t, d)
+            x = x + self.proj(a) * self.ls1
+            return x + self.fc2(F.gelu(self.fc1(self.norm2(x)))) * self.ls2
+
+    class TimmLikeViT(nn.Module):
+        def __init__(self):
+            super().__init__()
+            d = arch["dim"]
+            self.patch = nn.Conv2d(3, d, 16, 16)
+            self.cls, self.pos = nn.Parameter(torch.zeros(1, 1, d)), nn.Parameter(torch.zeros(1, 197, d))
+            self.blocks = nn.ModuleList([Block(d, arch["heads"], arch["mlp_dim"]) for _ in range(arch["depth"])])
+            self.norm = nn.LayerNorm(d, eps=1e-6)
+
+        def forward(self, x):
+            x = self.patch(x).flatten(2).transpose(1, 2)
+            x = torch.cat([self.cls.expand(x.shape[0], -1, -1), x], 1) + self.pos
+            for b in self.blocks:
+                x = b(x)
+            return self.norm(x)[:, 0]
+
+    vit = TimmLikeViT().eval()
+    with torch.no_grad():
+        vit.patch.weight.copy_(csd["patch_embed.weight"]); vit.patch.bias.copy_(csd["patch_embed.bias"])
+        vit.cls.copy_(csd["cls_token"].view(1, 1, -1)); vit.pos.copy_(csd["pos_embed"][None])
+        vit.norm.weight.copy_(csd["norm.weight"]); vit.norm.bias.copy_(csd["norm.bias"])
+        for i, b in enumerate(vit.blocks):
+            p = f"blocks.{i}."
+            for mod, name in ((b.norm1, "ln1"), (b.norm2, "ln2"), (b.qkv, "qkv"), (b.proj, "proj"), (b.fc1, "fc1"), (b.fc2, "fc2")):
+                mod.weight.copy_(csd[p + name + ".weight"]); mod.bias.copy_(csd[p + name + ".bias"])
+            b.ls1.copy_(csd[p + "ls1"]); b.ls2.copy_(csd[p + "ls2"])
+    run("layerscale", vit, uni_preprocess, lambda m, x: m(x), 1024, 3, arrays)
+    np.savez_compressed(out_dir / "extract_batch_stress.npz", **arrays)
+
+
 def gen_features_h5(out_dir):
     """G5: features/<name> layout after the reference's own embed_all on a tiny synthetic slide."""
     import torch
@@ -585,4 +714,6 @@ if __name__ == "__main__":
         gen_extract_batch(out_dir)
     if "lowp" in which:
         gen_extract_batch_lowp(out_dir)
+    if "stress" in which:
+        gen_extract_batch_stress(out_dir)
     print("done")

@@ -115,25 +115,42 @@ def _hf_extractor(layers, dtype, **kw):
     return ex, sd
 
 
-# tolerance: features vs the CPU fp32 path.  Two statistics:
-#   norm-wise    ||a - b||_F / ||b||_F                       (TOL)
-#   element-wise max_ij |a_ij - b_ij| / (|b_ij| + 0.05 max|b|)    (ETOL; elements below 5 % of the feature scale are
-#                                                             compared on that absolute scale)
-#   float32 : BASELINE north_star tolerance 1e-3 on BOTH (exact-f32 MFMA measures ~1e-6 / ~1e-5)
-#   float16 / bfloat16, default dataflow (fused LayerNorm: the residual stream lives in the compute type, as in the
-#             reference's own model.half()): set from what is measured -- norm-wise 0.7e-3 at depth 2, 1.26e-3 at depth 12,
-#             1.56e-3 at depth 24 (f16); the REFERENCE's own float16 extract_batch measures 1.46e-3 against its float32
-#             one on the depth-12 model (golden G1b, test_lowp_error_not_above_the_references_own) -- with ~1.6 x headroom;
-#             element-wise (a maximum over 25 000 elements, heavy tailed) 1.9e-2
-#   float16 / bfloat16 with option f32_stream (float32 residual stream + standalone add+LayerNorm launches):
-#             norm-wise 0.87e-3 at depth 12, 0.93e-3 at depth 24 (TOL_F32S)
-TOL = {torch.float32: 1e-3, torch.float16: 2.5e-3, torch.bfloat16: 2e-2}
-ETOL = {torch.float32: 1e-3, torch.float16: 5e-2, torch.bfloat16: 2.5e-1}
-# the element-wise MAXIMUM is heavy tailed (one element of 25 000: 1.6e-2 .. 3.1e-2 across encoders and across two
-# equally accurate builds of the attention row sums), so it gets a loose bound and the 99.9th percentile of the same
-# statistic (measured: f16 <= 1.6e-2, bf16 <= 5.8e-2) carries the tight one
-ETOL_Q = {torch.float32: 1e-3, torch.float16: 2.5e-2, torch.bfloat16: 1e-1}
-TOL_F32S = {torch.float16: 1.5e-3, torch.bfloat16: 1.2e-2}
+# tolerance: features vs the CPU fp32 path.  Three statistics:
+#   norm-wise      ||a - b||_F / ||b||_F
+#   element-wise   max_ij |a_ij - b_ij| / (|b_ij| + 0.05 max|b|)    (elements below 5 % of the feature scale are compared
+#                                                                    on that absolute scale)
+#   q99.9          the 99.9th percentile of the same per-element statistic
+# Bounds are set PER CASE from what was measured on MI355X (round 3, profiles/r03_parity_lines.txt: every test is seeded
+# and the device path is bit-repeatable, so a case reproduces its numbers), with 1.2x headroom on the norm-wise figure,
+# 1.25x on q99.9 and 1.5x on the element-wise maximum (one element of ~25 000: heavy tailed, moves by 20-30 % between two
+# equally accurate builds of the attention row sums).  float32 additionally keeps the north star's 1e-3 on every statistic
+# (exact-f32 MFMA measures ~2e-6 / ~3e-5), and the 16-bit modes must also sit inside the REFERENCE's own 16-bit error
+# (G1b / G1c envelope tests below).  A case without an entry falls back to the widest measured bound of its type.
+MEASURED = {
+    # (case, dtype): (norm-wise, element-wise max, q99.9)
+    ("G1 L2", "float32"): (1.54e-6, 2.36e-5, 1.57e-5),
+    ("G1 L2", "float16"): (7.28e-4, 1.38e-2, 7.6e-3),
+    ("G1 L2", "bfloat16"): (5.57e-3, 8.93e-2, 5.76e-2),
+    ("vit_b_16 L12 vs reference golden", "float32"): (2.11e-6, 2.70e-5, 2.05e-5),
+    ("vit_b_16 L12 vs oracle", "float32"): (2.03e-6, 3.43e-5, 2.31e-5),
+    ("vit_b_16 L12 vs reference golden", "float16"): (1.260e-3, 1.884e-2, 1.311e-2),
+    ("vit_b_16 L12 vs oracle", "float16"): (1.256e-3, 1.617e-2, 1.260e-2),
+    ("vit_b_16 L12 vs oracle, f32_stream", "float16"): (8.71e-4, 1.421e-2, 9.04e-3),
+    ("vit_b_16 L12 vs reference golden, f32_stream", "float16"): (8.51e-4, 1.268e-2, 9.94e-3),
+    ("massive activations, fused", "float16"): (1.270e-3, 4.85e-3, 3.92e-3),
+    ("massive activations, f32_stream", "float16"): (2.46e-4, 1.15e-3, 8.2e-4),
+    ("massive activations, fused", "bfloat16"): (8.62e-3, 4.17e-2, 3.09e-2),
+    ("massive activations, f32_stream", "bfloat16"): (1.94e-3, 7.84e-3, 6.45e-3),
+    ("uni_v1 L24", "float16"): (1.599e-3, 2.092e-2, 1.402e-2),
+    ("uni_v1 L24, f32_stream", "float16"): (9.39e-4, 1.441e-2, 9.97e-3),
+    ("uni_v1 L24", "float32"): (2.36e-6, 2.89e-5, 2.18e-5),
+    ("vit_l_16 L24", "float16"): (1.579e-3, 3.108e-2, 1.601e-2),
+    ("vit_l_16 L24, f32_stream", "float16"): (9.24e-4, 1.334e-2, 1.048e-2),
+    ("conch_v1 L12 @448", "float16"): (6.54e-4, 9.79e-3, 7.86e-3),
+}
+HEADROOM = (1.2, 1.5, 1.25)
+FALLBACK = {"float32": (2.4e-6, 3.5e-5, 2.4e-5), "float16": (1.6e-3, 3.2e-2, 1.7e-2), "bfloat16": (1.03e-2, 9e-2, 5.8e-2)}
+NORTH_STAR_F32 = 1e-3
 
 
 def _elem(a, b, floor=0.05):
@@ -146,10 +163,21 @@ def _elem_q(a, b, q=0.999, floor=0.05):
     return float(np.quantile(np.abs(a - b) / (np.abs(b) + floor * np.abs(b).max()), q))
 
 
-def _check(got, want, dtype, what="", tol=None):
+def _bounds(what, dtype):
+    name = str(dtype).split(".")[-1]
+    key = what.split(" n=")[0]
+    measured = MEASURED.get((key, name), FALLBACK[name])
+    return tuple(m * h for m, h in zip(measured, HEADROOM))
+
+
+def _check(got, want, dtype, what=""):
     r, e, eq = _rel(got, want), _elem(got, want), _elem_q(got, want)
-    print(f"PARITY {what} {str(dtype).split('.')[-1]}: norm-wise {r:.3e} element-wise max {e:.3e} q99.9 {eq:.3e}")
-    assert r <= (tol or TOL)[dtype] and e <= ETOL[dtype] and eq <= ETOL_Q[dtype], (what, dtype, r, e, eq)
+    br, be, bq = _bounds(what, dtype)
+    print(f"PARITY {what} {str(dtype).split('.')[-1]}: norm-wise {r:.3e} (bound {br:.2e}) element-wise max {e:.3e} ({be:.2e}) "
+          f"q99.9 {eq:.3e} ({bq:.2e})")
+    assert r <= br and e <= be and eq <= bq, (what, dtype, (r, br), (e, be), (eq, bq))
+    if dtype == torch.float32:
+        assert max(r, e, eq) <= NORTH_STAR_F32
     return r
 
 
@@ -185,9 +213,8 @@ def test_vit_b16_full_depth_vs_golden_and_oracle(dtype, golden_dir):
     _check(got, want, dtype, "vit_b_16 L12 vs oracle")
     if dtype != torch.float32:                        # the f32-residual-stream dataflow stays available and is closer
         ex.vit.set_option("f32_stream", True)
-        _check(ex.extract_batch(more, batch_size=7), want, dtype, "vit_b_16 L12 vs oracle, f32_stream", tol=TOL_F32S)
-        _check(ex.extract_batch(patches, batch_size=32), g["L12_n5_out"], dtype, "vit_b_16 L12 vs reference golden, f32_stream",
-               tol=TOL_F32S)
+        _check(ex.extract_batch(more, batch_size=7), want, dtype, "vit_b_16 L12 vs oracle, f32_stream")
+        _check(ex.extract_batch(patches, batch_size=32), g["L12_n5_out"], dtype, "vit_b_16 L12 vs reference golden, f32_stream")
     ex.cleanup()
 
 
@@ -236,7 +263,79 @@ def test_fused_dataflow_with_large_row_means_and_massive_channels(dtype):
     got_f32s = ex.extract_batch(tiles, batch_size=32)
     ex.cleanup()
     _check(got, want, dtype, "massive activations, fused")
-    _check(got_f32s, want, dtype, "massive activations, f32_stream", tol=TOL_F32S)
+    _check(got_f32s, want, dtype, "massive activations, f32_stream")
+
+
+def _stress_massive_sd():
+    """The weights of golden G1c (a): the seeded depth-12 HF ViT with fc2 rows of three channels x50 in blocks 2 / 5 / 8."""
+    from oracle import vit_oracle
+    sd = dict(vit_oracle.make_hf_vit(layers=12).state_dict())
+    for blk in (2, 5, 8):
+        key = next(k for k in sd if k.endswith("weight") and (f"layer.{blk}.output.dense" in k or f"layers.{blk}.mlp.fc2" in k))
+        w = sd[key].clone()
+        w[[7, 300, 511], :] *= 50.0
+        sd[key] = w
+    return sd
+
+
+@pytest.mark.parametrize("dtype,tag", [(torch.float32, "f32"), (torch.float16, "f16"), (torch.bfloat16, "bf16")])
+def test_massive_activations_inside_the_references_own_16bit_envelope(dtype, tag, golden_dir):
+    """G1c (a): per-block massive activations.  fc2 of blocks 2, 5 and 8 writes three channels of the residual stream at
+    ~50x the scale of the rest, so from block 2 on every row of the 16-bit stream carries outliers that set its ulp and
+    dominate its LayerNorm statistics.  The REFERENCE's own float16 / bfloat16 extract_batch on these weights (generated
+    here by running it, tests/golden/gen_golden.py stress) is the envelope: the build's error against the reference's
+    float32 features must not exceed the reference's own in the same type; float32 mode keeps the north star's 1e-3."""
+    import os
+    from atlaspatch_amd.encoders.vit import build_hip_vit_extractor
+    g = np.load(os.path.join(golden_dir, "extract_batch_stress.npz"))
+    want = g["massive_f32"]
+    sd = _stress_massive_sd()
+    ex = build_hip_vit_extractor(name="hfvit_massive_blocks", arch="vit_b_16", depth=12, state_dict=sd, device=_dev(),
+                                 dtype=dtype, source="hf")
+    rng = np.random.default_rng(77)
+    tiles = [rng.integers(0, 256, (256, 256, 3), dtype=np.uint8) for _ in range(5)]
+    got = ex.extract_batch(tiles, batch_size=32)
+    ours = _rel(got, want)
+    if dtype == torch.float32:
+        ex.cleanup()
+        print(f"PARITY stress massive f32: {ours:.3e}")
+        assert ours <= 4e-6 and _elem(got, want) <= 1e-4
+        return
+    ex.vit.set_option("f32_stream", True)
+    ours_f32s = _rel(ex.extract_batch(tiles, batch_size=32), want)
+    ex.cleanup()
+    ref_err = _rel(g[f"massive_{tag}"], want)
+    print(f"PARITY stress massive {tag}: reference's own {ref_err:.3e}, build (fused LayerNorm) {ours:.3e}, build (f32 stream) {ours_f32s:.3e}")
+    assert ours <= ref_err and ours_f32s <= ref_err, (tag, ref_err, ours, ours_f32s)
+
+
+@pytest.mark.parametrize("dtype,tag", [(torch.float32, "f32"), (torch.float16, "f16"), (torch.bfloat16, "bf16")])
+def test_layerscale_at_unis_init_value_inside_the_references_own_16bit_envelope(dtype, tag, golden_dir):
+    """G1c (b): 24-block ViT-L/16 with LayerScale gamma = 1e-5 (UNI's init_values, models/patch/uni.py:35).  The build folds
+    gamma into the proj / fc2 weights (one rounding to the compute type): at 1e-5 the folded float16 weights are
+    subnormal.  Envelope = the reference's own 16-bit run of a timm-ordered module with the same weights."""
+    import os
+    from atlaspatch_amd.encoders.vit import ARCHS, TRANSFORM_RESIZE, build_hip_vit_extractor, random_canonical_state_dict
+    g = np.load(os.path.join(golden_dir, "extract_batch_stress.npz"))
+    want = g["layerscale_f32"]
+    sd = random_canonical_state_dict(ARCHS["uni_v1"], seed=31)
+    ex = build_hip_vit_extractor(name="uni_ls_init", arch="uni_v1", state_dict=sd, source="canonical", device=_dev(), dtype=dtype,
+                                 resize=TRANSFORM_RESIZE["uni_v1"], expect_size=None)
+    rng = np.random.default_rng(77)
+    tiles = [rng.integers(0, 256, (256, 256, 3), dtype=np.uint8) for _ in range(3)]
+    got = ex.extract_batch(tiles, batch_size=32)
+    ours = _rel(got, want)
+    if dtype == torch.float32:
+        ex.cleanup()
+        print(f"PARITY stress layerscale f32: {ours:.3e}")
+        assert ours <= 1e-6 and _elem(got, want) <= 1e-4
+        return
+    ex.vit.set_option("f32_stream", True)
+    ours_f32s = _rel(ex.extract_batch(tiles, batch_size=32), want)
+    ex.cleanup()
+    ref_err = _rel(g[f"layerscale_{tag}"], want)
+    print(f"PARITY stress layerscale {tag}: reference's own {ref_err:.3e}, build (fused LayerNorm) {ours:.3e}, build (f32 stream) {ours_f32s:.3e}")
+    assert ours <= ref_err and ours_f32s <= ref_err, (tag, ref_err, ours, ours_f32s)
 
 
 def test_parameter_updates_after_finalize_cannot_leave_stale_folded_weights():
@@ -314,7 +413,7 @@ def test_vit_l_full_depth_vs_fp32_oracle(name, dtype):
     assert got.shape == (8, 1024)
     _check(got, want, dtype, f"{name} L24")
     if got_f32s is not None:
-        _check(got_f32s, want, dtype, f"{name} L24, f32_stream", tol=TOL_F32S)
+        _check(got_f32s, want, dtype, f"{name} L24, f32_stream")
 
 
 def test_conch_v1_full_depth_f16_vs_fp32_oracle():
@@ -588,7 +687,7 @@ def test_f32_stream_option_repeatable_and_batch_cut_invariant(dtype):
             ex.forward_device(tiles[lo:lo + 77], cut[lo:lo + 77])
         assert torch.equal(cut, out), mode
     assert not torch.equal(refs[False], refs[True])        # they are different computations ...
-    assert _rel(refs[False].cpu().numpy(), refs[True].cpu().numpy()) < TOL[dtype]   # ... of the same features
+    assert _rel(refs[False].cpu().numpy(), refs[True].cpu().numpy()) < FALLBACK[str(dtype).split(".")[-1]][0]   # ... of the same features
     ex.cleanup()
 
 

@@ -15,6 +15,7 @@ PROF_KINDS = ("preproc", "gemm_patch_embed", "gemm_qkv", "gemm_proj", "gemm_fc1"
               "attention", "layernorm", "cls_tail")
 AP_ERR_CAPACITY = -6
 AP_ERR_UNSUPPORTED = -4
+AP_ERR_INVALID = -1
 
 _LIB_NAME = "libatlaspatch_hip.so"
 _lock = threading.Lock()
@@ -107,6 +108,11 @@ SIGNATURES = {
                                  C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]),
     "ap_synth_tiles": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                  C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "ap_gather2d_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "ap_synth_region": (C.c_int, [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_uint32,
+                                  C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "ap_pillow_reduce_u8": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_void_p]),
     "ap_host_openslide_available": (C.c_int, []),
     "ap_host_openslide_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "ap_host_openslide_read_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

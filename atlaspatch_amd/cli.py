@@ -214,7 +214,10 @@ process = cli.command(name="process",
 
 
 def _segmenter_for(files, seg_cfg: SegmentationConfig):
-    if all(Path(f).suffix.lower() == ".synth" for f in files):
+    """Synthetic slides carry their own tissue geometry (analytic mask); everything else goes through SAM2 like the
+    reference.  ATLASPATCH_SEGMENTER=sam2 forces the SAM2 path for synthetic slides too (timing / plumbing runs)."""
+    forced = os.environ.get("ATLASPATCH_SEGMENTER", "auto").lower()
+    if forced != "sam2" and all(Path(f).suffix.lower() == ".synth" for f in files):
         return AnalyticSegmentationService(seg_cfg.thumbnail_max)
     return SAM2SegmentationService(seg_cfg)
 

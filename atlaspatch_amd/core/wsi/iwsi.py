@@ -155,15 +155,8 @@ class IWSI(abc.ABC):
                 out[label] = found
         return out
 
-    def get_thumbnail_at_power(self, *, power: float = 1.25,
-                               interpolation: str = "optimise") -> Image.Image:
-        """Whole-slide RGB image at objective ``power`` (iwsi.py:246-323).
-
-        Reads the pyramid level chosen by ``optimal_level(mag / power)`` in full and, when
-        that level is not already the exact ``(W0/ds, H0/ds)`` size, resamples it with
-        ``cv2.resize`` semantics (AREA when shrinking / CUBIC when enlarging, iwsi.py:305-321)
-        on the device (``ap_cv2_resize_u8``).
-        """
+    def _thumbnail_geometry(self, power: float):
+        """(level, read_wh, out_wh) of the power-based thumbnail (iwsi.py:246-303)."""
         self._ensure_loaded()
         if self.mag is None:
             raise ValueError(
@@ -177,11 +170,49 @@ class IWSI(abc.ABC):
         level, _ = self.optimal_level(ds_target)
         ds_level = float((self.ds or [1.0])[level])
         read_wh = (max(1, int(round(width0 / ds_level))), max(1, int(round(height0 / ds_level))))
+        out_wh = (max(1, int(round(width0 / ds_target))), max(1, int(round(height0 / ds_target))))
+        return level, read_wh, out_wh
+
+    def read_level_device(self, level: int, wh: Tuple[int, int], device):
+        """Optional capability: the region (0, 0, wh) of pyramid ``level`` as uint8 [h, w, 3] IN HBM, or None when the
+        backend has nothing better than ``extract`` (the caller then reads on the host and uploads).  Backends that can
+        produce pixels on the device (synthetic slides) or read strips in parallel outside the interpreter lock
+        (OpenSlide through the native hook) override it: the whole-level read is what the reference's thumbnail spends
+        its time on (iwsi.py:296-303: one ``read_region`` of the full level)."""
+        return None
+
+    def get_thumbnail_at_power_device(self, *, power: float = 1.25, interpolation: str = "optimise", device=None):
+        """``get_thumbnail_at_power`` with the image left in HBM: uint8 [out_h, out_w, 3] on ``device``.  Same level
+        choice, same ``cv2.resize`` (AREA when shrinking / CUBIC when enlarging, iwsi.py:305-321, ``ap_cv2_resize_u8``);
+        the segmentation path continues on the device from here (Pillow ``thumbnail``, the SAM2 input resize)."""
+        import torch
+        from atlaspatch_amd.utils.resample import cv2_resize_device, thumbnail_interpolation
+        level, read_wh, (out_w, out_h) = self._thumbnail_geometry(power)
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        region = self.read_level_device(level, read_wh, dev)
+        if region is None:
+            arr = self.extract((0, 0), lv=level, wh=read_wh, mode="array")
+            if not isinstance(arr, np.ndarray):
+                raise RuntimeError("Failed to read thumbnail region as array")
+            region = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.uint8)).to(dev)
+        if region.shape[1] != out_w or region.shape[0] != out_h:
+            region = cv2_resize_device(region[None], (out_w, out_h),
+                                       thumbnail_interpolation(tuple(region.shape[:2]), (out_w, out_h), interpolation))[0]
+        return region
+
+    def get_thumbnail_at_power(self, *, power: float = 1.25,
+                               interpolation: str = "optimise") -> Image.Image:
+        """Whole-slide RGB image at objective ``power`` (iwsi.py:246-323).
+
+        Reads the pyramid level chosen by ``optimal_level(mag / power)`` in full and, when
+        that level is not already the exact ``(W0/ds, H0/ds)`` size, resamples it with
+        ``cv2.resize`` semantics (AREA when shrinking / CUBIC when enlarging, iwsi.py:305-321)
+        on the device (``ap_cv2_resize_u8``).
+        """
+        level, read_wh, (out_w, out_h) = self._thumbnail_geometry(power)
         region = self.extract((0, 0), lv=level, wh=read_wh, mode="array")
         if not isinstance(region, np.ndarray):
             raise RuntimeError("Failed to read thumbnail region as array")
-        out_w = max(1, int(round(width0 / ds_target)))
-        out_h = max(1, int(round(height0 / ds_target)))
         if region.shape[1] != out_w or region.shape[0] != out_h:
             from atlaspatch_amd.utils.resample import cv2_resize_array, thumbnail_interpolation
             region = cv2_resize_array(region, (out_w, out_h),

@@ -141,23 +141,73 @@ class OpenSlideWSI(IWSI):
         self._ensure_loaded()
         if not rows:
             return True
-        if self._native is False or os.environ.get("ATLASPATCH_OPENSLIDE_NATIVE", "1") == "0":
-            return False
         lv0 = int(rows[0][4])
         if any(int(r[2]) != tile_side or int(r[3]) != tile_side or int(r[4]) != lv0 for r in rows):
             return False
         lib = _lib.load()
-        if self._native is None:
-            handle = C.c_void_p()
-            code = lib.ap_host_openslide_open(str(self.path).encode(), C.byref(handle))
-            if code != _lib.AP_OK:         # no libopenslide on this host (or it cannot open what openslide-python opened)
-                self._native = False
-                return False
-            self._native = handle
+        handle = self._native_handle()
+        if handle is None:                 # no libopenslide on this host (or it cannot open what openslide-python opened)
+            return False
         xy = np.ascontiguousarray([[r[0], r[1]] for r in rows], dtype=np.int64)
-        _lib.check(lib.ap_host_openslide_read_tiles(self._native, xy.ctypes.data, len(rows), lv0, tile_side, tile_side, dst_ptr),
+        _lib.check(lib.ap_host_openslide_read_tiles(handle, xy.ctypes.data, len(rows), lv0, tile_side, tile_side, dst_ptr),
                    "ap_host_openslide_read_tiles")
         return True
+
+    def _native_handle(self):
+        """ap_openslide handle of the batched native reader, or None when libopenslide does not resolve."""
+        import ctypes as C
+        import os
+        from ... import _lib
+        if self._native is False or os.environ.get("ATLASPATCH_OPENSLIDE_NATIVE", "1") == "0":
+            return None
+        if self._native is None:
+            handle = C.c_void_p()
+            if _lib.load().ap_host_openslide_open(str(self.path).encode(), C.byref(handle)) != _lib.AP_OK:
+                self._native = False
+                return None
+            self._native = handle
+        return self._native
+
+    def read_level_device(self, level: int, wh, device):
+        """Whole-level read for the thumbnail (iwsi.py:296-303 is ONE read_region of the full level on one thread):
+        full-width strips read by libopenslide on a thread pool outside the interpreter lock (the strips of one image are
+        consecutive ``w * rows * 3``-byte slots, i.e. exactly the image), into pinned memory, then one H2D copy."""
+        import concurrent.futures as futures
+        import os
+        import torch
+        from ... import _lib
+        self._ensure_loaded()
+        handle = self._native_handle()
+        if handle is None:
+            return None
+        w, h = int(wh[0]), int(wh[1])
+        ds = float(self.ds[level])
+        rows = max(16, min(256, -(-h // 64)))               # strip height: ~64 strips per level, 16..256 rows each
+        if ds != float(int(ds)):
+            # read_region takes LEVEL-0 coordinates and divides by the level's downsample: with a non-integer downsample
+            # (4.0001...) a strip that starts at level row y cannot be addressed exactly (round(y * ds) / ds != y), and a
+            # sub-pixel offset makes OpenSlide resample.  Such levels are read in ONE region like the reference does --
+            # still outside the interpreter lock, just not in parallel.
+            rows = h
+        host = torch.empty((h, w, 3), dtype=torch.uint8, pin_memory=True)
+        base = host.data_ptr()
+        lib = _lib.load()
+        strips = [(y, min(rows, h - y)) for y in range(0, h, rows)]
+        tail = [s for s in strips if s[1] != rows]
+        full = [s for s in strips if s[1] == rows]
+
+        def read(group):
+            # level-0 y of a strip that starts at level row y (openslide's read_region takes level-0 coordinates)
+            xy = np.ascontiguousarray([[0, y * int(ds)] for y, _ in group], dtype=np.int64)
+            for (y, n), pt in zip(group, xy):
+                _lib.check(lib.ap_host_openslide_read_tiles(handle, pt.ctypes.data, 1, int(level), w, n,
+                                                            base + y * w * 3), "ap_host_openslide_read_tiles")
+
+        workers = max(1, min(32, len(strips), os.cpu_count() or 8))
+        chunks = [full[i::workers] for i in range(workers) if full[i::workers]] + ([tail] if tail else [])
+        with futures.ThreadPoolExecutor(max_workers=workers, thread_name_prefix="level") as pool:
+            list(pool.map(read, chunks))
+        return host.to(torch.device(device), non_blocking=False)
 
     def get_size(self, lv: int = 0) -> Tuple[int, int]:
         self._ensure_loaded()

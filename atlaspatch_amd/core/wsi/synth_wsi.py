@@ -129,6 +129,29 @@ class SynthWSI(IWSI):
                        "ap_synth_tiles")
         return tiles
 
+    def read_level_device(self, level: int, wh, device):
+        """The whole-level read of the thumbnail path, rendered in HBM by ``ap_synth_region`` (bit-identical to
+        ``render_region``): on a 100 000 x 100 000 slide level 2 is 6250 x 6250 = 117 MB, 3.3 s through the NumPy renderer."""
+        import torch
+        from ... import _lib
+        self._ensure_loaded()
+        if self.jpeg_dir is not None:
+            return None
+        device = torch.device(device)
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        cache = getattr(self, "_dev_ellipses", None)
+        if cache is None or cache.device != device:
+            cache = torch.from_numpy(self.spec.ellipses()).to(device)
+            self._dev_ellipses = cache
+        w, h = int(wh[0]), int(wh[1])
+        out = torch.empty((h, w, 3), dtype=torch.uint8, device=device)
+        with torch.cuda.device(device):
+            _lib.check(_lib.load().ap_synth_region(0, 0, w, h, int(round(self.ds[level])), int(level), self.spec.width,
+                                                   self.spec.height, self.spec.seed, cache.data_ptr(), cache.shape[0],
+                                                   out.data_ptr(), _lib.current_stream_ptr(device)), "ap_synth_region")
+        return out
+
     def read_tiles_into(self, rows, dst_ptr: int, tile_side: int) -> bool:
         """Optional IWSI capability (native batched host decode): decode the tiles of ``rows`` (x, y, rw, rh, lv) into
         consecutive ``tile_side^2 * 3``-byte slots at ``dst_ptr`` in ONE call outside the interpreter lock, or return

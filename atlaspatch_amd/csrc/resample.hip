@@ -138,6 +138,33 @@ void resample_fused_kernel(const uint8_t* __restrict__ src, int h, int w, int oh
     }
 }
 
+// Image.reduce((fx, fy), box) of Pillow (libImaging/Reduce.c) for uint8 RGB: out[oy][ox] = box average of the fx x fy block
+// (partial blocks at the right / bottom edge of the box are averaged over the pixels they have), computed as
+// ((sum + n / 2) * mult(n)) >> 24 in uint32 arithmetic with mult(n) = (uint32)(2^32 / (256 n)) evaluated in float32.
+// One thread per output pixel; a wave reads fx * 64 consecutive pixels of each of its fy rows (HBM-bound: every source
+// byte is read once).
+__global__ __launch_bounds__(256)
+void pillow_reduce_kernel(const uint8_t* __restrict__ src, int w, int x0, int y0, int bw, int bh, int fx, int fy,
+                          int ow, int oh, uint8_t* __restrict__ dst) {
+    const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (ox >= ow || oy >= oh) return;
+    const int xs = ox * fx, ys = oy * fy;
+    const int nx = min(fx, bw - xs), ny = min(fy, bh - ys);
+    uint32_t s0 = 0, s1 = 0, s2 = 0;
+    for (int y = 0; y < ny; ++y) {
+        const uint8_t* p = src + ((size_t)(y0 + ys + y) * w + (x0 + xs)) * 3;
+        for (int x = 0; x < nx; ++x) { s0 += p[3 * x]; s1 += p[3 * x + 1]; s2 += p[3 * x + 2]; }
+    }
+    const uint32_t n = (uint32_t)(nx * ny);
+    const uint32_t mult = (uint32_t)(4294967296.0f / (float)(256u * n));
+    const uint32_t amend = n / 2;
+    uint8_t* d = dst + ((size_t)oy * ow + ox) * 3;
+    d[0] = (uint8_t)(((s0 + amend) * mult) >> 24);
+    d[1] = (uint8_t)(((s1 + amend) * mult) >> 24);
+    d[2] = (uint8_t)(((s2 + amend) * mult) >> 24);
+}
+
 }  // namespace
 }  // namespace ap
 
@@ -168,6 +195,20 @@ extern "C" int ap_resample_u8(const uint8_t* src, int n, int h, int w, uint8_t* 
     const size_t t1 = (size_t)n * h * ow, t2 = (size_t)n * oh * ow;
     ap::resample_h_kernel<<<(unsigned)((t1 + 255) / 256), 256, 0, s>>>(src, n, h, w, ow, bounds_x, coeffs_x, ksize_x, tmp);
     ap::resample_v_kernel<<<(unsigned)((t2 + 255) / 256), 256, 0, s>>>(tmp, n, h, ow, oh, bounds_y, coeffs_y, ksize_y, dst);
+    AP_HIP_CHECK(hipGetLastError());
+    return AP_OK;
+}
+
+extern "C" int ap_pillow_reduce_u8(const uint8_t* src, int h, int w, int box_x, int box_y, int box_w, int box_h, int fx, int fy,
+                                   uint8_t* dst, ap_stream_t stream) {
+    AP_REQUIRE(src && dst, "ap_pillow_reduce_u8: null pointer");
+    AP_REQUIRE(h > 0 && w > 0 && fx >= 1 && fy >= 1 && box_x >= 0 && box_y >= 0 && box_w > 0 && box_h > 0 &&
+               box_x + box_w <= w && box_y + box_h <= h, "ap_pillow_reduce_u8: box (%d, %d, %d, %d) / factor (%d, %d) outside %d x %d",
+               box_x, box_y, box_w, box_h, fx, fy, w, h);
+    AP_REQUIRE((long long)fx * fy <= 65536, "ap_pillow_reduce_u8: factor %d x %d too large", fx, fy);     // sum stays inside uint32
+    const int ow = (box_w + fx - 1) / fx, oh = (box_h + fy - 1) / fy;
+    dim3 grid((unsigned)((ow + 63) / 64), (unsigned)((oh + 3) / 4));
+    ap::pillow_reduce_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(src, w, box_x, box_y, box_w, box_h, fx, fy, ow, oh, dst);
     AP_HIP_CHECK(hipGetLastError());
     return AP_OK;
 }

@@ -406,6 +406,16 @@ __global__ void convt_shuffle_kernel(const float* g, const float* bias, const fl
     out[i] = act_apply(v, act);
 }
 // F.interpolate(bilinear, align_corners=False) x4 of logits [S, S] and `> threshold` -> float {0, 1}
+// dst[y][x] = src[yidx[y]][xidx[x]]: the mask's way back to the thumbnail's shape (PIL NEAREST resize = a gather through
+// per-axis index tables; services/segmentation.py:112-118).
+__global__ void gather2d_kernel(const float* __restrict__ src, int src_w, const int* __restrict__ yidx,
+                                const int* __restrict__ xidx, int oh, int ow, float* __restrict__ dst) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)oh * ow) return;
+    const int y = (int)(i / ow), x = (int)(i - (size_t)y * ow);
+    dst[i] = src[(size_t)yidx[y] * src_w + xidx[x]];
+}
+
 __global__ void bilinear_up4_threshold_kernel(const float* lg, int S, float thr, float* mask) {
     const int OS = S * 4;
     const size_t total = (size_t)OS * OS;
@@ -597,6 +607,14 @@ int ap_convt2x2_shuffle(const float* g, const float* bias, const float* skip, fl
 int ap_bilinear_up4_threshold(const float* logits, int size, float threshold, float* mask, ap_stream_t stream) {
     AP_REQUIRE(logits && mask && size > 1, "ap_bilinear_up4_threshold: bad arguments");
     ap::bilinear_up4_threshold_kernel<<<ap::grid1((size_t)16 * size * size), 256, 0, (hipStream_t)stream>>>(logits, size, threshold, mask);
+    AP_HIP_CHECK(hipGetLastError());
+    return AP_OK;
+}
+
+int ap_gather2d_f32(const float* src, int src_h, int src_w, const int32_t* yidx, const int32_t* xidx, int oh, int ow, float* dst,
+                    ap_stream_t stream) {
+    AP_REQUIRE(src && yidx && xidx && dst && src_h > 0 && src_w > 0 && oh > 0 && ow > 0, "ap_gather2d_f32: bad arguments");
+    ap::gather2d_kernel<<<ap::grid1((size_t)oh * ow), 256, 0, (hipStream_t)stream>>>(src, src_w, yidx, xidx, oh, ow, dst);
     AP_HIP_CHECK(hipGetLastError());
     return AP_OK;
 }

@@ -12,23 +12,25 @@ __device__ __forceinline__ uint32_t mix32(uint32_t a) {
     return a;
 }
 
-__global__ __launch_bounds__(256) void synth_tiles_kernel(const int32_t* __restrict__ xy, int n, int ps,
-                                                          int ds, int level, long long width,
+// xy == nullptr: ONE region of pw x ph level pixels whose level-0 corner is (rx, ry) (the whole-level read of the thumbnail
+// path); otherwise n tiles of pw x ph at the corners in xy.
+__global__ __launch_bounds__(256) void synth_tiles_kernel(const int32_t* __restrict__ xy, long long rx, long long ry, int n,
+                                                          int pw, int ph, int ds, int level, long long width,
                                                           long long height, uint32_t seed,
                                                           const long long* __restrict__ ell, int k,
                                                           uint8_t* __restrict__ dst) {
     extern __shared__ long long sell[];
     for (int i = threadIdx.x; i < k * 4; i += 256) sell[i] = ell[i];
     __syncthreads();
-    const size_t per_tile = (size_t)ps * ps;
+    const size_t per_tile = (size_t)pw * ph;
     size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t total = (size_t)n * per_tile;
     if (idx >= total) return;
     const int tile = (int)(idx / per_tile);
     const int rem = (int)(idx - (size_t)tile * per_tile);
-    const int py = rem / ps, px = rem - py * ps;
-    const long long gx = (long long)xy[2 * tile] + (long long)px * ds;
-    const long long gy = (long long)xy[2 * tile + 1] + (long long)py * ds;
+    const int py = rem / pw, px = rem - py * pw;
+    const long long gx = (xy ? (long long)xy[2 * tile] : rx) + (long long)px * ds;
+    const long long gy = (xy ? (long long)xy[2 * tile + 1] : ry) + (long long)py * ds;
     const long long ux = gx >> 4, uy = gy >> 4;
     bool tissue = false;
     for (int e = 0; e < k; ++e) {
@@ -62,7 +64,21 @@ extern "C" int ap_synth_tiles(const int32_t* xy, int n, int ps, int level_ds, in
     const size_t blocks = (total + 255) / 256;
     AP_REQUIRE(blocks < (1ull << 31), "synth_tiles: too many pixels in one call");
     ap::synth_tiles_kernel<<<(unsigned)blocks, 256, (size_t)k * 4 * sizeof(long long), (hipStream_t)stream>>>(
-        xy, n, ps, level_ds, level, (long long)width, (long long)height, seed, (const long long*)ellipses, k, dst);
+        xy, 0, 0, n, ps, ps, level_ds, level, (long long)width, (long long)height, seed, (const long long*)ellipses, k, dst);
+    AP_HIP_CHECK(hipGetLastError());
+    return AP_OK;
+}
+
+extern "C" int ap_synth_region(int64_t x, int64_t y, int w, int h, int level_ds, int level, int64_t width, int64_t height,
+                               uint32_t seed, const int64_t* ellipses, int k, uint8_t* dst, ap_stream_t stream) {
+    AP_REQUIRE(dst && (ellipses || k == 0), "synth_region: null pointer");
+    AP_REQUIRE(w > 0 && h > 0 && level_ds > 0 && k >= 0 && k <= 256, "synth_region: bad arguments");
+    const size_t total = (size_t)w * h;
+    AP_REQUIRE(total < (1ull << 31), "synth_region: region of %d x %d pixels is too large for one call", w, h);
+    const size_t blocks = (total + 255) / 256;
+    ap::synth_tiles_kernel<<<(unsigned)blocks, 256, (size_t)k * 4 * sizeof(long long), (hipStream_t)stream>>>(
+        nullptr, (long long)x, (long long)y, 1, w, h, level_ds, level, (long long)width, (long long)height, seed,
+        (const long long*)ellipses, k, dst);
     AP_HIP_CHECK(hipGetLastError());
     return AP_OK;
 }

@@ -32,6 +32,8 @@ from ..utils.contours import DeviceContours
 from .geometry import PatchGeometry, prepare_geometry
 from .interfaces import ExtractionService
 
+from ..utils.stages import stage
+
 logger = logging.getLogger("atlaspatch_amd.extraction_service")
 
 
@@ -93,7 +95,8 @@ class PatchExtractionService(ExtractionService):
 
         (build_run_root(self.output_cfg, self.cfg) / "patches").mkdir(parents=True, exist_ok=True)
         out_h5 = patch_h5_path(slide, self.output_cfg, self.cfg)
-        coords, geometry = self.coords(wsi, mask)
+        with stage("contours_and_grid"):
+            coords, geometry = self.coords(wsi, mask)
         img_dir = None
         if self.output_cfg.save_images:
             img_dir = images_dir(slide, self.output_cfg, self.cfg)
@@ -111,7 +114,8 @@ class PatchExtractionService(ExtractionService):
                                level0_wh=(int(width0), int(height0)),
                                overlap=max(0, int(self.cfg.patch_size) - int(step)),
                                slide_stem=slide.stem, wsi_path=str(wsi.path), extra_file_attrs=extra)
-        total = writer.write_coords_array(out_h5, coords)
+        with stage("h5_coords"):
+            total = writer.write_coords_array(out_h5, coords)
         logger.debug("Wrote %d coords for %s to %s", total, slide.path.name, out_h5)
         return ExtractionResult(slide=slide, h5_path=Path(out_h5), num_patches=int(total), image_dir=img_dir,
                                 coords=None, patch_size_level0=geometry.patch_size_level0)

@@ -58,6 +58,7 @@ class Sam2HipPredictor:
         self._graph = None
         self.fused_attention = os.environ.get("ATLASPATCH_SAM2_UNFUSED_ATTENTION") in (None, "", "0")
         self._static_img = self._static_mask = None
+        self._resamplers: dict = {}
         f = lambda t: t.detach().to(torch.float32).contiguous()
         sd = {k: f(v) for k, v in state_dict.items()}
         dev = lambda t: t.to(self.device).contiguous()
@@ -328,22 +329,7 @@ class Sam2HipPredictor:
         it is captured once into a hipGraph (through torch's stream capture: every C-ABI launch goes to the capturing
         stream, buffers come from the graph's private pool) and replayed per slide -- one graph launch instead of 550
         kernel launches.  ATLASPATCH_SAM2_GRAPH=0 runs the launches one by one (per-kernel profiling)."""
-        import os
-        src = torch.from_numpy(np.ascontiguousarray(arr))
-        if os.environ.get("ATLASPATCH_SAM2_GRAPH", "1") == "0":
-            return self._forward_mask(src.to(self.device))
-        if self._graph is None:
-            self._static_img = torch.empty((self.input_size, self.input_size, 3), dtype=torch.uint8, device=self.device)
-            self._static_img.copy_(src)
-            self._forward_mask(self._static_img)                 # warm-up outside the capture (lazy initialisation)
-            torch.cuda.synchronize(self.device)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                self._static_mask = self._forward_mask(self._static_img)
-            self._graph = graph
-        self._static_img.copy_(src)
-        self._graph.replay()
-        return self._static_mask
+        return self._graph_mask_device(torch.from_numpy(np.ascontiguousarray(arr)).to(self.device))
 
     @torch.inference_mode()
     def predict_logits(self, image_u8_1024: np.ndarray) -> torch.Tensor:
@@ -367,6 +353,54 @@ class Sam2HipPredictor:
             pil = Image.fromarray((out * 255).astype(np.uint8), mode="L").resize((orig[1], orig[0]), resample=Image.Resampling.NEAREST)
             out = np.asarray(pil, dtype=np.float32) / 255.0
         return out
+
+    @torch.inference_mode()
+    def predict_device(self, thumb: torch.Tensor, *, resize_to_input: bool = True) -> np.ndarray:
+        """``predict_image`` for a thumbnail that already lives in HBM (uint8 [h, w, 3]): the PIL BILINEAR resize to
+        1024 x 1024 (``_resize_input_for_sam``, segmentation.py:104-110) runs on the device bit-identically to Pillow
+        (``ap_resample_u8``), the network is the same captured graph, and the mask returns to the thumbnail's shape by
+        PIL NEAREST semantics (``_resize_mask``, :112-118) as a device gather.  One D2H copy: the float {0, 1} mask."""
+        from ..utils.resample import DeviceResampler, pillow_nearest_index
+        assert thumb.is_cuda and thumb.dtype == torch.uint8 and thumb.dim() == 3 and thumb.shape[2] == 3
+        h, w = int(thumb.shape[0]), int(thumb.shape[1])
+        S = self.input_size
+        with torch.cuda.device(self.device):
+            img = thumb.contiguous()
+            if (h, w) != (S, S):
+                rs = self._resamplers.get((h, w))
+                if rs is None:
+                    yi = torch.from_numpy(pillow_nearest_index(S, h)).to(self.device)
+                    xi = torch.from_numpy(pillow_nearest_index(S, w)).to(self.device)
+                    rs = self._resamplers[(h, w)] = (DeviceResampler((h, w), (S, S), "bilinear", self.device), yi, xi)
+                    if len(self._resamplers) > 8:                      # bounded: thumbnails of a cohort share a few shapes
+                        self._resamplers.pop(next(iter(self._resamplers)))
+                img = rs[0](img[None])[0]
+            mask = self._graph_mask_device(img)
+            if resize_to_input and (h, w) != (S, S):
+                _, yi, xi = self._resamplers[(h, w)]
+                out = self._buf(h, w)
+                _lib.check(self.lib.ap_gather2d_f32(mask.data_ptr(), S, S, yi.data_ptr(), xi.data_ptr(), h, w, out.data_ptr(),
+                                                    self._stream()), "ap_gather2d_f32")
+                mask = out
+            return mask.cpu().numpy()
+
+    def _graph_mask_device(self, img: torch.Tensor) -> torch.Tensor:
+        """``_graph_mask`` for an input already in HBM (device-to-device copy into the graph's static input)."""
+        import os
+        if os.environ.get("ATLASPATCH_SAM2_GRAPH", "1") == "0":
+            return self._forward_mask(img)
+        if self._graph is None:
+            self._static_img = torch.empty((self.input_size, self.input_size, 3), dtype=torch.uint8, device=self.device)
+            self._static_img.copy_(img)
+            self._forward_mask(self._static_img)                 # warm-up outside the capture (lazy initialisation)
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._static_mask = self._forward_mask(self._static_img)
+            self._graph = graph
+        self._static_img.copy_(img)
+        self._graph.replay()
+        return self._static_mask
 
     def close(self) -> None:
         self._graph = None

@@ -21,14 +21,38 @@ import numpy as np
 from ..core.config import SegmentationConfig
 from ..core.models import Mask
 from ..core.wsi.iwsi import IWSI
+from ..utils.stages import stage
 from .interfaces import SegmentationService
 
 
 def prepare_thumbnail(wsi: IWSI, cfg: SegmentationConfig):
     """1.25x power image, then Pillow ``thumbnail((max, max))`` (segmentation.py:202-206)."""
-    thumb = wsi.get_thumbnail_at_power(power=cfg.thumbnail_power, interpolation="optimise")
+    with stage("thumbnail_at_power"):
+        thumb = wsi.get_thumbnail_at_power(power=cfg.thumbnail_power, interpolation="optimise")
     if cfg.thumbnail_max:
-        thumb.thumbnail((cfg.thumbnail_max, cfg.thumbnail_max))
+        with stage("thumbnail_pil"):
+            thumb.thumbnail((cfg.thumbnail_max, cfg.thumbnail_max))
+    return thumb
+
+
+def prepare_thumbnail_device(wsi: IWSI, cfg: SegmentationConfig, device):
+    """``prepare_thumbnail`` with every pixel operation on the device: the level read where the backend can
+    (``read_level_device``), ``cv2.resize`` to the 1.25x size (``ap_cv2_resize_u8``), Pillow's ``thumbnail`` = integer box
+    reduce + bicubic resize (``ap_pillow_reduce_u8`` + ``ap_resample_u8``, bit-identical to Pillow).  -> uint8 [h, w, 3] in HBM."""
+    from ..utils.resample import pillow_thumbnail_device
+    with stage("thumbnail_at_power"):
+        thumb = wsi.get_thumbnail_at_power_device(power=cfg.thumbnail_power, interpolation="optimise", device=device)
+    if cfg.thumbnail_max:
+        with stage("thumbnail_pil"):
+            h, w = int(thumb.shape[0]), int(thumb.shape[1])
+            if h > 100 * w:                  # Pillow resizes such images in two separate passes (Image.resize): host Pillow
+                from PIL import Image
+                img = Image.fromarray(thumb.cpu().numpy())
+                img.thumbnail((cfg.thumbnail_max, cfg.thumbnail_max))
+                import torch
+                thumb = torch.from_numpy(np.asarray(img)).to(thumb.device)
+            else:
+                thumb = pillow_thumbnail_device(thumb, (cfg.thumbnail_max, cfg.thumbnail_max))
     return thumb
 
 
@@ -107,17 +131,23 @@ class SAM2SegmentationService(SegmentationService):
         return self._predictor
 
     def segment_thumbnail(self, wsi: IWSI) -> Mask:
-        thumb = prepare_thumbnail(wsi, self.cfg)
-        data = self.predictor.predict_image(thumb, resize_to_input=True).astype(np.float32)
+        predictor = self.predictor
+        thumb = prepare_thumbnail_device(wsi, self.cfg, predictor.device)
+        with stage("sam2_predict"):
+            data = predictor.predict_device(thumb, resize_to_input=True)
         return Mask(data=data, source_shape=(int(data.shape[0]), int(data.shape[1])))
 
     def segment_batch(self, wsis: Sequence[IWSI]) -> list[Mask]:
+        # thumbnails are prepared on a thread pool like the reference's (segmentation.py:216-220): the level reads of
+        # host-decoded backends overlap; every pixel operation after the read is on the device, in stream order
+        predictor = self.predictor
         workers = max(1, min(8, len(wsis), os.cpu_count() or 8))
         with ThreadPoolExecutor(max_workers=workers, thread_name_prefix="thumb") as pool:
-            thumbs = list(pool.map(lambda w: prepare_thumbnail(w, self.cfg), wsis))
+            thumbs = list(pool.map(lambda w: prepare_thumbnail_device(w, self.cfg, predictor.device), wsis))
         out = []
         for thumb in thumbs:                      # one forward per slide (the reference batches them; same results)
-            data = self.predictor.predict_image(thumb, resize_to_input=True).astype(np.float32)
+            with stage("sam2_predict"):
+                data = predictor.predict_device(thumb, resize_to_input=True)
             out.append(Mask(data=data, source_shape=(int(data.shape[0]), int(data.shape[1]))))
         return out
 

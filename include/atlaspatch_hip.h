@@ -117,6 +117,16 @@ int ap_resample_u8(const uint8_t* src, int n, int h, int w, uint8_t* dst, int oh
                    const int32_t* bounds_y, const int32_t* coeffs_y, int ksize_y,
                    uint8_t* tmp, ap_stream_t stream);
 
+/* Pillow's Image.reduce((fx, fy), box) for one uint8 RGB image: the integer box reduction that Image.thumbnail(...,
+ * reducing_gap=2.0) -- the reference's thumbnail call, services/segmentation.py:202-206, Pillow defaults -- runs before its
+ * bicubic resize.  out[oy][ox] = ((sum of the block + n / 2) * (uint32)(2^32 / (256 n))) >> 24 (uint32 arithmetic, the
+ * multiplier evaluated in float32), partial blocks at the right / bottom edge averaged over the pixels they have.
+ * src: device uint8 [h, w, 3]; box = (box_x, box_y, box_w, box_h) inside it; dst: device uint8
+ * [ceil(box_h / fy), ceil(box_w / fx), 3].  Bit-identical to Pillow (tested against it).  The resize that follows is
+ * ap_resample_u8 with tables built for Pillow's `box` argument (utils/resample.py::pillow_resample_tables). */
+int ap_pillow_reduce_u8(const uint8_t* src, int h, int w, int box_x, int box_y, int box_w, int box_h, int fx, int fy,
+                        uint8_t* dst, ap_stream_t stream);
+
 /* ---- cv2.resize for uint8 RGB ----------------------------------------------------------
  * Replaces the host cv2.resize calls of the path: services/feature_embedding.py:94-95 and
  * services/extraction.py:112-113 (cv2.resize(patch, (ps, ps)), INTER_LINEAR, on every tile whose level read is
@@ -352,6 +362,11 @@ int ap_convt2x2_shuffle(const float* g, const float* bias, const float* skip, fl
                         int act, ap_stream_t stream);
 /* postprocess_masks: bilinear x4 (align_corners False) of logits [size, size], then > threshold -> float {0,1} */
 int ap_bilinear_up4_threshold(const float* logits, int size, float threshold, float* mask, ap_stream_t stream);
+/* _resize_mask (services/segmentation.py:112-118: PIL NEAREST back to the thumbnail's shape) as a gather:
+ * dst[y][x] = src[yidx[y]][xidx[x]]; yidx int32 [oh], xidx int32 [ow] (device; built on the host with Pillow's
+ * accumulated-double index arithmetic, utils/resample.py::pillow_nearest_index; entries must lie inside src). */
+int ap_gather2d_f32(const float* src, int src_h, int src_w, const int32_t* yidx, const int32_t* xidx, int oh, int ow,
+                    float* dst, ap_stream_t stream);
 
 /* ---- tissue mask -> patch coordinates ----------------------------------------------
  * Replaces utils/contours.py:41-131 (mask_to_contours, scale_contours) and the grid scan of
@@ -386,6 +401,11 @@ int ap_grid_coords(const ap_contours* c, int patch_size_src, int step_src,
 int ap_synth_tiles(const int32_t* xy, int n, int ps, int level_ds, int level,
                    int64_t width, int64_t height, uint32_t seed,
                    const int64_t* ellipses, int k, uint8_t* dst, ap_stream_t stream);
+/* One w x h region of pyramid level `level` whose level-0 corner is (x, y): dst uint8 [h, w, 3].  The whole-level read of
+ * the thumbnail path (core/wsi/iwsi.py:246-323 reads the level nearest 1.25x in full) for synthetic slides, in HBM. */
+int ap_synth_region(int64_t x, int64_t y, int w, int h, int level_ds, int level,
+                    int64_t width, int64_t height, uint32_t seed,
+                    const int64_t* ellipses, int k, uint8_t* dst, ap_stream_t stream);
 
 #ifdef __cplusplus
 }

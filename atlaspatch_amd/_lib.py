@@ -46,6 +46,7 @@ SIGNATURES = {
                                                 C.POINTER(C.c_float), C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ap_host_inflate_tiles": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.c_int, C.c_size_t]),
     "ap_host_decode_jpeg_tiles": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.c_int, C.c_int]),
+    "ap_host_format_passports": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_void_p, C.c_int]),
     "ap_host_gather_tiles": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_size_t]),
     "ap_host_synth_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                       C.c_uint32, C.c_void_p, C.c_int]),

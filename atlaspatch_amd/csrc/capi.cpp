@@ -64,6 +64,35 @@ int ap_host_gather_tiles(void* dst, const void* const* src, int n, size_t bytes_
     return AP_OK;
 }
 
+int ap_host_format_passports(const int32_t* coords, int n, const char* prefix, const char* suffix, char* out, int width) {
+    AP_REQUIRE((coords || n == 0) && prefix && suffix && out && n >= 0 && width > 0, "ap_host_format_passports: bad arguments");
+    const size_t plen = strlen(prefix), slen = strlen(suffix);
+    std::vector<char> line(plen + slen + 128);
+    memcpy(line.data(), prefix, plen);
+    for (int i = 0; i < n; ++i) {
+        const int32_t* c = coords + (size_t)i * 5;
+        char* p = line.data() + plen;
+        // "__x{X}_y{Y}_rw{RW}_rh{RH}_lv{LV}": decimal int32 fields, '-' for negatives (Python's str(int))
+        static const char* const tags[5] = {"__x", "_y", "_rw", "_rh", "_lv"};
+        for (int f = 0; f < 5; ++f) {
+            for (const char* t = tags[f]; *t; ++t) *p++ = *t;
+            uint32_t v = (uint32_t)c[f];
+            if (c[f] < 0) { *p++ = '-'; v = 0u - v; }
+            char digits[12];
+            int nd = 0;
+            do { const uint32_t q = v / 10u; digits[nd++] = (char)('0' + (v - q * 10u)); v = q; } while (v);
+            while (nd) *p++ = digits[--nd];
+        }
+        memcpy(p, suffix, slen);
+        const size_t len = (size_t)(p - line.data()) + slen;
+        char* o = out + (size_t)i * width;
+        const size_t take = len < (size_t)width ? len : (size_t)width;      // NumPy's S<width> truncates longer strings
+        memcpy(o, line.data(), take);
+        memset(o + take, 0, (size_t)width - take);                           // ... and pads shorter ones with NUL
+    }
+    return AP_OK;
+}
+
 int ap_host_inflate_tiles(void* dst, const char* const* paths, int n, size_t bytes_each) {
     AP_REQUIRE(dst && (paths || n == 0) && n >= 0 && bytes_each > 0, "ap_host_inflate_tiles: bad arguments");
     std::vector<unsigned char> buf;

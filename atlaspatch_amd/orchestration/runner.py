@@ -52,6 +52,7 @@ class ProcessingRunner:
         self.wsi_loader = wsi_loader
         self.show_progress = show_progress
         self.rank, self.world_size = int(rank), max(1, int(world_size))
+        self._device_index = None
 
     # ------------------------------------------------------------------ discovery
     def discover_slides(self) -> list[Slide]:
@@ -139,6 +140,22 @@ class ProcessingRunner:
         failures: list[tuple] = []
         bar = tqdm(total=len(slides), disable=not self.show_progress, desc="Processing slides")
         tick = (lambda: bar.update(1)) if self.show_progress else (lambda: None)
+        import concurrent.futures as futures
+        import torch
+        self._device_index = torch.cuda.current_device() if torch.cuda.is_available() else None
+        workers = self.config.extraction.workers or min(8, os.cpu_count() or 1)
+        open_cap = max(1, int(self.config.extraction.max_open_slides or 200))
+        pool = futures.ThreadPoolExecutor(max_workers=max(1, int(workers)), thread_name_prefix="coords")
+        inflight: list = []
+
+        def drain(item):
+            slide, fut = item
+            try:
+                results.append(fut.result())
+            except Exception as exc:  # noqa: BLE001
+                failures.append((slide, exc))
+                logger.error("Extraction failed for %s: %s", slide.path.name, exc)
+            tick()
 
         for group in _batches(slides, max(1, self.config.segmentation.batch_size)):
             opened = []
@@ -173,23 +190,33 @@ class ProcessingRunner:
                     self._release_lock(fd, lock_path)
                     tick()
                 continue
+            # coordinates + H5 of a segmented slide run on a worker pool (the reference's PatchExtractionExecutor:
+            # orchestration/parallel.py:105-160, `--patch-workers` threads, at most `--max-open-slides` slides open) while
+            # this thread goes on to segment the next group; results keep the submission order
             for (slide, wsi, fd, lock_path), mask in zip(opened, masks):
-                try:
-                    with stage("coords_and_h5"):
-                        result = self.extractor.extract(wsi, mask.data, slide=slide)
-                    if self.visualizer is not None:
-                        with stage("visualize"):
-                            self.visualizer.visualize(result, wsi=wsi, mask=mask.data)
-                    results.append(result)
-                except Exception as exc:  # noqa: BLE001
-                    failures.append((slide, exc))
-                    logger.error("Extraction failed for %s: %s", slide.path.name, exc)
-                finally:
-                    self._close(wsi)
-                    self._release_lock(fd, lock_path)
-                    tick()
+                while len(inflight) >= open_cap:
+                    drain(inflight.pop(0))
+                inflight.append((slide, pool.submit(self._extract_one, slide, wsi, fd, lock_path, mask)))
+        for item in inflight:
+            drain(item)
+        pool.shutdown(wait=True)
         bar.close()
         return results, failures
+
+    def _extract_one(self, slide, wsi, fd, lock_path, mask):
+        try:
+            if self._device_index is not None:       # the HIP device is per thread: follow the rank's device, not device 0
+                import torch
+                torch.cuda.set_device(self._device_index)
+            with stage("coords_and_h5"):
+                result = self.extractor.extract(wsi, mask.data, slide=slide)
+            if self.visualizer is not None:
+                with stage("visualize"):
+                    self.visualizer.visualize(result, wsi=wsi, mask=mask.data)
+            return result
+        finally:
+            self._close(wsi)
+            self._release_lock(fd, lock_path)
 
     @staticmethod
     def _close(wsi) -> None:

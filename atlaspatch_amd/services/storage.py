@@ -51,6 +51,26 @@ class H5PatchWriter:
         return (f"{self.slide_stem}__x{x}_y{y}_rw{rw}_rh{rh}_lv{lv}_mag{mag}_tmag{tmag}"
                 f"_total{self.total_patches}")
 
+    def _passports(self, block: np.ndarray) -> np.ndarray:
+        """S160 passports of a block of coords rows: formatted by ``ap_host_format_passports`` (same bytes as the per-row
+        ``_passport`` f-string, tested); a stem that is not ASCII takes the per-row path, which fails where the
+        reference's ``np.asarray(..., dtype="S160")`` fails."""
+        from .. import _lib
+        try:
+            prefix = self.slide_stem.encode("ascii")
+        except UnicodeEncodeError:
+            return np.asarray([self._passport(*row) for row in block.tolist()], dtype=self._passport_dtype)
+        if self.total_patches is None:
+            raise RuntimeError("total_patches must be set before generating passports")
+        mag = self.level0_mag if self.level0_mag else "na"
+        tmag = self.target_mag if self.target_mag else "na"
+        suffix = f"_mag{mag}_tmag{tmag}_total{self.total_patches}".encode("ascii")
+        block = np.ascontiguousarray(block, dtype=np.int32).reshape(-1, 5)
+        out = np.empty(block.shape[0], dtype=self._passport_dtype)
+        _lib.check(_lib.load().ap_host_format_passports(block.ctypes.data, block.shape[0], prefix, suffix, out.ctypes.data,
+                                                        self._passport_dtype.itemsize), "ap_host_format_passports")
+        return out
+
     def _open_seeded(self, output_path: Path) -> H5AppendWriter:
         writer = H5AppendWriter(str(output_path), chunk_rows=self.chunk_rows)
         writer.append({"coords": np.empty((0, 5), dtype=np.int32),
@@ -73,8 +93,7 @@ class H5PatchWriter:
         try:
             for start in range(0, coords.shape[0], self.chunk_rows):
                 block = coords[start:start + self.chunk_rows]
-                passports = np.asarray([self._passport(*row) for row in block.tolist()],
-                                       dtype=self._passport_dtype)
+                passports = self._passports(block)
                 writer.append({"coords": block, "passports": passports})
             writer.update_file_attrs({"num_patches": int(coords.shape[0])})
             writer.close()

@@ -10,6 +10,7 @@ reads and writes, and scalar int / float / str attributes stored the way h5py st
 from __future__ import annotations
 
 import ctypes as C
+import threading
 import ctypes.util
 import glob
 import os
@@ -65,6 +66,32 @@ def available() -> bool:
         return False
 
 
+class _Serialised:
+    """libhdf5 is not thread-safe unless built with --enable-threadsafe (the system's is not; h5py guards it with one
+    global lock for the same reason).  The coordinate path writes H5 files from worker threads while the main thread reads
+    others, so every call into the library goes through ONE re-entrant lock; ctypes would otherwise release the interpreter
+    lock and let two threads into the library at once."""
+
+    def __init__(self, lib) -> None:
+        self._raw = lib
+        self._cache: dict = {}
+
+    def __getattr__(self, name):
+        fn = self._cache.get(name)
+        if fn is None:
+            raw = getattr(self._raw, name)
+
+            def call(*args, _raw=raw):
+                with _H5_LOCK:
+                    return _raw(*args)
+
+            fn = self._cache[name] = call
+        return fn
+
+
+_H5_LOCK = threading.RLock()
+
+
 def _load():
     global _lib
     if _lib is not None:
@@ -77,8 +104,8 @@ def _load():
             if lib.H5open() < 0:
                 continue
             _declare(lib)
-            _lib = lib
-            return lib
+            _lib = _Serialised(lib)
+            return _lib
         except OSError as exc:          # noqa: PERF203
             last = exc
     raise H5LiteError("No HDF5 backend: h5py is not importable and libhdf5 was not found "
@@ -139,7 +166,7 @@ def _declare(lib):
 
 
 def _g(name: str) -> int:
-    return hid_t.in_dll(_load(), name).value
+    return hid_t.in_dll(_load()._raw, name).value
 
 
 def _ok(code, what):

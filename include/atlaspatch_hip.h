@@ -74,6 +74,12 @@ int ap_host_gather_tiles(void* dst, const void* const* src, int n, size_t bytes_
  * format takes (the reference's per-tile Python read, services/feature_embedding.py:86-95, cannot leave the interpreter). */
 int ap_host_inflate_tiles(void* dst, const char* const* paths, int n, size_t bytes_each);
 
+/* Passport strings of services/storage.py:387-392 for n coords rows, without the per-row Python f-string (58 938 rows of a
+ * 100 000 x 100 000 slide: 75 ms in the interpreter): out[i] = prefix + "__x{X}_y{Y}_rw{RW}_rh{RH}_lv{LV}" + suffix, where the
+ * caller passes prefix = slide stem and suffix = "_mag{MAG}_tmag{TMAG}_total{TOTAL}"; each entry is `width` bytes (NumPy
+ * S<width>: NUL padded, truncated when longer).  coords: HOST int32 [n, 5].  Host only. */
+int ap_host_format_passports(const int32_t* coords, int n, const char* prefix, const char* suffix, char* out, int width);
+
 /* The same for tiles stored as baseline JPEG files (what a real slide's tiles are; core/wsi/openslide_wsi.py:184-205 decodes
  * them one by one in the interpreter): reads and decodes n files into consecutive side x side x 3 RGB slots with the
  * system's libjpeg-turbo (libjpeg.so.8, loaded on first use; the pixels are the ones PIL's Image.open(...).convert("RGB")

@@ -634,3 +634,53 @@ def test_pin_order_is_numa_local_first_and_disjoint_across_local_ranks(tmp_path)
     finally:
         for k, v in old.items():
             os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+
+
+def test_native_passports_equal_the_python_format_string():
+    """H5PatchWriter._passports (ap_host_format_passports) == the per-row f-string of services/storage.py:387-392 for
+    every sign / width of the five integers, long stems (S160 truncation), mag / target-mag 0 -> "na"."""
+    from atlaspatch_amd.services.storage import H5PatchWriter
+    rng = np.random.default_rng(0)
+    for stem, mag, tmag in [("s000", 20, 20), ("a very long slide name " * 8, 40, 0), ("x", 0, 20), ("CMU-1", 20, 40)]:
+        w = H5PatchWriter(chunk_rows=8192, patch_size=256, patch_size_level0=256, level0_mag=mag, target_mag=tmag,
+                          level0_wh=(100000, 100000), overlap=0, slide_stem=stem, wsi_path="/x")
+        w.total_patches = 58938
+        block = np.concatenate([rng.integers(-5000, 2 ** 31 - 1, (2000, 5)), rng.integers(0, 100000, (2000, 5)),
+                                np.array([[0, 0, 0, 0, 0], [-2 ** 31, 2 ** 31 - 1, -1, 10, 9]])]).astype(np.int32)
+        got = w._passports(block)
+        want = np.asarray([w._passport(*r) for r in block.tolist()], dtype="S160")
+        assert got.dtype == want.dtype and np.array_equal(got, want), stem
+    w = H5PatchWriter(chunk_rows=8, patch_size=256, patch_size_level0=256, level0_mag=20, target_mag=20, level0_wh=(10, 10),
+                      overlap=0, slide_stem="s", wsi_path="/x")
+    with pytest.raises(RuntimeError):
+        w._passports(np.zeros((1, 5), np.int32))          # total_patches not set, like _passport
+
+
+def test_h5_backend_survives_concurrent_writers_and_readers(tmp_path):
+    """The coordinate path writes one H5 per slide from worker threads (orchestration/runner.py) while other threads read:
+    the ctypes binding over a non-thread-safe libhdf5 serialises every library call.  16 threads write and re-read their
+    own files at once; every file must come back intact."""
+    import concurrent.futures as futures
+    from atlaspatch_amd.services.storage import H5PatchWriter, read_coords
+    from atlaspatch_amd.utils.h5 import h5
+
+    def work(i):
+        rng = np.random.default_rng(i)
+        n = int(rng.integers(1000, 20000))
+        coords = rng.integers(0, 100000, (n, 5)).astype(np.int32)
+        path = tmp_path / f"s{i}.h5"
+        w = H5PatchWriter(chunk_rows=2048, patch_size=256, patch_size_level0=256, level0_mag=20, target_mag=20,
+                          level0_wh=(100000, 100000), overlap=0, slide_stem=f"s{i}", wsi_path=f"/x/s{i}")
+        assert w.write_coords_array(path, coords) == n
+        feats = rng.standard_normal((n, 64)).astype(np.float32)
+        w.append_feature_matrix(output_path=path, feature_name="enc", features=feats, feature_attrs={"name": "enc", "embedding_dim": 64},
+                                feature_batch=512, expected_total=n)
+        assert np.array_equal(read_coords(path), coords)
+        with h5.File(path, "r") as f:
+            assert np.array_equal(f["features"]["enc"][:], feats) and int(f.attrs["num_patches"]) == n
+            first = f["passports"][0]
+        assert bytes(first).rstrip(b"\\0").decode().startswith(f"s{i}__x{coords[0, 0]}_y{coords[0, 1]}")
+        return n
+
+    with futures.ThreadPoolExecutor(16) as pool:
+        assert all(n > 0 for n in pool.map(work, range(32)))

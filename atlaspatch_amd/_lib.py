@@ -17,6 +17,10 @@ AP_ERR_CAPACITY = -6
 AP_ERR_UNSUPPORTED = -4
 AP_ERR_INVALID = -1
 
+# Stream capture (the SAM2 hipGraph) must not overlap synchronous HIP calls on the legacy stream from other threads (the
+# encoder built on a side thread uploads weights with hipMemcpy): both sides hold this lock for their critical section.
+HIP_CAPTURE_LOCK = threading.RLock()
+
 _LIB_NAME = "libatlaspatch_hip.so"
 _lock = threading.Lock()
 _lib = None

@@ -128,6 +128,10 @@ def _run_pipeline(*, wsi_path, output, patch_size, step_size, target_mag, device
                               visualizer=DefaultVisualizationService(app_cfg.output, app_cfg.extraction, app_cfg.visualization),
                               mpp_resolver=CSVMPPResolver(app_cfg.processing.mpp_csv), wsi_loader=loader,
                               show_progress=not verbose, rank=rank, world_size=world)
+    service = None
+    if app_cfg.features is not None:
+        service = PatchFeatureEmbeddingService(app_cfg.extraction, app_cfg.output, app_cfg.features, registry=registry)
+        service.prefetch_extractor()         # the first encoder is built on a side thread while phase 1 runs
     try:
         with stage("phase1_segment_and_coords"):
             results, failures = runner.run()
@@ -135,8 +139,7 @@ def _run_pipeline(*, wsi_path, output, patch_size, step_size, target_mag, device
         segmenter.close()
     click.echo("Segmentation and patch coordinate extraction complete.")
 
-    if app_cfg.features is not None:
-        service = PatchFeatureEmbeddingService(app_cfg.extraction, app_cfg.output, app_cfg.features, registry=registry)
+    if service is not None:
         units = len(results) * len(app_cfg.features.extractors)
         bar = tqdm(total=units, desc="Feature embedding", disable=verbose or units == 0)
         try:

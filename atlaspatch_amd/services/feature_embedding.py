@@ -88,6 +88,14 @@ class PatchFeatureEmbeddingService(FeatureEmbeddingService):
         # them (ATLASPATCH_GATHER_FEATURES), so that the all-gather does not read the matrices back from disk
         self.feature_blocks: dict = {}
         self._keep_blocks = bool(os.environ.get("ATLASPATCH_GATHER_FEATURES"))
+        # embed_all pipelines slides: slide k's feature matrix lands in one of two grow-only pinned buffers and is written to
+        # its H5 by a writer thread while slide k + 1 embeds into the other; the first encoder can be built on a side thread
+        # while phase 1 (segmentation + coordinates) still runs (prefetch_extractor)
+        self._result_bufs: list = [None, None]
+        self._result_busy: list = [None, None]
+        self._result_next = 0
+        self._h5_pool = None
+        self._prefetched = None
 
     # ------------------------------------------------------------------ bookkeeping
     def _existing(self, h5_path: Path, expected_total: int | None = None) -> set[str]:
@@ -176,11 +184,14 @@ class PatchFeatureEmbeddingService(FeatureEmbeddingService):
                              overlap=max(0, int(self.cfg.patch_size) - int(step)),
                              slide_stem=result.slide.stem, wsi_path=str(wsi.path))
 
-    def _embed_with_extractor(self, *, result: ExtractionResult, wsi: IWSI, extractor) -> ExtractionResult:
+    def _embed_with_extractor(self, *, result: ExtractionResult, wsi: IWSI, extractor, defer=None) -> ExtractionResult:
+        """``defer`` (embed_all only): a list that receives ``(slide, future)`` when the H5 write of this slide's feature
+        matrix was handed to the writer thread; the lock is released and the bookkeeping done there, after the write."""
         fd, lock_path = self._lock(result.slide)
         if fd is None:
             logger.info("Skipping feature embedding for %s (locked by another process).", result.slide.path.name)
             return self._stamp(result)
+        deferred = False
         try:
             if extractor.name.lower() in self._existing(result.h5_path, expected_total=result.num_patches):
                 logger.info("Skipping feature embedding for %s (feature '%s' already exists).",
@@ -189,29 +200,103 @@ class PatchFeatureEmbeddingService(FeatureEmbeddingService):
             attrs = {"name": extractor.name, "embedding_dim": extractor.embedding_dim}
             writer = self._writer(result, wsi)
             if isinstance(extractor, HipViTFeatureExtractor):
+                slot = self._result_slot() if defer is not None else None
                 with stage("embed_matrix"):
-                    feats = self.embed_matrix(result, wsi, extractor)
+                    feats = self.embed_matrix(result, wsi, extractor, slot=slot)
                 if self._keep_blocks:
-                    self.feature_blocks[(str(result.h5_path), extractor.name.lower())] = feats
-                with stage("h5_features"):
-                    writer.append_feature_matrix(output_path=result.h5_path, feature_name=extractor.name,
-                                                 features=feats, feature_attrs=attrs,
-                                                 feature_batch=self.feature_cfg.batch_size,
-                                                 expected_total=result.num_patches)
-            else:
-                writer.append_features(output_path=result.h5_path, entries=self._entries(wsi, result),
-                                       feature_name=extractor.name,
-                                       feature_fn=lambda patches, ex=extractor: ex.extract_batch(
-                                           patches, batch_size=self.feature_cfg.batch_size),
-                                       feature_attrs=attrs, feature_batch=self.feature_cfg.batch_size,
-                                       expected_total=result.num_patches)
+                    self.feature_blocks[(str(result.h5_path), extractor.name.lower())] = np.array(feats, copy=True)
+
+                def write_and_finish(feats=feats):
+                    try:
+                        with stage("h5_features"):
+                            writer.append_feature_matrix(output_path=result.h5_path, feature_name=extractor.name,
+                                                         features=feats, feature_attrs=attrs,
+                                                         feature_batch=self.feature_cfg.batch_size,
+                                                         expected_total=result.num_patches)
+                        self._remember(result.h5_path, extractor.name, result.num_patches)
+                        self._finish(result, extractor.name)
+                    finally:
+                        self._unlock(fd, lock_path)
+
+                if defer is not None:
+                    if self._h5_pool is None:
+                        import concurrent.futures as futures
+                        self._h5_pool = futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="h5-features")
+                    fut = self._h5_pool.submit(write_and_finish)
+                    self._result_busy[slot] = fut
+                    defer.append((result.slide, fut))
+                    deferred = True
+                    return result
+                deferred = True                      # write_and_finish releases the lock itself
+                write_and_finish()
+                return result
+            writer.append_features(output_path=result.h5_path, entries=self._entries(wsi, result),
+                                   feature_name=extractor.name,
+                                   feature_fn=lambda patches, ex=extractor: ex.extract_batch(
+                                       patches, batch_size=self.feature_cfg.batch_size),
+                                   feature_attrs=attrs, feature_batch=self.feature_cfg.batch_size,
+                                   expected_total=result.num_patches)
             self._remember(result.h5_path, extractor.name, result.num_patches)
         finally:
-            self._unlock(fd, lock_path)
+            if not deferred:
+                self._unlock(fd, lock_path)
+        return self._finish(result, extractor.name)
+
+    def _finish(self, result: ExtractionResult, name: str) -> ExtractionResult:
         known = result.metadata.get("feature_sets", [])
-        merged = list(dict.fromkeys([*known, extractor.name])) if isinstance(known, list) else [extractor.name]
+        merged = list(dict.fromkeys([*known, name])) if isinstance(known, list) else [name]
         result.metadata["feature_sets"] = merged
         return self._stamp(result)
+
+    def _result_slot(self) -> int:
+        """Index of the pinned result buffer the next slide embeds into; waits for the writer that still reads it."""
+        slot = self._result_next
+        self._result_next = 1 - slot
+        busy = self._result_busy[slot]
+        if busy is not None:
+            try:
+                busy.result()
+            except Exception:  # noqa: BLE001 -- reported through the deferred list
+                pass
+            self._result_busy[slot] = None
+        return slot
+
+    def _result_buffer(self, slot: int, rows: int, dim: int) -> torch.Tensor:
+        buf = self._result_bufs[slot]
+        if buf is None or buf.shape[0] < rows or buf.shape[1] != dim:
+            self._result_bufs[slot] = None
+            buf = self._result_bufs[slot] = torch.empty((max(rows, 2048), dim), dtype=torch.float32, pin_memory=True)
+        return buf
+
+    def prefetch_extractor(self) -> None:
+        """Build the first encoder (checkpoint load, upload, weight folding: ~0.1-0.2 s) on a side thread; embed_all picks it
+        up.  Called by the CLI before phase 1 so that the build overlaps segmentation + coordinates."""
+        if self._prefetched is not None or not self.extractor_names:
+            return
+        import concurrent.futures as futures
+        name = self.extractor_names[0]
+        device_index = torch.cuda.current_device() if (self.device.type == "cuda" and torch.cuda.is_available()) else None
+
+        def build():
+            if device_index is not None:
+                torch.cuda.set_device(device_index)          # the HIP device is per thread
+            from .. import _lib
+            with stage("encoder_create"), _lib.HIP_CAPTURE_LOCK:
+                return self.registry.create(name)
+
+        pool = futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="encoder")
+        self._prefetched = (name, pool.submit(build), pool)
+
+    def _create_extractor(self, name: str):
+        if self._prefetched is not None and self._prefetched[0] == name:
+            _, fut, pool = self._prefetched
+            self._prefetched = None
+            try:
+                return fut.result()
+            finally:
+                pool.shutdown(wait=False)
+        with stage("encoder_create"):
+            return self.registry.create(name)
 
     # one ring batch: 2048 tiles quantise best onto the 256 persistent GEMM workgroups (DESIGN.md section 5); tiles that are
     # read larger than the patch size (resized on the device) shrink the batch so that a pinned slot stays <= ~0.8 GB
@@ -222,7 +307,7 @@ class PatchFeatureEmbeddingService(FeatureEmbeddingService):
         by_bytes = max(64, self._SLOT_BYTES // (tile_hw[0] * tile_hw[1] * 3))
         return max(1, min(cap, by_bytes))
 
-    def embed_matrix(self, result: ExtractionResult, wsi: IWSI, extractor: HipViTFeatureExtractor) -> np.ndarray:
+    def embed_matrix(self, result: ExtractionResult, wsi: IWSI, extractor: HipViTFeatureExtractor, *, slot=None) -> np.ndarray:
         """float32 [N, D] for one slide through the pinned tile ring (device pipeline).  Tiles cross the ring at
         their read size; ``cv2.resize`` to ``patch_size`` (feature_embedding.py:94-95) runs on the device."""
         from .tile_ring import TileRing
@@ -235,7 +320,8 @@ class PatchFeatureEmbeddingService(FeatureEmbeddingService):
             raise ValueError("coords rows of one slide must share one read size")
         tile_hw = (rh, rw)
         batch = self._ring_batch(extractor, tile_hw)
-        feats = self._embed_device_source(coords, wsi, extractor, batch)
+        pinned = self._result_buffer(slot, coords.shape[0], extractor.embedding_dim) if slot is not None else None
+        feats = self._embed_device_source(coords, wsi, extractor, batch, pinned)
         if feats is not None:
             return feats
         # sized once per (patch size, read size): short slides run as partial batches, the pinned slots are kept
@@ -254,24 +340,31 @@ class PatchFeatureEmbeddingService(FeatureEmbeddingService):
         with torch.cuda.device(extractor.device):
             return ring.run(coords, read,
                             lambda tiles, out: extractor.forward_device(_to_patch_size(tiles, ps), out),
-                            extractor.embedding_dim, read_chunk=getattr(wsi, "read_tiles_into", None))
+                            extractor.embedding_dim, read_chunk=getattr(wsi, "read_tiles_into", None), out_host=pinned)
 
-    def _embed_device_source(self, coords: np.ndarray, wsi: IWSI, extractor, batch: int):
+    def _embed_device_source(self, coords: np.ndarray, wsi: IWSI, extractor, batch: int, pinned=None):
         """Backends that can materialise tiles in HBM themselves (``extract_batch_device``, e.g. the synthetic
-        slide) skip the host ring: tiles never cross PCIe.  ATLASPATCH_HOST_TILES=1 forces the ring."""
+        slide) skip the host ring: tiles never cross PCIe.  ATLASPATCH_HOST_TILES=1 forces the ring.  Features leave
+        the device batch by batch (asynchronous copies into pinned memory, hidden behind the next batch's forward)."""
         source = getattr(wsi, "extract_batch_device", None)
         if source is None or os.environ.get("ATLASPATCH_HOST_TILES"):
             return None
         n = int(coords.shape[0])
         ps = int(self.cfg.patch_size)
-        out = torch.empty((n, extractor.embedding_dim), dtype=torch.float32, device=extractor.device)
+        dim = extractor.embedding_dim
+        host = pinned if pinned is not None else torch.empty((n, dim), dtype=torch.float32, pin_memory=True)
+        outs = [torch.empty((batch, dim), dtype=torch.float32, device=extractor.device) for _ in range(2)]
         with torch.cuda.device(extractor.device):
-            for lo in range(0, n, batch):
+            for i, lo in enumerate(range(0, n, batch)):
                 tiles = source(coords[lo:lo + batch], extractor.device, ps)
                 if tiles is None:
+                    torch.cuda.synchronize(extractor.device)
                     return None
-                extractor.forward_device(_to_patch_size(tiles, ps), out[lo:lo + tiles.shape[0]])
-            return out.cpu().numpy()
+                out = outs[i & 1][:tiles.shape[0]]           # stream order protects the buffer two batches back
+                extractor.forward_device(_to_patch_size(tiles, ps), out)
+                host[lo:lo + tiles.shape[0]].copy_(out, non_blocking=True)
+            torch.cuda.synchronize(extractor.device)
+        return host[:n].numpy()
 
     def embed_all(self, results: list[ExtractionResult], *, wsi_loader, progress=None) -> list[tuple]:
         failures: list[tuple] = []
@@ -290,8 +383,7 @@ class PatchFeatureEmbeddingService(FeatureEmbeddingService):
 
         for name in self.extractor_names:
             try:
-                with stage("encoder_create"):
-                    extractor = self.registry.create(name)
+                extractor = self._create_extractor(name)
             except Exception as exc:  # noqa: BLE001
                 for res in results:
                     if name in todo.get(res.h5_path, ()):
@@ -299,6 +391,7 @@ class PatchFeatureEmbeddingService(FeatureEmbeddingService):
                         if progress:
                             progress.update(1)
                 continue
+            deferred: list = []
             try:
                 for res in results:
                     if name not in todo.get(res.h5_path, ()):
@@ -307,7 +400,7 @@ class PatchFeatureEmbeddingService(FeatureEmbeddingService):
                     try:
                         if extractor.name.lower() not in self._existing(res.h5_path, expected_total=res.num_patches):
                             wsi = wsi_loader.open(res.slide)
-                            self._embed_with_extractor(result=res, wsi=wsi, extractor=extractor)
+                            self._embed_with_extractor(result=res, wsi=wsi, extractor=extractor, defer=deferred)
                         self._stamp(res)
                     except Exception as exc:  # noqa: BLE001
                         failures.append((res.slide, exc))
@@ -320,6 +413,14 @@ class PatchFeatureEmbeddingService(FeatureEmbeddingService):
                     if progress:
                         progress.update(1)
             finally:
+                # the writer thread still holds this extractor's last matrices: every H5 of this extractor is complete
+                # (and its lock released) before the next extractor -- or the caller -- looks at the files again
+                for slide, fut in deferred:
+                    try:
+                        fut.result()
+                    except Exception as exc:  # noqa: BLE001
+                        failures.append((slide, exc))
+                self._result_busy = [None, None]
                 try:
                     extractor.cleanup()
                 except Exception:  # noqa: BLE001
@@ -327,4 +428,7 @@ class PatchFeatureEmbeddingService(FeatureEmbeddingService):
         if self._ring is not None:
             self._ring.close()
             self._ring = None
+        if self._h5_pool is not None:
+            self._h5_pool.shutdown(wait=True)
+            self._h5_pool = None
         return failures

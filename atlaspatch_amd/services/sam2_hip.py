@@ -393,10 +393,11 @@ class Sam2HipPredictor:
             self._static_img = torch.empty((self.input_size, self.input_size, 3), dtype=torch.uint8, device=self.device)
             self._static_img.copy_(img)
             self._forward_mask(self._static_img)                 # warm-up outside the capture (lazy initialisation)
-            torch.cuda.synchronize(self.device)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                self._static_mask = self._forward_mask(self._static_img)
+            with _lib.HIP_CAPTURE_LOCK:                          # no weight upload of a side thread inside the capture
+                torch.cuda.synchronize(self.device)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    self._static_mask = self._forward_mask(self._static_img)
             self._graph = graph
         self._static_img.copy_(img)
         self._graph.replay()

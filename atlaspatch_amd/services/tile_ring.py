@@ -135,18 +135,22 @@ class TileRing:
 
     def run(self, coords: np.ndarray, read_tile: Callable[[int, int, int, int, int], np.ndarray],
             forward: Callable[[torch.Tensor, torch.Tensor], None], out_dim: int, *,
-            read_chunk: Callable | None = None) -> np.ndarray:
+            read_chunk: Callable | None = None, out_host: torch.Tensor | None = None) -> np.ndarray:
         """coords int32 [N, 5]; ``read_tile(x, y, rw, rh, lv)`` -> uint8 [th, tw, 3];
         ``forward(tiles_dev [n,th,tw,3], out_dev [n,D])`` enqueues on the current stream.
         ``read_chunk(rows, dst_ptr, tile_side) -> bool`` (optional): a backend's native batched decoder; when it
-        returns True the chunk's tiles are already in the pinned slot.  Returns float32 [N, D] (host; a fresh array)."""
+        returns True the chunk's tiles are already in the pinned slot.  Returns float32 [N, D] (host; a fresh array --
+        or, when the caller passes its own pinned ``out_host`` [>= N, D], a view of that buffer: no extra copy)."""
         n_total = int(coords.shape[0])
         if n_total == 0:
             return np.empty((0, out_dim), dtype=np.float32)
         # grow-only pinned result buffer: re-pinning [N, D] for every slide costs more than the copy out of it
-        if self._out_host is None or self._out_host.shape[0] < n_total or self._out_host.shape[1] != out_dim:
-            self._out_host = torch.empty((max(n_total, self.batch), out_dim), dtype=torch.float32, pin_memory=True)
-        out_host = self._out_host
+        own = out_host is None
+        if own:
+            if self._out_host is None or self._out_host.shape[0] < n_total or self._out_host.shape[1] != out_dim:
+                self._out_host = torch.empty((max(n_total, self.batch), out_dim), dtype=torch.float32, pin_memory=True)
+            out_host = self._out_host
+        assert out_host.shape[0] >= n_total and out_host.shape[1] == out_dim and out_host.is_pinned()
         out_dev = [torch.empty((self.batch, out_dim), dtype=torch.float32, device=self.device)
                    for _ in range(self.slots)]
         compute = torch.cuda.current_stream(self.device)
@@ -233,7 +237,7 @@ class TileRing:
             torch.cuda.synchronize(self.device)
             raise
         torch.cuda.synchronize(self.device)
-        return out_host[:n_total].numpy().copy()
+        return out_host[:n_total].numpy().copy() if own else out_host[:n_total].numpy()
 
     def close(self) -> None:
         self.pool.shutdown(wait=True)

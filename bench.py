@@ -291,6 +291,67 @@ def jpeg_store_rate(device, tmp):
                     "lock) -> pinned ring -> H2D -> K1 + ViT-B/16 f16 -> H5"}
 
 
+def openslide_stub_rate(device, ex, tmp):
+    """Tiles of a 100 000^2 slide served by a stand-in libopenslide (tools/stub_openslide: libopenslide's interface, hash
+    pixels with partial alpha; the real library is not in the image) through OpenSlideWSI.read_tiles_into ->
+    ap_host_openslide_read_tiles on the ring's pinned threads -> pinned ring -> H2D -> K1 + ViT-B/16 -> pinned features.
+    The coords are the synthetic 100 000^2 slide's 58 938 rows (segmentation is the same for every backend and is timed
+    elsewhere).  Runs in a subprocess: libopenslide is resolved once per process."""
+    import subprocess
+    import textwrap
+    from tools import stub_openslide as so
+    lib = so.build(os.path.join(tmp, "stublib"))
+    code = f"""
+        import json, os, sys, time, numpy as np, torch
+        sys.path.insert(0, {ROOT!r})
+        from tools import stub_openslide as so
+        from atlaspatch_amd.core.wsi import openslide_wsi
+        from atlaspatch_amd.core.wsi.synth_pixels import SynthSpec, analytic_mask
+        from atlaspatch_amd.encoders.vit import build_hip_vit_extractor
+        from atlaspatch_amd.services.extraction import coords_from_mask
+        from atlaspatch_amd.services.tile_ring import TileRing
+        openslide_wsi.openslide = so.python_module({lib!r})
+        path = so.write_slide({os.path.join(tmp, 'stub100k.svs')!r}, 100000, 100000, seed=9, alpha_period=3)
+        spec = SynthSpec(width=100000, height=100000, seed=1234)
+        coords, _ = coords_from_mask(analytic_mask(spec), level0_wh=(100000, 100000), downsamples=[1.0, 4.0, 16.0], src_mag=20,
+                                     tgt_mag=20, patch_size=256, step_size=None, tissue_thresh=0.0)
+        dev = torch.device("cuda:0")
+        ex = build_hip_vit_extractor(name="vit_b_16", arch="vit_b_16", device=dev, dtype=torch.float16, random_init_seed=0, max_batch=2048)
+        wsi = openslide_wsi.OpenSlideWSI(path)
+        wsi._ensure_loaded()
+        workers = min(64, os.cpu_count() or 8)
+        ring = TileRing(device=dev, batch=2048, patch_size=256, slots=3, workers=workers)
+        read = lambda x, y, rw, rh, lv: wsi.extract((x, y), lv=lv, wh=(rw, rh), mode="array")
+        fwd = lambda t, o: ex.forward_device(t, o)
+        ring.run(coords[:4096], read, fwd, 768, read_chunk=wsi.read_tiles_into)
+        t0 = time.perf_counter()
+        feats = ring.run(coords, read, fwd, 768, read_chunk=wsi.read_tiles_into)
+        dt = time.perf_counter() - t0
+        # decode-only rate of the hook (no GPU work): the ring's threads, one slot
+        import concurrent.futures as futures
+        n = 8192
+        host = np.empty((n, 256, 256, 3), np.uint8)
+        rows = coords[:n].tolist()
+        chunk = 32
+        t1 = time.perf_counter()
+        with futures.ThreadPoolExecutor(workers) as pool:
+            list(pool.map(lambda s: wsi.read_tiles_into(rows[s:s + chunk], host.ctypes.data + s * 196608, 256), range(0, n, chunk)))
+        dt_read = time.perf_counter() - t1
+        assert np.isfinite(feats).all() and feats.shape == (coords.shape[0], 768)
+        print(json.dumps(dict(patches_per_s=round(coords.shape[0] / dt, 1), tiles=int(coords.shape[0]), seconds=round(dt, 3),
+                              host_threads=workers, hook_read_only_tiles_per_s=round(n / dt_read, 1))))
+        """
+    env = dict(os.environ, ATLASPATCH_LIBOPENSLIDE=lib)
+    res = subprocess.run([sys.executable, "-c", textwrap.dedent(code)], capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    if res.returncode != 0:
+        return {"error": (res.stdout + res.stderr)[-600:]}
+    out = json.loads(res.stdout.strip().splitlines()[-1])
+    out["what"] = ("58938 tiles of a 100000x100000 slide read by a stand-in libopenslide through the native batched hook "
+                   "(ap_host_openslide_read_tiles: premultiplied ARGB -> RGB as openslide-python + PIL do, outside the interpreter "
+                   "lock) -> pinned ring -> H2D -> K1 + ViT-B/16 f16 -> features; hook_read_only = the hook alone on the same threads")
+    return out
+
+
 def secondary_rates(device, ex, tiles, B):
     """Rates that are NOT `value` (outside its timed region), measured in the same process so that the driver's line
     carries them: PCIe-inclusive ring, end-to-end CLI on the 100 000^2 slide (device tile source / host ring with the
@@ -334,48 +395,95 @@ def secondary_rates(device, ex, tiles, B):
                                          "host: synchronous H2D + forward + D2H, the drop-in boundary as the reference "
                                          "calls it (storage.py:283-294)"}
     del host
-    # ---- (3) end-to-end `process` CLI on the north-star slide (100 000 x 100 000), f16, weights from a file
+    # ---- (3) end-to-end `process` CLI, f16, weights from a file: config 2's own slide (40 000^2), the north-star slide
+    #      (100 000^2; device tile source / host ring), eight 100 000^2 slides in one invocation, with the stage breakdown
+    from atlaspatch_amd.utils import stages as stage_table
     with tempfile.TemporaryDirectory() as tmp:
         from safetensors.torch import save_file
         from atlaspatch_amd.encoders.vit import ARCHS, random_canonical_state_dict
         save_file(random_canonical_state_dict(ARCHS["vit_b_16"], 0), os.path.join(tmp, "vit_b_16.safetensors"))
-        slide = os.path.join(tmp, "big.synth")
-        json.dump({"width": 100000, "height": 100000, "seed": 1234, "mag": 20, "mpp": 0.5, "downsamples": [1, 4, 16]},
-                  open(slide, "w"))
-        for key, host_tiles in (("e2e_cli_100k_device_tile_source", False), ("e2e_cli_100k_host_ring", True)):
-            env = {"ATLASPATCH_WEIGHTS_DIR": tmp}
-            if host_tiles:
-                env["ATLASPATCH_HOST_TILES"] = "1"
+
+        def synth(name, side, seed=1234):
+            path = os.path.join(tmp, name)
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            json.dump({"width": side, "height": side, "seed": seed, "mag": 20, "mpp": 0.5, "downsamples": [1, 4, 16]}, open(path, "w"))
+            return path
+
+        def run_cli(command, target, out_name, env, extra=()):
+            env = dict(env, ATLASPATCH_WEIGHTS_DIR=tmp)
             old = {k: os.environ.get(k) for k in list(env) + ["ATLASPATCH_RANDOM_INIT"]}
             os.environ.update(env)
-            os.environ.pop("ATLASPATCH_RANDOM_INIT", None)
+            if "ATLASPATCH_RANDOM_INIT" not in env:
+                os.environ.pop("ATLASPATCH_RANDOM_INIT", None)
             try:
-                out_dir = os.path.join(tmp, "out_" + key)
+                out_dir = os.path.join(tmp, out_name)
+                stage_table.snapshot(reset=True)
                 t0 = time.perf_counter()
-                res = CliRunner().invoke(cli, ["process", slide, "-o", out_dir, "--patch-size", "256", "--target-mag", "20",
-                                               "--feature-extractors", "vit_b_16", "--feature-precision", "float16",
-                                               "--feature-num-workers", str(min(64, os.cpu_count() or 8))],
+                res = CliRunner().invoke(cli, [command, target, "-o", out_dir, "--patch-size", "256", "--target-mag", "20", *extra],
                                          catch_exceptions=False)
                 dt = time.perf_counter() - t0
                 assert res.exit_code == 0 and "failures: 0" in res.output, res.output
-                with h5.File(os.path.join(out_dir, "patches", "big.h5"), "r") as f:
-                    n = int(f["coords"].shape[0])
-                    assert f["features"]["vit_b_16"].shape == (n, 768)
-                rates[key] = {"patches_per_s": round(n / dt, 1), "tiles": n, "seconds": round(dt, 3),
-                              "what": ("`process` on one synthetic 100000x100000 slide: checkpoint load, analytic "
-                                       "segmentation, device coords, H5 coords, " +
-                                       ("tiles rendered on HOST threads by the native renderer (the stand-in decoder) -> "
-                                        "pinned ring -> H2D" if host_tiles else "tiles from the slide's device tile source") +
-                                       ", K1 + ViT-B/16 f16, H5 features")}
+                return out_dir, dt, {k: v["seconds"] for k, v in stage_table.snapshot(reset=True).items()}
             finally:
                 for k, v in old.items():
                     if v is None:
                         os.environ.pop(k, None)
                     else:
                         os.environ[k] = v
+
+        feat = ("--feature-extractors", "vit_b_16", "--feature-precision", "float16",
+                "--feature-num-workers", str(min(64, os.cpu_count() or 8)))
+
+        def tiles_in(out_dir):
+            total = 0
+            for name in sorted(os.listdir(os.path.join(out_dir, "patches"))):
+                if name.endswith(".h5"):
+                    with h5.File(os.path.join(out_dir, "patches", name), "r") as f:
+                        n = int(f["coords"].shape[0])
+                        assert f["features"]["vit_b_16"].shape == (n, 768)
+                        total += n
+            return total
+
+        what = ("`process`: checkpoint load (side thread, overlaps phase 1), analytic segmentation, device coords, H5 coords, {}"
+                ", K1 + ViT-B/16 f16, H5 features (writer thread); stage seconds are sums per stage, overlapping stages included")
+        slide40, slide100 = synth("s40.synth", 40000), synth("big.synth", 100000)
+        run_cli("process", slide40, "warm", {}, feat)                    # first invocation of the process: kernels, allocator
+        for key, target, env, src in (("e2e_cli_40k", slide40, {}, "tiles from the slide's device tile source"),
+                                      ("e2e_cli_100k_device_tile_source", slide100, {}, "tiles from the slide's device tile source"),
+                                      ("e2e_cli_100k_host_ring", slide100, {"ATLASPATCH_HOST_TILES": "1"},
+                                       "tiles rendered on HOST threads by the native renderer (the stand-in decoder) -> pinned ring -> H2D")):
+            out_dir, dt, st = run_cli("process", target, "out_" + key, env, feat)
+            n = tiles_in(out_dir)
+            rates[key] = {"patches_per_s": round(n / dt, 1), "tiles": n, "seconds": round(dt, 3), "stage_seconds": st,
+                          "what": what.format(src)}
+        for i in range(8):
+            synth(f"eight/s{i}.synth", 100000, seed=300 + i)
+        out_dir, dt, st = run_cli("process", os.path.join(tmp, "eight"), "out_eight", {}, feat)
+        n = tiles_in(out_dir)
+        rates["e2e_cli_8x100k_one_gpu"] = {"patches_per_s": round(n / dt, 1), "tiles": n, "slides": 8, "seconds": round(dt, 3),
+                                           "stage_seconds": st, "what": "one `process` invocation over a folder of eight 100000x100000 "
+                                           "slides on one GPU: slide k's H5 write overlaps slide k + 1's embedding"}
+        # ---- (3a) segment-and-get-coords with the SAM2 segmenter forced on synthetic slides (seeded random SAM2 weights: the
+        #      masks are arbitrary, the work is not): thumbnail -> SAM2 -> contours -> grid -> H5, 64 slides of 100 000^2
+        from atlaspatch_amd.services.segmentation import random_sam2_state_dict
+        torch.save({"model": random_sam2_state_dict(0)}, os.path.join(tmp, "sam2.pt"))
+        for i in range(64):
+            synth(f"seg/s{i:03d}.synth", 100000, seed=500 + i)
+        seg_env = {"ATLASPATCH_SEGMENTER": "sam2"}
+        run_cli("segment-and-get-coords", os.path.join(tmp, "eight"), "seg_warm", seg_env)
+        out_dir, dt, st = run_cli("segment-and-get-coords", os.path.join(tmp, "seg"), "out_seg", seg_env)
+        steady = max(1e-9, st.get("segmentation", 0.0))
+        rates["segment_and_get_coords"] = {
+            "slides_per_s": round(64 / dt, 2), "slides": 64, "seconds": round(dt, 3), "ms_per_slide": round(dt / 64 * 1e3, 2),
+            "stage_seconds": st, "reference_published": "~19 s per 100 WSIs (docs/release-notes/v1.0.0.md:17; hardware unstated)",
+            "what": "one `segment-and-get-coords` invocation over 64 synthetic 100000x100000 slides, SAM2 checkpoint loaded from a "
+                    "file: level read + cv2 / Pillow thumbnail + SAM2 (hipGraph) + mask resize on the device, contours + grid + "
+                    "H5 on worker threads; includes the per-invocation predictor build and graph capture"}
         # ---- (3b) the same slide with its tiles stored as JPEG files (quality 80, 4:2:0), decoded by the ring's pinned host
         #      threads through the native batched decoder (ap_host_decode_jpeg_tiles, libjpeg-turbo outside the interpreter lock)
         rates["e2e_cli_100k_jpeg_store"] = jpeg_store_rate(device, tmp)
+        # ---- (3c) tiles served by (stub) OpenSlide through the native batched hook
+        rates["e2e_openslide_stub_100k"] = openslide_stub_rate(device, ex, tmp)
     # ---- (4) float32 mode (the 1e-3 parity mode): value + fc1 roofline fraction against the f32 MFMA peak
     Bf = 512
     ex32 = build_hip_vit_extractor(name="vit_b_16", arch="vit_b_16", device=device, dtype=torch.float32,

@@ -561,6 +561,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
 #ifdef AP_G256_ALT
         if (g.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(ti, 3); }
 #endif
+#ifdef AP_G256_ALT
+        // ablation bit 8 (timing only): no epilogue body at all (drain and accumulator restart stay) = the bound on what
+        // hiding the epilogue behind another tile's MFMAs could return
+        if (g.ablate & 8) {
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) asm volatile("" ::"v"(acc[nb][mb]));
+        } else
+#endif
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
             if constexpr (EPI == EPI_BIAS_RESID) {

@@ -182,9 +182,11 @@ int ap_gemm_fused(int dtype, int epilogue, const void* A, int lda, const void* W
     ap::GemmArgs g{};
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K;
     g.bias = bias; g.colsum = colsum; g.rowstats = rowstats; g.partial = partial; g.out = out; g.ldo = ldo;
-    AP_REQUIRE(impl == 0 || impl == 128 || impl == 256, "ap_gemm_fused: impl %d (0 = pick, 128, 256)", impl);
+    const int variant = (int)((unsigned)impl >> 12);      // bits 12..: kernel tuning variant (tools only), low 12 bits: implementation
+    impl &= 0xfff;
+    AP_REQUIRE(impl == 0 || impl == 128 || impl == 256 || impl == 257, "ap_gemm_fused: impl %d (0 = pick, 128, 256; 257 = the A/B twin)", impl);
     AP_REQUIRE(M > 0 && (impl == 128 || ap::gemm256_supports(dtype, epi, g)), "ap_gemm_fused: unsupported problem (N %% 256, K %% 128, 16-byte strides)");
-    return ap::launch_gemm_impl(dtype, epi, g, impl, 0, (hipStream_t)stream);
+    return ap::launch_gemm_impl(dtype, epi, g, impl, variant, (hipStream_t)stream);
 }
 
 int ap_stream_init(int dtype, const float* tok, int rows, int dim, float eps, void* x, float* rowstats, ap_stream_t stream) {

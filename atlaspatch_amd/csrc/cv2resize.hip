@@ -24,6 +24,7 @@
 #include <tuple>
 #include <vector>
 #include "ap_common.h"
+#include <memory>
 
 namespace ap {
 namespace {
@@ -105,9 +106,19 @@ void axis_area(int ssize, int dsize, double scale, std::vector<int32_t>& beg, st
     beg[dsize] = (int32_t)si.size();
 }
 
+// Table cache: one entry per (device, shape, interpolation), at most kMaxCached of them (every slide's 1.25x thumbnail has
+// its own shape, so an unbounded cache would grow with the cohort).  Entries are handed out as shared_ptr: an evicted
+// entry's device tables are freed when its last user lets go (hipFree waits for the launches that still read them).
 using Key = std::tuple<int, int, int, int, int, int>;
+constexpr size_t kMaxCached = 64;
+struct Entry {
+    Tables t;
+    uint64_t last_use = 0;
+    ~Entry() { if (t.i32) (void)hipFree(t.i32); if (t.f32) (void)hipFree(t.f32); }
+};
 std::mutex g_mu;
-std::map<Key, Tables> g_tables;
+std::map<Key, std::shared_ptr<Entry>> g_tables;
+uint64_t g_use_clock = 0;
 
 int upload(const std::vector<int32_t>& ints, const std::vector<float>& flts, Tables& t) {
     if (!ints.empty()) {
@@ -121,14 +132,15 @@ int upload(const std::vector<int32_t>& ints, const std::vector<float>& flts, Tab
     return AP_OK;
 }
 
-int get_tables(int h, int w, int oh, int ow, int interp, const Tables** out) {
+int get_tables(int h, int w, int oh, int ow, int interp, std::shared_ptr<Entry>* out) {
     int dev = 0;
     AP_HIP_CHECK(hipGetDevice(&dev));
     const Key key{dev, h, w, oh, ow, interp};
     std::lock_guard<std::mutex> lock(g_mu);
     auto it = g_tables.find(key);
-    if (it != g_tables.end()) { *out = &it->second; return AP_OK; }
-    Tables t;
+    if (it != g_tables.end()) { it->second->last_use = ++g_use_clock; *out = it->second; return AP_OK; }
+    auto entry = std::make_shared<Entry>();
+    Tables& t = entry->t;
     const double inv_x = (double)ow / w, inv_y = (double)oh / h;
     const double scale_x = 1. / inv_x, scale_y = 1. / inv_y;
     const int isx = (int)lrint(scale_x), isy = (int)lrint(scale_y);
@@ -170,7 +182,15 @@ int get_tables(int h, int w, int oh, int ow, int interp, const Tables** out) {
             if (rc != AP_OK) return rc;
         }
     }
-    *out = &(g_tables[key] = t);
+    if (g_tables.size() >= kMaxCached) {          // drop the least recently used entry
+        auto lru = g_tables.begin();
+        for (auto i = g_tables.begin(); i != g_tables.end(); ++i)
+            if (i->second->last_use < lru->second->last_use) lru = i;
+        g_tables.erase(lru);
+    }
+    entry->last_use = ++g_use_clock;
+    g_tables[key] = entry;
+    *out = entry;
     return AP_OK;
 }
 
@@ -328,9 +348,10 @@ extern "C" int ap_cv2_resize_u8(const uint8_t* src, int n, int h, int w, uint8_t
                "ap_cv2_resize_u8: unsupported interpolation %d", interpolation);
     if (n == 0) return AP_OK;                 // an empty batch has no buffers to check
     AP_REQUIRE(src && dst, "ap_cv2_resize_u8: null pointer");
-    const Tables* t = nullptr;
-    const int rc = get_tables(h, w, oh, ow, interpolation, &t);
+    std::shared_ptr<Entry> entry;             // keeps the tables alive through the launch below
+    const int rc = get_tables(h, w, oh, ow, interpolation, &entry);
     if (rc != AP_OK) return rc;
+    const Tables* t = &entry->t;
     hipStream_t s = (hipStream_t)stream;
     const size_t total = (size_t)n * oh * ow;
     const unsigned grid = (unsigned)((total + 255) / 256);
@@ -339,7 +360,9 @@ extern "C" int ap_cv2_resize_u8(const uint8_t* src, int n, int h, int w, uint8_t
         AP_HIP_CHECK(hipMemcpyAsync(dst, src, total * 3, hipMemcpyDeviceToDevice, s));
         return AP_OK;
     case M_AREA_FAST:
-        if (t->isx == 2 && t->isy == 2 && ow % 4 == 0 && w == 2 * ow && h == 2 * oh) {
+        // the quad kernel reads 8 bytes and stores 4 at a time: only for pointers aligned accordingly (the C ABI takes any)
+        if (t->isx == 2 && t->isy == 2 && ow % 4 == 0 && w == 2 * ow && h == 2 * oh && ((uintptr_t)src & 7) == 0 &&
+            ((uintptr_t)dst & 3) == 0) {
             const size_t quads = (size_t)n * oh * (ow / 4);
             area_2x2_quad_kernel<<<(unsigned)((quads + 255) / 256), 256, 0, s>>>(src, quads, oh, ow, dst);
             break;

@@ -51,9 +51,14 @@
 #include "ap_common.h"
 #include "gemm_mma.h"
 
-// The file is compiled twice: the product build, and (-DAP_G256_ALT) an experimental twin that
-// ap_gemm reaches as impl 257, so a schedule change can be A/B-timed inside one process
-// (tools/gemm_check.py); code under `#ifdef AP_G256_ALT` is the experiment.
+// The file is compiled twice: the product build, and (-DAP_G256_ALT) a twin that ap_gemm reaches as impl 257, so a
+// schedule change can be A/B-timed inside one process (tools/gemm_check.py, tools/gemm_twin_ab.py).  The twin normally
+// also carries the diagnostics (-DAP_G256_DIAG: per-tile time stamps, start skew, ablation flags); an experiment is
+// timed with `make ALT_FLAGS="-DAP_G256_ALT -DAP_EXP_..."`, i.e. the product code plus the experiment, without them.
+// Round 3 timed three such experiments on the four ViT-B shapes (2048 images), all inside +-1 % of the product kernel
+// and none kept: the tile's first K-tile writing the accumulators with C = 0 instead of a zeroed register block; the
+// last K-tile's phase-2 / 3 stagings issued behind the drain that opens the epilogue; the two LDS-DMA loads of a phase
+// issued two MFMA pairs apart.
 #ifdef AP_G256_ALT
 #define AP_G256_FN(name) name##_alt
 #else
@@ -137,8 +142,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
     // Start-time skew: equal tiles keep every CU in step, so all epilogues (the HBM write bursts)
     // would coincide.  Workgroup j of an XCD starts j / nwx of a tile period late; the early ones are
     // the ones that own one tile more.
-    // (diagnostics -- start skew, per-tile time stamps, ablation flags -- exist only in the -DAP_G256_ALT twin, impl 257)
-#ifdef AP_G256_ALT
+    // (diagnostics -- start skew, per-tile time stamps, ablation flags -- exist only under -DAP_G256_DIAG: the twin, impl 257)
+#ifdef AP_G256_DIAG
     if (g.skew_ticks > 0) {
         const int nx = gridDim.x < 8 ? gridDim.x : 8;
         const long long until = (long long)__builtin_amdgcn_s_memrealtime() +
@@ -176,11 +181,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
         }
     };
     const uint32_t lds_wave = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + wave * 1024;
-#ifdef AP_G256_ALT
+#ifdef AP_G256_DIAG
     bool dma_off = false;
 #endif
     auto stage = [&](const Cursor& c, bool is_x, int buf, int unit) {
-#ifdef AP_G256_ALT
+#ifdef AP_G256_DIAG
         if ((g.ablate & 4) && dma_off) return;
 #endif
         const char* base = (is_x ? c.abase : c.wbase) + (size_t)c.kt * kRowBytes;
@@ -267,7 +272,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
     AP_VMCNT(8);              // X0 / Y0 of K-tile 0 have landed (phase 0 reads them)
     __builtin_amdgcn_s_barrier();
     init_acc();
-#ifdef AP_G256_ALT
+#ifdef AP_G256_DIAG
     dma_off = true;
 #endif
 
@@ -276,7 +281,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
     // DMA (issued after it) behind every wave's fragment reads of the unit it overwrites.  The
     // fragment reads written before it may be hoisted by the compiler into the previous phase's
     // MFMA block (everything they read was published by the previous barrier); the wait may not.
-#ifdef AP_G256_ALT
+#ifdef AP_G256_DIAG
     // ablation twin (timing only, results are wrong when a flag is set; ap_gemm impl 257, variant bits 0-2):
     // 1 = no counted wait, 2 = no barrier, 4 = no LDS-DMA after the prologue.  Measured (fc2, K = 3072):
     // none 1.005 ms, no wait 1.013, no barrier 0.947, no DMA 0.940, all three 0.812 -> the fragment-read ->
@@ -359,7 +364,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
     };
 
     char* scr = smem + kScratchOff + wave * 4096;
-#ifdef AP_G256_ALT
+#ifdef AP_G256_DIAG
     auto stamp = [&](int ti, int k) {
         if (g.trace && ti < g.trace_tiles && threadIdx.x == 0)
             g.trace[((size_t)blockIdx.x * g.trace_tiles + ti) * 8 + k] = (long long)__builtin_amdgcn_s_memrealtime();
@@ -376,7 +381,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
         stamp(ti, 0);
         stamp_clk(ti, 5);
         for (int kt = 0; kt < nk; kt += 2) {
-#ifdef AP_G256_ALT
+#ifdef AP_G256_DIAG
             // fine timeline (twin only): start of every K-tile pair, in a second [workgroups, tiles, 8] block of the buffer
             if (g.trace && ti < g.trace_tiles && threadIdx.x == 0 && (kt >> 1) < 8)
                 g.trace[((size_t)(gridDim.x + blockIdx.x) * g.trace_tiles + ti) * 8 + (kt >> 1)] =
@@ -477,10 +482,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
         stamp(ti, 2);
         const bool has_gamma = (EPI == EPI_BIAS_STORE || EPI == EPI_BIAS_RESID) && g.gamma != nullptr;
         const float* gp = g.gamma + n0 + hi * 4;
-#ifdef AP_G256_ALT
+#ifdef AP_G256_DIAG
         if (g.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(ti, 3); }
 #endif
-#ifdef AP_G256_ALT
+#ifdef AP_G256_DIAG
         // ablation bit 8 (timing only): no epilogue body at all (drain and accumulator restart stay) = the bound on what
         // hiding the epilogue behind another tile's MFMAs could return
         if (g.ablate & 8) {
@@ -651,7 +656,7 @@ int AP_G256_FN(launch_gemm256)(int dtype, int epilogue, const GemmArgs& a, int v
     }
     AP_REQUIRE(AP_G256_FN(gemm256_supports)(dtype, epilogue, a), "gemm256: unsupported problem");
     GemmArgs b = a;
-#ifdef AP_G256_ALT
+#ifdef AP_G256_DIAG
     b.trace = g_gemm_trace; b.trace_tiles = g_gemm_trace_tiles;
     const int skew_pct = (variant >> 4) & 0xfff;
     const int tiles = ((a.M + kBM - 1) / kBM) * (a.N / kBN);

@@ -177,7 +177,8 @@ extern "C" int ap_resample_u8(const uint8_t* src, int n, int h, int w, uint8_t* 
     if (n == 0) return AP_OK;
     hipStream_t s = (hipStream_t)stream;
     // fused LDS path: largest band (multiple of 8 output rows) whose input rows + intermediate fit 52 KiB (three workgroups / CU)
-    if ((w * 3) % 16 == 0 && (ow * 3) % 4 == 0 && n <= 65535) {
+    // (16-byte loads of the staged rows, dword stores: only for pointers aligned accordingly -- the C ABI takes any)
+    if ((w * 3) % 16 == 0 && (ow * 3) % 4 == 0 && n <= 65535 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 3) == 0) {
         int band = 0, cap = 0;
         for (int b = 64; b >= 8; b -= 8) {
             const int c = (int)(((long long)(b - 1) * h) / oh) + ksize_y + 2;

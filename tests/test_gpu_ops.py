@@ -534,3 +534,30 @@ def test_cv2_resize_exact_halving_quad_kernel(env):
             for i in range(n):
                 assert np.array_equal(got[i], R.resize(tiles[i], (ow, oh), interp)), (n, oh, ow, interp, i)
 
+
+def test_cv2_resize_takes_unaligned_pointers_and_a_bounded_table_cache(env):
+    """The C ABI accepts any pointer: source / destination buffers that start 1 .. 3 bytes off an aligned address run the
+    one-pixel-per-thread kernels and agree with the aligned launch bit for bit (the vector kernels are only dispatched on
+    aligned pointers).  And the per-shape table cache is bounded: 80 distinct shapes (more than it holds) in a row, then the
+    first again, all equal the NumPy restatement."""
+    from oracle import cv2_resize as R
+    _lib, lib, dev, stream = env
+    rng = np.random.default_rng(5)
+    n, oh, ow = 3, 20, 32
+    tiles = rng.integers(0, 256, (n, 2 * oh, 2 * ow, 3), dtype=np.uint8)
+    want = np.stack([R.resize(t, (ow, oh), 3) for t in tiles])
+    flat = torch.from_numpy(tiles.reshape(-1)).to(dev)
+    for so, do in ((0, 0), (1, 0), (0, 1), (3, 2)):
+        src = torch.zeros(flat.numel() + 16, dtype=torch.uint8, device=dev)
+        src[so:so + flat.numel()] = flat
+        dst = torch.zeros(n * oh * ow * 3 + 16, dtype=torch.uint8, device=dev)
+        _lib.check(lib.ap_cv2_resize_u8(src.data_ptr() + so, n, 2 * oh, 2 * ow, dst.data_ptr() + do, oh, ow, 3, 0, stream), "resize")
+        torch.cuda.synchronize()
+        got = dst[do:do + n * oh * ow * 3].cpu().numpy().reshape(n, oh, ow, 3)
+        assert np.array_equal(got, want), (so, do)
+    from atlaspatch_amd.utils.resample import cv2_resize_device
+    shapes = [(17 + i, 23 + (i * 7) % 31, 9 + i % 13, 11 + (i * 3) % 17) for i in range(80)]
+    for (h, w, oh2, ow2) in shapes + shapes[:1]:
+        img = rng.integers(0, 256, (1, h, w, 3), dtype=np.uint8)
+        got = cv2_resize_device(torch.from_numpy(img).to(dev), (ow2, oh2), 3).cpu().numpy()[0]
+        assert np.array_equal(got, R.resize(img[0], (ow2, oh2), 3)), (h, w, oh2, ow2)

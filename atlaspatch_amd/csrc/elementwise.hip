@@ -5,6 +5,7 @@
 // Algorithmic bytes per row: LayerNorm reads 4*dim and writes sizeof(T)*dim; with the fused residual
 // add it also reads sizeof(T)*dim (delta) and writes 4*dim (the updated stream).
 #include "ap_common.h"
+#include <type_traits>
 
 namespace ap {
 namespace {
@@ -401,6 +402,54 @@ __global__ __launch_bounds__(256) void fold_ls_kernel(const float* __restrict__ 
     if (threadIdx.x == 0) bias_out[n] = bias_in[n] * sc;
 }
 
+// Narrow rows in float32 (the SAM2 Hiera-T trunk: dims 96 / 192 / 384, neck / decoder 256; no pending branch to add): LPR
+// lanes per row, NV float4 per lane (dim = LPR * NV * 4), 64 / LPR rows per wave -- every lane works and a wave's loads cover
+// whole rows (the one-wave-per-row kernel below leaves 40 of 64 lanes idle at dim 96).  Two-pass mean / variance on the
+// register-resident row like the other LayerNorm kernels.
+template <int LPR, int NV>
+__global__ __launch_bounds__(256) void layernorm_narrow_kernel(const float* __restrict__ x, long stride, int rows,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               float eps, float* __restrict__ out) {
+    constexpr int kDim = LPR * NV * 4, kRowsPerWave = 64 / LPR;
+    const int lane = threadIdx.x & 63, l = lane % LPR;
+    const long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * kRowsPerWave + lane / LPR;
+    const bool live = row < rows;
+    const long r = live ? row : rows - 1;                       // idle lanes re-read the last row: the shuffles need every lane
+    const f32x4* src = (const f32x4*)(x + r * stride);
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = src[l + i * LPR];
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+#pragma unroll
+    for (int m = 1; m < LPR; m <<= 1) s += __shfl_xor(s, m, 64);
+    const float mean = s / (float)kDim;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = v[i][e] - mean;
+            q += d * d;
+        }
+#pragma unroll
+    for (int m = 1; m < LPR; m <<= 1) q += __shfl_xor(q, m, 64);
+    const float rstd = 1.0f / sqrtf(q / (float)kDim + eps);
+    if (!live) return;
+    f32x4* dst = (f32x4*)(out + row * kDim);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const f32x4 ga = ((const f32x4*)gamma)[l + i * LPR];
+        const f32x4 be = ((const f32x4*)beta)[l + i * LPR];
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * ga[e] + be[e];
+        dst[l + i * LPR] = y;
+    }
+}
+
 template <typename TD, typename TO>
 int launch_ln_typed(float* x, long stride, const LnAdds& add, int rows, int dim,
                     const float* gamma, const float* beta, float eps, void* out, hipStream_t stream) {
@@ -416,6 +465,24 @@ int launch_ln_typed(float* x, long stride, const LnAdds& add, int rows, int dim,
         if (dim == 768) layernorm16_kernel<TD, TO, 12, true><<<g16, b16, lds, stream>>>(x, stride, add, rows, dim, gamma, beta, eps, o, groups);
         else layernorm16_kernel<TD, TO, 16, true><<<g16, b16, lds, stream>>>(x, stride, add, rows, dim, gamma, beta, eps, o, groups);
     } else {
+        if constexpr (std::is_same<TD, float>::value && std::is_same<TO, float>::value) {
+            if (!add.d[0] && !add.d[1]) {
+#define AP_LN_NARROW(DIM, LPR, NV)                                                                                       \
+                if (dim == DIM) {                                                                                        \
+                    const int per_wg = 4 * (64 / LPR);                                                                   \
+                    layernorm_narrow_kernel<LPR, NV><<<(rows + per_wg - 1) / per_wg, 256, 0, stream>>>(                  \
+                        x, stride, rows, gamma, beta, eps, (float*)out);                                                 \
+                    AP_HIP_CHECK(hipGetLastError());                                                                     \
+                    return AP_OK;                                                                                        \
+                }
+                AP_LN_NARROW(96, 8, 3)
+                AP_LN_NARROW(192, 16, 3)
+                AP_LN_NARROW(384, 32, 3)
+                AP_LN_NARROW(256, 16, 4)
+                AP_LN_NARROW(128, 8, 4)
+#undef AP_LN_NARROW
+            }
+        }
         dim3 grid((rows + 3) / 4), block(256);
         layernorm_kernel<TD, TO><<<grid, block, 0, stream>>>(x, stride, add, rows, dim, gamma, beta, eps, o);
     }

@@ -157,7 +157,7 @@ class ProcessingRunner:
                 logger.error("Extraction failed for %s: %s", slide.path.name, exc)
             tick()
 
-        for group in _batches(slides, max(1, self.config.segmentation.batch_size)):
+        def open_group(group):
             opened = []
             for slide in group:
                 if self._handled_as_existing(slide, results, tick):
@@ -175,21 +175,17 @@ class ProcessingRunner:
                     logger.error("Failed to open %s: %s", slide.path.name, exc)
                     self._release_lock(fd, lock_path)
                     tick()
-            if not opened:
-                continue
-            try:
-                wsis = [w for _, w, _, _ in opened]
-                with stage("segmentation"):
-                    masks = (self.segmentation.segment_batch(wsis) if len(wsis) > 1
-                             else [self.segmentation.segment_thumbnail(wsis[0])])
-            except Exception as exc:  # noqa: BLE001
-                for slide, wsi, fd, lock_path in opened:
-                    failures.append((slide, exc))
-                    logger.error("Segmentation failed for %s: %s", slide.path.name, exc)
-                    self._close(wsi)
-                    self._release_lock(fd, lock_path)
-                    tick()
-                continue
+            return opened
+
+        def segmentation_failed(opened, exc):
+            for slide, wsi, fd, lock_path in opened:
+                failures.append((slide, exc))
+                logger.error("Segmentation failed for %s: %s", slide.path.name, exc)
+                self._close(wsi)
+                self._release_lock(fd, lock_path)
+                tick()
+
+        def submit(opened, masks):
             # coordinates + H5 of a segmented slide run on a worker pool (the reference's PatchExtractionExecutor:
             # orchestration/parallel.py:105-160, `--patch-workers` threads, at most `--max-open-slides` slides open) while
             # this thread goes on to segment the next group; results keep the submission order
@@ -197,6 +193,52 @@ class ProcessingRunner:
                 while len(inflight) >= open_cap:
                     drain(inflight.pop(0))
                 inflight.append((slide, pool.submit(self._extract_one, slide, wsi, fd, lock_path, mask)))
+
+        groups = _batches(slides, max(1, self.config.segmentation.batch_size))
+        seg = self.segmentation
+        if os.environ.get("ATLASPATCH_SEG_PIPELINE", "1") != "0" and hasattr(seg, "prepare_input") and hasattr(seg, "segment_prepared"):
+            # Pipelined: a helper thread prepares group k + 1's network inputs (level read, cv2 / Pillow resizes) while
+            # this thread runs group k's forwards.  Same calls on the same inputs in the same order per slide: same masks.
+            prep = futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="seg-input")
+
+            def prepare(opened):
+                if self._device_index is not None:
+                    torch.cuda.set_device(self._device_index)
+                return [seg.prepare_input(w) for _, w, _, _ in opened]
+
+            def finish(item):
+                opened, fut = item
+                try:
+                    with stage("segmentation"):
+                        masks = [seg.segment_prepared(t) for t in fut.result()]
+                except Exception as exc:  # noqa: BLE001
+                    segmentation_failed(opened, exc)
+                    return
+                submit(opened, masks)
+
+            pending = None
+            for group in groups:
+                opened = open_group(group)
+                nxt = (opened, prep.submit(prepare, opened)) if opened else None
+                if pending is not None:
+                    finish(pending)
+                pending = nxt
+            if pending is not None:
+                finish(pending)
+            prep.shutdown(wait=True)
+        else:
+            for group in groups:
+                opened = open_group(group)
+                if not opened:
+                    continue
+                try:
+                    wsis = [w for _, w, _, _ in opened]
+                    with stage("segmentation"):
+                        masks = (seg.segment_batch(wsis) if len(wsis) > 1 else [seg.segment_thumbnail(wsis[0])])
+                except Exception as exc:  # noqa: BLE001
+                    segmentation_failed(opened, exc)
+                    continue
+                submit(opened, masks)
         for item in inflight:
             drain(item)
         pool.shutdown(wait=True)

@@ -131,10 +131,16 @@ class SAM2SegmentationService(SegmentationService):
         return self._predictor
 
     def segment_thumbnail(self, wsi: IWSI) -> Mask:
-        predictor = self.predictor
-        thumb = prepare_thumbnail_device(wsi, self.cfg, predictor.device)
+        return self.segment_prepared(self.prepare_input(wsi))
+
+    # The two halves of segment_thumbnail, so that a caller can prepare slide k + 1's input (level read, cv2 / Pillow
+    # resizes: host work + short device kernels) on another thread while slide k's forward runs (orchestration/runner.py).
+    def prepare_input(self, wsi: IWSI):
+        return prepare_thumbnail_device(wsi, self.cfg, self.predictor.device)
+
+    def segment_prepared(self, thumb) -> Mask:
         with stage("sam2_predict"):
-            data = predictor.predict_device(thumb, resize_to_input=True)
+            data = self.predictor.predict_device(thumb, resize_to_input=True)
         return Mask(data=data, source_shape=(int(data.shape[0]), int(data.shape[1])))
 
     def segment_batch(self, wsis: Sequence[IWSI]) -> list[Mask]:

@@ -217,7 +217,9 @@ def test_gemm_repeatable(env):
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.6e-2), (torch.float32, 2e-5)])
-@pytest.mark.parametrize("rows,dim", [(1, 768), (37, 768), (1000, 1024), (50, 512)])
+@pytest.mark.parametrize("rows,dim", [(1, 768), (37, 768), (1000, 1024), (50, 512),
+                                      # the float32 narrow-row kernel (SAM2 dims): rows off every rows-per-wave multiple
+                                      (1, 96), (65537, 96), (4099, 192), (4097, 384), (9, 256), (33, 128)])
 def test_layernorm_vs_torch(env, dt, tol, rows, dim):
     _lib, lib, dev, stream = env
     g = torch.Generator(device=dev).manual_seed(rows + dim)

@@ -588,6 +588,31 @@ def test_coords_and_contours_random_masks_vs_oracle(seed):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_coords_row_bucketed_scan_equals_the_full_scan(seed, monkeypatch):
+    """The grid kernel visits, per grid row, only the polygon edges whose y-range meets the row's probe band (the host
+    buckets them).  Against the full scan of every vertex (AP_GRID_FLAGS_LEGACY=1: the kernel of rounds 1-2) on random
+    masks with geometry chosen so that probes fall ON vertices and ON horizontal / vertical edges (integer scale factors,
+    steps that divide them): identical rows, and identical to the oracle."""
+    from atlaspatch_amd.services.extraction import coords_from_mask
+    from oracle import coords_oracle
+    rng = np.random.default_rng(4200 + seed)
+    h, w = int(rng.integers(30, 120)), int(rng.integers(30, 120))
+    mask = _random_mask(rng, seed % 5, h, w)
+    scale = int(rng.choice([32, 64, 128]))                       # level-0 size = mask size x an integer: contours on a lattice
+    ps = int(rng.choice([64, 128, 256]))                         # patch / step commensurate with it: probes hit the lattice
+    kw = dict(level0_wh=(w * scale, h * scale), downsamples=[1.0, 4.0, 16.0], src_mag=20, tgt_mag=20, patch_size=ps,
+              step_size=None if seed % 2 else ps // 2, tissue_thresh=0.0)
+    got, _ = coords_from_mask(mask, **kw)
+    monkeypatch.setenv("AP_GRID_FLAGS_LEGACY", "1")
+    legacy, _ = coords_from_mask(mask, **kw)
+    monkeypatch.delenv("AP_GRID_FLAGS_LEGACY")
+    want, _ = coords_oracle.coords_from_mask(mask, **kw)
+    assert got.shape == legacy.shape == want.shape and got.shape[0] > 0
+    assert np.array_equal(got, legacy)
+    assert np.array_equal(got, want)
+
+
 def test_synth_tiles_bit_exact():
     import ctypes as C
     from atlaspatch_amd import _lib

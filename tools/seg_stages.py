@@ -8,13 +8,17 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 side = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
 segb = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 os.environ["ATLASPATCH_SEGMENTER"] = "sam2"
-os.environ.setdefault("ATLASPATCH_RANDOM_INIT", "0")
 import torch
+if os.environ.get('AP_SWITCH'): sys.setswitchinterval(float(os.environ['AP_SWITCH']))
 from click.testing import CliRunner
 from atlaspatch_amd.cli import cli
 from atlaspatch_amd.utils import stages
 torch.zeros(1, device="cuda")
 with tempfile.TemporaryDirectory() as tmp:
+    # the SAM2 weights come from a checkpoint file, as in bench.py (generating 38 M random parameters on the host takes ~1.7 s)
+    from atlaspatch_amd.services.segmentation import random_sam2_state_dict
+    torch.save({"model": random_sam2_state_dict(0)}, os.path.join(tmp, "sam2.pt"))
+    os.environ["ATLASPATCH_WEIGHTS_DIR"] = tmp
     os.makedirs(os.path.join(tmp, "slides"))
     for i in range(n):
         json.dump({"width": side, "height": side, "seed": 100 + i, "mag": 20, "mpp": 0.5, "downsamples": [1, 4, 16]},

@@ -117,7 +117,8 @@ struct Entry {
     ~Entry() { if (t.i32) (void)hipFree(t.i32); if (t.f32) (void)hipFree(t.f32); }
 };
 std::mutex g_mu;
-std::map<Key, std::shared_ptr<Entry>> g_tables;
+// never destroyed: at process exit the HIP runtime may be gone before static destructors run, and ~Entry calls hipFree
+std::map<Key, std::shared_ptr<Entry>>& g_tables = *new std::map<Key, std::shared_ptr<Entry>>();
 uint64_t g_use_clock = 0;
 
 int upload(const std::vector<int32_t>& ints, const std::vector<float>& flts, Tables& t) {

@@ -58,7 +58,9 @@
 // Round 3 timed three such experiments on the four ViT-B shapes (2048 images), all inside +-1 % of the product kernel
 // and none kept: the tile's first K-tile writing the accumulators with C = 0 instead of a zeroed register block; the
 // last K-tile's phase-2 / 3 stagings issued behind the drain that opens the epilogue; the two LDS-DMA loads of a phase
-// issued two MFMA pairs apart.
+// issued two MFMA pairs apart.  A fourth replaced the epilogue's LDS transposition by v_permlane32_swap pairs and 16-byte
+// row-per-lane stores (32 rows x 32 bytes per instruction): bit-identical, qkv 5 % slower, fc1 unchanged -- the whole-row
+// stores are worth their LDS round trip.
 #ifdef AP_G256_ALT
 #define AP_G256_FN(name) name##_alt
 #else
@@ -527,55 +529,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
                     }
                 }
             } else {
-#ifdef AP_EXP_T21
-                // experiment: no LDS transposition for the store-type epilogues.  A lane owns row l31 of the 32-row block and,
-                // per 8-column group, 4 of its columns (the partner lane ^ 32 the other 4): one v_permlane32_swap per dword
-                // and pair of groups gives the lower half 16 contiguous bytes of group 2j and the upper half those of
-                // group 2j + 1 -> one 16-byte store per lane (a wave writes 32 rows x 32 bytes per instruction).
-                if constexpr (!kRes) {
-                    const int m = m0 + mb * 32 + l31;
-#pragma unroll
-                    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            u32x2 pr[2];
-#pragma unroll
-                            for (int t = 0; t < 2; ++t) {
-                                const int g4 = 2 * j + t;
-                                f32x4 v;
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] = acc[nb][mb][g4 * 4 + e];
-                                if constexpr (kNorm) {
-                                    const f32x2_t rs2 = {rst[mb][0], rst[mb][0]}, nm2 = {rst[mb][1], rst[mb][1]};
-                                    const f32x2_t lo = __builtin_elementwise_fma(rs2, f32x2_t{v[0], v[1]},
-                                        __builtin_elementwise_fma(nm2, f32x2_t{ncs[nb][g4][0], ncs[nb][g4][1]}, f32x2_t{nbias[nb][g4][0], nbias[nb][g4][1]}));
-                                    const f32x2_t hi2 = __builtin_elementwise_fma(rs2, f32x2_t{v[2], v[3]},
-                                        __builtin_elementwise_fma(nm2, f32x2_t{ncs[nb][g4][2], ncs[nb][g4][3]}, f32x2_t{nbias[nb][g4][2], nbias[nb][g4][3]}));
-                                    v = f32x4{lo[0], lo[1], hi2[0], hi2[1]};
-                                }
-                                if constexpr (EPI == EPI_BIAS_GELU || EPI == EPI_NORM_GELU) {
-                                    const f32x2_t lo = gelu_sigmoid_poly2(f32x2_t{v[0], v[1]}), hi2 = gelu_sigmoid_poly2(f32x2_t{v[2], v[3]});
-                                    v = f32x4{lo[0], lo[1], hi2[0], hi2[1]};
-                                }
-                                if (has_gamma) {
-                                    const f32x4 ga = *(const f32x4*)(gp + nb * 32 + g4 * 8);
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) v[e] *= ga[e];
-                                }
-                                pr[t] = pack4<T>(v);
-                            }
-                            u32x4 o;
-#pragma unroll
-                            for (int d = 0; d < 2; ++d) {
-                                const auto r = __builtin_amdgcn_permlane32_swap(pr[0][d], pr[1][d], false, false);
-                                o[d] = r[0];
-                                o[2 + d] = r[1];
-                            }
-                            if (m < g.M) *(u32x4*)((T*)g.out + (size_t)m * g.ldo + n0 + nb * 32 + (2 * j + hi) * 8) = o;
-                        }
-                    continue;
-                }
-#endif
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb)
 #pragma unroll

@@ -63,6 +63,7 @@ SIGNATURES = {
     "ap_vit_create": (C.c_int, [C.POINTER(VitConfig), C.POINTER(C.c_void_p)]),
     "ap_vit_destroy": (None, [C.c_void_p]),
     "ap_vit_set_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),
+    "ap_vit_set_params": (C.c_int, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int]),
     "ap_vit_finalize": (C.c_int, [C.c_void_p]),
     "ap_vit_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ap_vit_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),

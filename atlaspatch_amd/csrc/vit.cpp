@@ -64,6 +64,7 @@ struct ap_vit {
     std::vector<void*> fused_allocs;
     void* pos16 = nullptr;                  // position embedding in the compute type (fused patch embedding), in fused_allocs
     bool fold_dirty = false;                // a parameter the folded weights depend on was set after the last finalize
+    std::vector<float*> pending_free;       // ap_vit_set_params: f32 uploads to release once its stream has drained
     int device = 0;
     // optional per-launch HIP-event timing (ap_vit_profile_*): kind -> events of the last forwards
     bool profile = false;
@@ -603,6 +604,82 @@ int ap_vit_set_param(ap_vit* m, const char* name, const float* host, size_t coun
         m->finalized = false;
     }
     return AP_OK;
+}
+
+// Every parameter of a checkpoint in ONE call: the per-tensor work then runs outside the interpreter lock of a Python
+// caller (the encoder is built on a side thread while the CLI's phase 1 runs, services/feature_embedding.py), and it is
+// pipelined instead of synchronous per tensor: the host pages (typically an mmap of the checkpoint file) are copied into one
+// of two pinned staging buffers by this thread while the previous buffer's H2D copy and f32 -> T conversion run on a private
+// stream; one synchronisation at the end.  Same result as n ap_vit_set_param calls in order.
+int ap_vit_set_params(ap_vit* m, const char* const* names, const float* const* hosts, const size_t* counts, int n) {
+    AP_REQUIRE(m && (n == 0 || (names && hosts && counts)), "vit_set_params: null argument");
+    size_t largest = 0;
+    for (int i = 0; i < n; ++i) {
+        AP_REQUIRE(names[i] && hosts[i], "vit_set_params: null entry %d", i);
+        auto it = m->params.find(names[i]);
+        AP_REQUIRE(it != m->params.end(), "vit_set_param: unknown parameter '%s'", names[i]);
+        AP_REQUIRE(counts[i] == it->second.count, "vit_set_param: '%s' expects %zu values, got %zu", names[i], it->second.count,
+                   counts[i]);
+        largest = counts[i] > largest ? counts[i] : largest;
+    }
+    if (n == 0) return AP_OK;
+    struct Stage { float* pin = nullptr; hipEvent_t done = nullptr; bool busy = false; } st[2];
+    hipStream_t stream = nullptr;
+    int rc = AP_OK;
+    auto fail = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && rc == AP_OK) { ap::set_error("vit_set_params: %s failed: %s", what, hipGetErrorString(e)); rc = AP_ERR_HIP; }
+        return e != hipSuccess;
+    };
+    if (fail(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate")) return rc;
+    for (auto& b : st)
+        if (fail(hipHostMalloc((void**)&b.pin, largest * sizeof(float), hipHostMallocDefault), "hipHostMalloc") ||
+            fail(hipEventCreateWithFlags(&b.done, hipEventDisableTiming), "hipEventCreate"))
+            break;
+    for (int i = 0; i < n && rc == AP_OK; ++i) {
+        Param& p = m->params.find(names[i])->second;
+        Stage& b = st[i & 1];
+        if (b.busy && fail(hipEventSynchronize(b.done), "hipEventSynchronize")) break;
+        memcpy(b.pin, hosts[i], counts[i] * sizeof(float));
+        if (!p.matrix) {
+            if (fail(hipMemcpyAsync(p.dev, b.pin, counts[i] * sizeof(float), hipMemcpyHostToDevice, stream), "hipMemcpyAsync")) break;
+        } else {
+            float* tmp = nullptr;
+            const size_t padded = (size_t)p.rows * p.ld;
+            if (fail(hipMalloc((void**)&tmp, padded * sizeof(float)), "hipMalloc")) break;
+            if (p.ld != p.cols && fail(hipMemsetAsync(tmp, 0, padded * sizeof(float), stream), "hipMemsetAsync")) { (void)hipFree(tmp); break; }
+            if (fail(hipMemcpy2DAsync(tmp, (size_t)p.ld * sizeof(float), b.pin, (size_t)p.cols * sizeof(float),
+                                      (size_t)p.cols * sizeof(float), p.rows, hipMemcpyHostToDevice, stream), "hipMemcpy2DAsync")) {
+                (void)hipFree(tmp); break;
+            }
+            const int crc = ap::launch_convert(m->cfg.compute_dtype, tmp, p.dev, padded, stream);
+            if (crc != AP_OK) { rc = crc; (void)hipFree(tmp); break; }
+            if (p.dev32) { (void)hipFree(p.dev32); p.dev32 = nullptr; }     // (hipFree waits for the device: a re-upload is rare)
+            const bool is_block = strncmp(names[i], "blocks.", 7) == 0;
+            if (m->cfg.compute_dtype != AP_F32 && is_block) p.dev32 = tmp;   // kept until ap_vit_finalize has folded it
+            else {
+                // freed once the stream is done with it: collect and release after the final synchronisation
+                p.dev32 = nullptr;
+                m->pending_free.push_back(tmp);
+            }
+        }
+        if (fail(hipEventRecord(b.done, stream), "hipEventRecord")) break;
+        b.busy = true;
+        p.set = true;
+        if (m->finalized && m->cfg.compute_dtype != AP_F32 &&
+            (strncmp(names[i], "blocks.", 7) == 0 || strcmp(names[i], "pos_embed") == 0)) {
+            m->fold_dirty = true;
+            m->finalized = false;
+        }
+    }
+    if (stream) fail(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    for (float* t : m->pending_free) (void)hipFree(t);
+    m->pending_free.clear();
+    for (auto& b : st) {
+        if (b.pin) (void)hipHostFree(b.pin);
+        if (b.done) (void)hipEventDestroy(b.done);
+    }
+    if (stream) (void)hipStreamDestroy(stream);
+    return rc;
 }
 
 int ap_vit_finalize(ap_vit* m) {

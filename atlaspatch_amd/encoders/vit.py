@@ -238,10 +238,15 @@ class HipViT:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.ap_vit_create(C.byref(cfg), C.byref(handle)), "ap_vit_create")
             self._handle = handle
-            for name, tensor in state.items():
-                arr = np.ascontiguousarray(tensor.detach().to(torch.float32).cpu().numpy())
-                _lib.check(self.lib.ap_vit_set_param(self._handle, name.encode(), arr.ctypes.data_as(C.c_void_p),
-                                                     arr.size), f"ap_vit_set_param({name})")
+            # one native call for the whole checkpoint: the uploads run outside the interpreter lock (the encoder is built
+            # on a side thread while the CLI's phase 1 runs)
+            arrs = [np.ascontiguousarray(t.detach().to(torch.float32).cpu().numpy()) for t in state.values()]
+            n = len(arrs)
+            names = (C.c_char_p * n)(*[k.encode() for k in state])
+            ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+            counts = (C.c_size_t * n)(*[a.size for a in arrs])
+            _lib.check(self.lib.ap_vit_set_params(self._handle, names, ptrs, counts, n), "ap_vit_set_params")
+            del arrs
             _lib.check(self.lib.ap_vit_finalize(self._handle), "ap_vit_finalize")
         self._workspace: Optional[torch.Tensor] = None
 

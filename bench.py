@@ -456,6 +456,20 @@ def secondary_rates(device, ex, tiles, B):
             n = tiles_in(out_dir)
             rates[key] = {"patches_per_s": round(n / dt, 1), "tiles": n, "seconds": round(dt, 3), "stage_seconds": st,
                           "what": what.format(src)}
+        # ---- BASELINE config 3 end to end: the 100 000^2 slide, UNI (ViT-L/16 + LayerScale, 256 -> 224 bicubic on the device),
+        #      tiles rendered by host threads through the async tile ring
+        save_file(random_canonical_state_dict(ARCHS["uni_v1"], 0), os.path.join(tmp, "uni_v1.safetensors"))
+        feat_uni = ("--feature-extractors", "uni_v1", "--feature-precision", "float16",
+                    "--feature-num-workers", str(min(64, os.cpu_count() or 8)))
+        out_dir, dt, st = run_cli("process", slide100, "out_uni", {"ATLASPATCH_HOST_TILES": "1"}, feat_uni)
+        with h5.File(os.path.join(out_dir, "patches", sorted(os.listdir(os.path.join(out_dir, "patches")))[0]), "r") as f:
+            n = int(f["coords"].shape[0])
+            assert f["features"]["uni_v1"].shape == (n, 1024)
+        rates["e2e_cli_100k_uni_v1_host_ring"] = {
+            "patches_per_s": round(n / dt, 1), "tiles": n, "seconds": round(dt, 3), "stage_seconds": st,
+            "what": "BASELINE config 3: `process` on the 100000x100000 slide with uni_v1 (f16), tiles rendered on host threads -> "
+                    "pinned ring -> H2D -> device Resize(224, bicubic) + K1 + ViT-L/16 -> H5"}
+        os.remove(os.path.join(tmp, "uni_v1.safetensors"))
         for i in range(8):
             synth(f"eight/s{i}.synth", 100000, seed=300 + i)
         out_dir, dt, st = run_cli("process", os.path.join(tmp, "eight"), "out_eight", {}, feat)

@@ -208,6 +208,8 @@ void ap_vit_destroy(ap_vit* m);
  *   attn_pool.out.weight [P, P] | .bias [P]   attn_pool.ln_out.weight|bias [P]
  * Synchronous (copies before returning). */
 int ap_vit_set_param(ap_vit* m, const char* name, const float* host, size_t count);
+/* n parameters in one call (same semantics as n ap_vit_set_param calls, in order; stops at the first error) */
+int ap_vit_set_params(ap_vit* m, const char* const* names, const float* const* host, const size_t* counts, int n);
 /* Checks every parameter was set and, for f16 / bf16, builds the derived weights of the fused-LayerNorm dataflow from the
  * float32 uploads (LayerNorm gain / LayerScale folded into the block matrices, column sums, folded biases, a T copy of
  * pos_embed); the float32 copies are released afterwards.  Setting a blocks.* parameter or pos_embed later un-finalises the

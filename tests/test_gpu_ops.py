@@ -563,3 +563,44 @@ def test_cv2_resize_takes_unaligned_pointers_and_a_bounded_table_cache(env):
         img = rng.integers(0, 256, (1, h, w, 3), dtype=np.uint8)
         got = cv2_resize_device(torch.from_numpy(img).to(dev), (ow2, oh2), 3).cpu().numpy()[0]
         assert np.array_equal(got, R.resize(img[0], (ow2, oh2), 3)), (h, w, oh2, ow2)
+
+
+def test_vit_set_params_equals_per_tensor_uploads_and_rejects_bad_entries(env):
+    """``ap_vit_set_params`` (a whole checkpoint in one native call, pipelined through pinned staging) gives the same
+    encoder as one ``ap_vit_set_param`` per tensor -- bit-identical features -- and fails loudly, with the parameter's name,
+    on an unknown name or a wrong element count."""
+    import ctypes as C
+    from atlaspatch_amd.encoders.vit import ARCHS, HipViT, random_canonical_state_dict
+    _lib, lib, dev, stream = env
+    arch = dict(ARCHS["vit_b_16"], depth=2)
+    state = random_canonical_state_dict(arch, 3)
+    tiles = torch.from_numpy(np.random.default_rng(0).integers(0, 256, (5, 256, 256, 3), dtype=np.uint8)).to(dev)
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    batched = HipViT(arch, state, device=dev, dtype=torch.float16)           # uses ap_vit_set_params
+    a = torch.empty((5, 768), dtype=torch.float32, device=dev)
+    batched.forward_u8(tiles, mean, std, a)
+    single = HipViT.__new__(HipViT)                                          # the same object built tensor by tensor
+    single.lib, single.device, single.dtype, single.arch, single.embed_dim, single._workspace = lib, dev, torch.float16, arch, 768, None
+    cfg = _lib.VitConfig(arch["image_size"], arch["patch_size"], arch["dim"], arch["depth"], arch["heads"], arch["mlp_dim"],
+                         float(arch["ln_eps"]), 0, _lib.AP_F16, 0, 0, 0, 1e-5)
+    h = C.c_void_p()
+    _lib.check(lib.ap_vit_create(C.byref(cfg), C.byref(h)), "create")
+    single._handle = h
+    for name, t in state.items():
+        arr = np.ascontiguousarray(t.float().numpy())
+        _lib.check(lib.ap_vit_set_param(h, name.encode(), arr.ctypes.data_as(C.c_void_p), arr.size), name)
+    _lib.check(lib.ap_vit_finalize(h), "finalize")
+    b = torch.empty((5, 768), dtype=torch.float32, device=dev)
+    single.forward_u8(tiles, mean, std, b)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    # error paths of the batched call
+    arr = np.zeros(7, np.float32)
+    names = (C.c_char_p * 1)(b"no.such.parameter")
+    ptrs = (C.c_void_p * 1)(arr.ctypes.data)
+    counts = (C.c_size_t * 1)(7)
+    assert lib.ap_vit_set_params(h, names, ptrs, counts, 1) != 0 and b"no.such.parameter" in lib.ap_last_error()
+    first = next(iter(state))
+    names = (C.c_char_p * 1)(first.encode())
+    assert lib.ap_vit_set_params(h, names, ptrs, counts, 1) != 0 and first.encode() in lib.ap_last_error()
+    batched.release(); single.release()

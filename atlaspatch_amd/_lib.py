@@ -87,6 +87,8 @@ SIGNATURES = {
     "ap_sgemm": (C.c_int, [C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_int, C.c_int,
                            C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.c_long,
                            C.c_void_p, C.c_long, C.c_long, C.c_void_p]),
+    "ap_sgemm_stacked": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                   C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p]),
     "ap_softmax_rows": (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]),
     "ap_sattention_f32": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_long, C.c_void_p]),

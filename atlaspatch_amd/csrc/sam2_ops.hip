@@ -440,10 +440,15 @@ inline dim3 grid1(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
 extern "C" {
 
-int ap_sgemm(const float* A, long lda, long strideA, const float* W, long ldw, long strideW, int w_is_kn,
-             int batch, int M, int N, int K, float alpha, const float* bias, int act,
-             const float* resid, long ldr, long strideR, float* out, long ldo, long strideO, ap_stream_t stream) {
+// stack > 1: the M rows are `stack` equally shaped problems stacked along M (a batch of images through a row-wise layer).
+// The split-K plan is then the single problem's, so every output row goes through exactly the arithmetic it would go
+// through alone (results independent of the batch size); only the tile size follows the whole problem.
+static int sgemm_impl(const float* A, long lda, long strideA, const float* W, long ldw, long strideW, int w_is_kn,
+                      int batch, int M, int N, int K, float alpha, const float* bias, int act,
+                      const float* resid, long ldr, long strideR, float* out, long ldo, long strideO, int stack,
+                      ap_stream_t stream) {
     AP_REQUIRE(A && W && out, "ap_sgemm: null pointer");
+    AP_REQUIRE(stack >= 1 && M % stack == 0, "ap_sgemm: %d rows are not %d stacked problems", M, stack);
     AP_REQUIRE(batch > 0 && M > 0 && N > 0 && K > 0 && batch <= 65535, "ap_sgemm: bad problem %d x %d x %d x %d", batch, M, N, K);
     AP_REQUIRE(act >= 0 && act <= 2, "ap_sgemm: activation %d", act);
     ap::SgemmArgs g{A, lda, strideA, W, ldw, strideW, w_is_kn, M, N, K, alpha, bias, act, resid, ldr, strideR, out, ldo, strideO,
@@ -453,16 +458,21 @@ int ap_sgemm(const float* A, long lda, long strideA, const float* W, long ldw, l
     // tile (M x N): 128 x 128 when that still gives every CU two workgroups, else 64 x 64.  (A 128 x 64 tile was measured
     // too: M = 4096, N = 1536, K = 384 went from 62.9 to 74.6 us -- two workgroups per CU instead of four cost more than
     // the 25 % fewer operand bytes returned.)
-    auto wgs = [&](int tm, int tn) { return (long)((M + tm - 1) / tm) * ((N + tn - 1) / tn) * batch; };
-    int TM = 64, TN = 64;
-    if (M > 64 && N > 64 && wgs(128, 128) >= 512) { TM = 128; TN = 128; }
+    auto wgs_m = [&](int m, int tm, int tn) { return (long)((m + tm - 1) / tm) * ((N + tn - 1) / tn) * batch; };
+    auto wgs = [&](int tm, int tn) { return wgs_m(M, tm, tn); };
     // split-K: few output tiles over a long K (P V of the global / token-to-image attention, the late MLPs) would leave
-    // most CUs idle behind serial K loops -> K chunks of >= 128 on separate workgroups, partial sums reduced in order
+    // most CUs idle behind serial K loops -> K chunks of >= 128 on separate workgroups, partial sums reduced in order.
+    // Planned on ONE of the stacked problems (its own tile size included), see above.
+    const int M1 = M / stack;
+    int TM1 = 64;
+    if (M1 > 64 && N > 64 && wgs_m(M1, 128, 128) >= 512) TM1 = 128;
     int splits = 1;
-    if (wgs(TM, TN) < 256 && K >= 512) {
-        splits = (int)std::min<long>(std::min<long>((256 + wgs(TM, TN) - 1) / wgs(TM, TN), K / 128), 32);
+    if (wgs_m(M1, TM1, TM1) < 256 && K >= 512) {
+        splits = (int)std::min<long>(std::min<long>((256 + wgs_m(M1, TM1, TM1) - 1) / wgs_m(M1, TM1, TM1), K / 128), 32);
         if (splits < 2) splits = 1;
     }
+    int TM = 64, TN = 64;
+    if (M > 64 && N > 64 && wgs(128, 128) >= 512) { TM = 128; TN = 128; }
     hipStream_t s = (hipStream_t)stream;
     if (splits > 1) {
         g.k_chunk = (int)ap::align_up((size_t)(K + splits - 1) / splits, 32);
@@ -503,6 +513,18 @@ int ap_sgemm(const float* A, long lda, long strideA, const float* W, long ldw, l
         ap::splitk_reduce_kernel<<<ap::grid1((size_t)batch * M * N), 256, 0, s>>>(g, batch);
     AP_HIP_CHECK(hipGetLastError());
     return AP_OK;
+}
+
+int ap_sgemm(const float* A, long lda, long strideA, const float* W, long ldw, long strideW, int w_is_kn,
+             int batch, int M, int N, int K, float alpha, const float* bias, int act,
+             const float* resid, long ldr, long strideR, float* out, long ldo, long strideO, ap_stream_t stream) {
+    return sgemm_impl(A, lda, strideA, W, ldw, strideW, w_is_kn, batch, M, N, K, alpha, bias, act, resid, ldr, strideR, out, ldo,
+                      strideO, 1, stream);
+}
+
+int ap_sgemm_stacked(const float* A, long lda, const float* W, long ldw, int stack, int M, int N, int K, const float* bias, int act,
+                     const float* resid, long ldr, float* out, long ldo, ap_stream_t stream) {
+    return sgemm_impl(A, lda, 0, W, ldw, 0, 0, 1, M, N, K, 1.0f, bias, act, resid, ldr, 0, out, ldo, 0, stack, stream);
 }
 
 int ap_sattention_f32(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv, int batch, int heads, int tq,

@@ -210,7 +210,9 @@ class ProcessingRunner:
                 opened, fut = item
                 try:
                     with stage("segmentation"):
-                        masks = [seg.segment_prepared(t) for t in fut.result()]
+                        thumbs = fut.result()
+                        masks = (seg.segment_prepared_batch(thumbs) if len(thumbs) > 1 and hasattr(seg, "segment_prepared_batch")
+                                 else [seg.segment_prepared(t) for t in thumbs])
                 except Exception as exc:  # noqa: BLE001
                     segmentation_failed(opened, exc)
                     return

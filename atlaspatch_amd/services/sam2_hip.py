@@ -56,6 +56,7 @@ class Sam2HipPredictor:
         self.input_size = 1024
         self.plan, self.stage_ends = block_plan()
         self._graph = None
+        self._batch_graphs: dict = {}
         self.fused_attention = os.environ.get("ATLASPATCH_SAM2_UNFUSED_ATTENTION") in (None, "", "0")
         self._static_img = self._static_mask = None
         self._resamplers: dict = {}
@@ -142,9 +143,19 @@ class Sam2HipPredictor:
         return _lib.current_stream_ptr(self.device)
 
     def _gemm(self, a, w, n, k, *, bias=None, act=0, resid=None, out=None, m=None, lda=None, ldw=None, ldo=None, ldr=None,
-              batch=1, sa=0, sw=0, so=0, sr=0, w_kn=False, alpha=1.0):
+              batch=1, sa=0, sw=0, so=0, sr=0, w_kn=False, alpha=1.0, stack=1):
         m = a.shape[0] if m is None else m
         out = self._buf(m, n) if out is None else out
+        if stack > 1:
+            # `stack` images through one row-wise layer: planned like a single image (ap_sgemm_stacked), so a row's result
+            # does not depend on the batch size
+            assert batch == 1 and not w_kn and alpha == 1.0
+            _lib.check(self.lib.ap_sgemm_stacked(a.data_ptr(), lda if lda is not None else k, w.data_ptr(),
+                                                 ldw if ldw is not None else k, stack, m, n, k,
+                                                 bias.data_ptr() if bias is not None else None, act,
+                                                 resid.data_ptr() if resid is not None else None, ldr if ldr is not None else n,
+                                                 out.data_ptr(), ldo if ldo is not None else n, self._stream()), "ap_sgemm_stacked")
+            return out
         _lib.check(self.lib.ap_sgemm(a.data_ptr(), lda if lda is not None else k, sa, w.data_ptr(),
                                      ldw if ldw is not None else (n if w_kn else k), sw, 1 if w_kn else 0, batch, m, n, k,
                                      C.c_float(alpha), bias.data_ptr() if bias is not None else None, act,
@@ -186,34 +197,44 @@ class Sam2HipPredictor:
         return out
 
     # ------------------------------------------------------------------ network
-    def _trunk(self, image_u8: torch.Tensor):
+    def _trunk(self, images_u8: torch.Tensor):
+        """uint8 [B, 1024, 1024, 3] (or [1024, 1024, 3]) -> per stage (x [B * H * W, C], H, W, C).  Every layer is row-wise,
+        per window or per image, so B images are simply stacked along the rows (GEMMs planned like one image:
+        ``ap_sgemm_stacked``): an image's activations do not depend on what it is batched with."""
         lib, st = self.lib, self._stream()
-        cols = self._buf(256 * 256, 147)
-        _lib.check(lib.ap_sam2_patchify(image_u8.data_ptr(), 1024, 1024, _lib.f3(MEAN), _lib.f3(STD), cols.data_ptr(), st))
-        x = self._gemm(cols, self.w["pe.w"], EMBED, 147, bias=self.w["pe.b"], resid=self.w["pos"])      # [65536, 96]
+        if images_u8.dim() == 3:
+            images_u8 = images_u8[None]
+        B = int(images_u8.shape[0])
+        cols = self._buf(B * 256 * 256, 147)
+        for b in range(B):
+            _lib.check(lib.ap_sam2_patchify(images_u8[b].data_ptr(), 1024, 1024, _lib.f3(MEAN), _lib.f3(STD),
+                                            cols[b * 65536:].data_ptr(), st))
+        # the positional embedding is the same for every image: batch stride 0 on the residual
+        x = self._gemm(cols, self.w["pe.w"], EMBED, 147, bias=self.w["pe.b"], resid=self.w["pos"], m=65536, batch=B,
+                       sa=65536 * 147, so=65536 * EMBED, sr=0, out=self._buf(B * 65536, EMBED))             # [B * 65536, 96]
         H = W = 256
         feats = []
         for i, (din, dout, heads, window, qpool) in enumerate(self.plan):
             g = lambda n: self.w[f"b{i}.{n}"]
-            rows = H * W
+            rows = B * H * W
             xn = self._ln(x, rows, din, g("norm1.weight"), g("norm1.bias"), 1e-6)
             shortcut = x
             if din != dout:
-                shortcut = self._gemm(xn, g("proj.weight"), dout, din, bias=g("proj.bias"))
+                shortcut = self._gemm(xn, g("proj.weight"), dout, din, bias=g("proj.bias"), stack=B)
                 if qpool:
-                    pooled = self._buf((H // 2) * (W // 2), dout)
-                    _lib.check(lib.ap_maxpool2x2(shortcut.data_ptr(), dout, 1, H, W, dout, pooled.data_ptr(), st))
+                    pooled = self._buf(B * (H // 2) * (W // 2), dout)
+                    _lib.check(lib.ap_maxpool2x2(shortcut.data_ptr(), dout, B, H, W, dout, pooled.data_ptr(), st))
                     shortcut = pooled
             if window > 0:
                 nwy, nwx = -(-H // window), -(-W // window)
-                nb, hh, ww = nwy * nwx, window, window
+                nb, hh, ww = B * nwy * nwx, window, window
                 win = self._buf(nb * hh * ww, din)
-                _lib.check(lib.ap_window_partition(xn.data_ptr(), 1, H, W, din, window, win.data_ptr(), st))
+                _lib.check(lib.ap_window_partition(xn.data_ptr(), B, H, W, din, window, win.data_ptr(), st))
                 xn = win
             else:
-                nb, hh, ww = 1, H, W
+                nb, hh, ww = B, H, W
             t_k = hh * ww
-            qkv = self._gemm(xn, g("attn.qkv.weight"), 3 * dout, din, bias=g("attn.qkv.bias"))              # [nb*t_k, 3*dout]
+            qkv = self._gemm(xn, g("attn.qkv.weight"), 3 * dout, din, bias=g("attn.qkv.bias"), stack=B)     # [nb*t_k, 3*dout]
             d = dout // heads
             q, ldq, t_q = qkv, 3 * dout, t_k
             if qpool:
@@ -229,22 +250,35 @@ class Sam2HipPredictor:
             # x = shortcut + attn: the residual add rides on the projection GEMM's epilogue (image-wide blocks) or on the
             # window un-partition pass (windowed blocks)
             if window > 0:
-                a = self._gemm(a, g("attn.proj.weight"), dout, dout, bias=g("attn.proj.bias"))
-                x2 = self._buf(H * W, dout)
-                _lib.check(lib.ap_window_unpartition_add(a.data_ptr(), shortcut.data_ptr(), 1, H, W, dout, window, x2.data_ptr(), st))
+                a = self._gemm(a, g("attn.proj.weight"), dout, dout, bias=g("attn.proj.bias"), stack=B)
+                x2 = self._buf(B * H * W, dout)
+                _lib.check(lib.ap_window_unpartition_add(a.data_ptr(), shortcut.data_ptr(), B, H, W, dout, window, x2.data_ptr(), st))
             else:
-                x2 = self._gemm(a, g("attn.proj.weight"), dout, dout, bias=g("attn.proj.bias"), resid=shortcut)
-            xn2 = self._ln(x2, H * W, dout, g("norm2.weight"), g("norm2.bias"), 1e-6)
-            hid = self._gemm(xn2, g("mlp.layers.0.weight"), 4 * dout, dout, bias=g("mlp.layers.0.bias"), act=1)
-            x = self._gemm(hid, g("mlp.layers.1.weight"), dout, 4 * dout, bias=g("mlp.layers.1.bias"), resid=x2)
+                x2 = self._gemm(a, g("attn.proj.weight"), dout, dout, bias=g("attn.proj.bias"), resid=shortcut, stack=B)
+            xn2 = self._ln(x2, B * H * W, dout, g("norm2.weight"), g("norm2.bias"), 1e-6)
+            hid = self._gemm(xn2, g("mlp.layers.0.weight"), 4 * dout, dout, bias=g("mlp.layers.0.bias"), act=1, stack=B)
+            x = self._gemm(hid, g("mlp.layers.1.weight"), dout, 4 * dout, bias=g("mlp.layers.1.bias"), resid=x2, stack=B)
             if i in self.stage_ends:
                 feats.append((x, H, W, dout))
         return feats
 
+    def image_features_batch(self, images_u8: torch.Tensor):
+        """[B, 1024, 1024, 3] -> [(embed, feat_s0, feat_s1)] per image: the trunk runs on the stacked batch, neck and
+        decoder inputs per image (their shapes are an image's)."""
+        feats = self._trunk(images_u8)
+        B = 1 if images_u8.dim() == 3 else int(images_u8.shape[0])
+        out = []
+        for b in range(B):
+            per = [(x[b * h * w:(b + 1) * h * w], h, w, c) for (x, h, w, c) in feats]
+            out.append(self._neck(per))
+        return out
+
     def image_features(self, image_u8: torch.Tensor):
         """set_image: uint8 [1024, 1024, 3] on the device -> (embed [4096, 256] incl. no_mem + no_mask embeds,
         feat_s0 [65536, 32], feat_s1 [16384, 64])."""
-        feats = self._trunk(image_u8)
+        return self._neck(self._trunk(image_u8))
+
+    def _neck(self, feats):
         lat = [self._gemm(x, self.w[f"neck{3 - i}.w"], 256, c, bias=self.w[f"neck{3 - i}.b"]) for i, (x, h, w, c) in enumerate(feats)]
         # top-down only into level 2 (stride 16) from level 3 (stride 32): FpnNeck fpn_top_down_levels [2, 3], nearest
         lvl2 = self._buf(64 * 64, 256)
@@ -403,8 +437,86 @@ class Sam2HipPredictor:
         self._graph.replay()
         return self._static_mask
 
+    # ------------------------------------------------------------------ batched (``--seg-batch-size`` > 1)
+    def _forward_masks(self, imgs: torch.Tensor) -> torch.Tensor:
+        """uint8 [B, 1024, 1024, 3] -> float {0, 1} masks [B, 1024, 1024]: the trunk on the stacked batch, neck + decoder per
+        image.  Mask b equals ``_forward_mask(imgs[b])`` bit for bit (tests)."""
+        B = int(imgs.shape[0])
+        masks = self._buf(B, 1024, 1024)
+        for b, (embed, s0, s1) in enumerate(self.image_features_batch(imgs)):
+            logits = self.mask_logits(embed, s0, s1)
+            _lib.check(self.lib.ap_bilinear_up4_threshold(logits.data_ptr(), 256, C.c_float(self.mask_threshold),
+                                                          masks[b].data_ptr(), self._stream()), "ap_bilinear_up4_threshold")
+        return masks
+
+    def _graph_masks_device(self, imgs: torch.Tensor) -> torch.Tensor:
+        """One captured graph per batch size (the reference batches ``seg_batch_size`` thumbnails per forward,
+        segmentation.py:142-180); the returned tensor is the graph's static output: consume it before the next call."""
+        import os
+        B = int(imgs.shape[0])
+        if B == 1:
+            return self._graph_mask_device(imgs[0])[None]
+        if os.environ.get("ATLASPATCH_SAM2_GRAPH", "1") == "0":
+            return self._forward_masks(imgs)
+        entry = self._batch_graphs.get(B)
+        if entry is None:
+            static_in = torch.empty((B, self.input_size, self.input_size, 3), dtype=torch.uint8, device=self.device)
+            static_in.copy_(imgs)
+            self._forward_masks(static_in)                       # warm-up outside the capture (scratch growth, lazy init)
+            with _lib.HIP_CAPTURE_LOCK:
+                torch.cuda.synchronize(self.device)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    static_out = self._forward_masks(static_in)
+            entry = self._batch_graphs[B] = (graph, static_in, static_out)
+            while len(self._batch_graphs) > 2:                   # a run uses one batch size plus at most one remainder size
+                self._batch_graphs.pop(next(iter(self._batch_graphs)))
+        graph, static_in, static_out = entry
+        static_in.copy_(imgs)
+        graph.replay()
+        return static_out
+
+    @torch.inference_mode()
+    def predict_batch_device(self, thumbs, *, resize_to_input: bool = True) -> list:
+        """``predict_device`` for several thumbnails (each uint8 [h, w, 3] in HBM, any sizes) in ONE forward: each is resized
+        to 1024 x 1024 as Pillow would, the batch goes through the trunk stacked, each mask returns to its thumbnail's shape.
+        Element i equals ``predict_device(thumbs[i])`` bit for bit."""
+        from ..utils.resample import DeviceResampler, pillow_nearest_index
+        S = self.input_size
+        with torch.cuda.device(self.device):
+            imgs = torch.empty((len(thumbs), S, S, 3), dtype=torch.uint8, device=self.device)
+            shapes = []
+            for b, thumb in enumerate(thumbs):
+                assert thumb.is_cuda and thumb.dtype == torch.uint8 and thumb.dim() == 3 and thumb.shape[2] == 3
+                h, w = int(thumb.shape[0]), int(thumb.shape[1])
+                shapes.append((h, w))
+                if (h, w) == (S, S):
+                    imgs[b].copy_(thumb)
+                    continue
+                rs = self._resamplers.get((h, w))
+                if rs is None:
+                    yi = torch.from_numpy(pillow_nearest_index(S, h)).to(self.device)
+                    xi = torch.from_numpy(pillow_nearest_index(S, w)).to(self.device)
+                    rs = self._resamplers[(h, w)] = (DeviceResampler((h, w), (S, S), "bilinear", self.device), yi, xi)
+                    while len(self._resamplers) > 8 + len(thumbs):
+                        self._resamplers.pop(next(iter(self._resamplers)))
+                imgs[b].copy_(rs[0](thumb.contiguous()[None])[0])
+            masks = self._graph_masks_device(imgs)
+            out = []
+            for b, (h, w) in enumerate(shapes):
+                m = masks[b]
+                if resize_to_input and (h, w) != (S, S):
+                    _, yi, xi = self._resamplers[(h, w)]
+                    g = self._buf(h, w)
+                    _lib.check(self.lib.ap_gather2d_f32(m.data_ptr(), S, S, yi.data_ptr(), xi.data_ptr(), h, w, g.data_ptr(),
+                                                        self._stream()), "ap_gather2d_f32")
+                    m = g
+                out.append(m.cpu().numpy())
+            return out
+
     def close(self) -> None:
         self._graph = None
+        self._batch_graphs = {}
         self._static_img = self._static_mask = None
         self.w = {}
 

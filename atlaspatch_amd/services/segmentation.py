@@ -150,12 +150,14 @@ class SAM2SegmentationService(SegmentationService):
         workers = max(1, min(8, len(wsis), os.cpu_count() or 8))
         with ThreadPoolExecutor(max_workers=workers, thread_name_prefix="thumb") as pool:
             thumbs = list(pool.map(lambda w: prepare_thumbnail_device(w, self.cfg, predictor.device), wsis))
-        out = []
-        for thumb in thumbs:                      # one forward per slide (the reference batches them; same results)
-            with stage("sam2_predict"):
-                data = predictor.predict_device(thumb, resize_to_input=True)
-            out.append(Mask(data=data, source_shape=(int(data.shape[0]), int(data.shape[1]))))
-        return out
+        return self.segment_prepared_batch(thumbs)
+
+    def segment_prepared_batch(self, thumbs) -> list[Mask]:
+        """One forward for the whole batch (segmentation.py:142-180): the trunk runs on the stacked thumbnails; every mask
+        equals the single-slide forward's bit for bit."""
+        with stage("sam2_predict"):
+            datas = self.predictor.predict_batch_device(list(thumbs), resize_to_input=True)
+        return [Mask(data=d, source_shape=(int(d.shape[0]), int(d.shape[1]))) for d in datas]
 
     def close(self) -> None:
         if self._predictor is not None:

@@ -532,7 +532,20 @@ def secondary_rates(device, ex, tiles, B):
     for _ in range(5):
         pred.predict_image(img)
     host_ms = (time.perf_counter() - t0) / 5 * 1e3
+    # --seg-batch-size 4: four thumbnails per forward (trunk on the stacked batch; every mask bit-equal to its single forward)
+    imgs4 = torch.from_numpy(np.random.default_rng(1).integers(0, 256, (4, 1024, 1024, 3), dtype=np.uint8)).to(device)
+    with torch.inference_mode():
+        for _ in range(2):
+            pred._graph_masks_device(imgs4)
+        torch.cuda.synchronize(device)
+        eb0, eb1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        eb0.record()
+        for _ in range(5):
+            pred._graph_masks_device(imgs4)
+        eb1.record()
+        torch.cuda.synchronize(device)
     rates["sam2_segmentation"] = {"ms_per_slide_device": round(ev0.elapsed_time(ev1) / 10, 3), "ms_per_slide_host_to_host": round(host_ms, 3),
+                                  "ms_per_slide_device_seg_batch_4": round(eb0.elapsed_time(eb1) / 20, 3),
                                   "slides_per_s": round(1e3 / host_ms, 1),
                                   "what": "SAM2.1 Hiera-T image encoder + box-prompted mask decoder on one 1024x1024 thumbnail "
                                           "(services/segmentation.py:120-140), exact-f32 MFMA GEMMs, ~350 launches captured in one "

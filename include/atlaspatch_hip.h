@@ -338,6 +338,11 @@ int ap_attention(int dtype, const void* qkv, void* out, int n, int tokens, int h
 int ap_sgemm(const float* A, long lda, long strideA, const float* W, long ldw, long strideW, int w_is_kn,
              int batch, int M, int N, int K, float alpha, const float* bias, int act,
              const float* resid, long ldr, long strideR, float* out, long ldo, long strideO, ap_stream_t stream);
+/* The same for `stack` equally shaped problems stacked along M (a batch of images through a row-wise layer), NT weights,
+ * no batch strides: every output row goes through exactly the arithmetic it would go through alone (the split-K plan is
+ * the single problem's), so the result does not depend on how many images are stacked; M % stack == 0. */
+int ap_sgemm_stacked(const float* A, long lda, const float* W, long ldw, int stack, int M, int N, int K, const float* bias,
+                     int act, const float* resid, long ldr, float* out, long ldo, ap_stream_t stream);
 int ap_softmax_rows(float* x, long ld, int rows, int cols, ap_stream_t stream);     /* in place */
 /* Fused attention of the trunk (hieradet.py MultiScaleAttention -> F.scaled_dot_product_attention), image-wide blocks
  * (batch = 1) and windowed blocks (batch = number of windows, window b owns rows b * tq .. of q / out and b * tk .. of k / v):

@@ -127,6 +127,34 @@ def test_sam2_predict_device_equals_predict_image():
 
 
 @pytest.mark.gpu
+def test_sam2_batched_forward_equals_the_single_slide_forwards_bit_for_bit():
+    """``--seg-batch-size`` > 1: the trunk runs on the stacked thumbnails (GEMMs planned like a single image,
+    ``ap_sgemm_stacked``; windows, images and rows are independent in every other operator).  Logits AND masks of every
+    image equal its own single-image forward exactly -- launch by launch and as the captured per-batch-size graph --
+    for batch sizes 2, 3 and 4 with mixed thumbnail shapes, whatever the image is batched with."""
+    import torch
+    from atlaspatch_amd.services.sam2_hip import Sam2HipPredictor
+    from atlaspatch_amd.services.segmentation import random_sam2_state_dict
+    pred = Sam2HipPredictor(random_sam2_state_dict(4), device="cuda")
+    rng = np.random.default_rng(11)
+    shapes = [(733, 1024), (1024, 1024), (1024, 681), (512, 700), (900, 1000)]
+    thumbs = [torch.from_numpy(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).cuda() for h, w in shapes]
+    single = [pred.predict_device(t, resize_to_input=True) for t in thumbs]
+    # logits of the stacked trunk vs the single trunk, no graph
+    imgs = torch.from_numpy(rng.integers(0, 256, (3, 1024, 1024, 3), dtype=np.uint8)).cuda()
+    with torch.inference_mode():
+        lone = [pred.mask_logits(*pred.image_features(imgs[b])).clone() for b in range(3)]
+        stacked = [pred.mask_logits(*f).clone() for f in pred.image_features_batch(imgs)]
+    for b in range(3):
+        assert torch.equal(lone[b], stacked[b]), (b, float((lone[b] - stacked[b]).abs().max()))
+    for group in ([0, 1], [2, 3, 4], [4, 0, 1, 2], [3, 2]):
+        got = pred.predict_batch_device([thumbs[i] for i in group], resize_to_input=True)
+        for i, g in zip(group, got):
+            assert g.shape == single[i].shape and np.array_equal(g, single[i]), (group, i, float((g != single[i]).mean()))
+    pred.close()
+
+
+@pytest.mark.gpu
 def test_openslide_level_read_in_parallel_strips_equals_one_read_region(tmp_path):
     """OpenSlideWSI.read_level_device: full-width strips read by libopenslide on a thread pool == extract((0, 0), level,
     dims) through openslide-python, for a level with an integer downsample (strips) -- run in a subprocess, the stub

@@ -47,6 +47,8 @@ def block_plan():
 
 
 class Sam2HipPredictor:
+    MAX_BATCH = 32          # thumbnails per forward (larger --seg-batch-size values run as several forwards)
+
     def __init__(self, state_dict: dict, *, device="cuda", mask_threshold: float = 0.0) -> None:
         self.device = torch.device(device)
         if self.device.type != "cuda" or not torch.cuda.is_available():
@@ -483,6 +485,11 @@ class Sam2HipPredictor:
         Element i equals ``predict_device(thumbs[i])`` bit for bit."""
         from ..utils.resample import DeviceResampler, pillow_nearest_index
         S = self.input_size
+        if len(thumbs) > self.MAX_BATCH:            # stage-1 windows: 1024 per image, 65 535 per fused-attention launch
+            out = []
+            for i in range(0, len(thumbs), self.MAX_BATCH):
+                out += self.predict_batch_device(thumbs[i:i + self.MAX_BATCH], resize_to_input=resize_to_input)
+            return out
         with torch.cuda.device(self.device):
             imgs = torch.empty((len(thumbs), S, S, 3), dtype=torch.uint8, device=self.device)
             shapes = []

@@ -61,7 +61,8 @@
 // issued two MFMA pairs apart.  A fourth replaced the epilogue's LDS transposition by v_permlane32_swap pairs and 16-byte
 // row-per-lane stores (32 rows x 32 bytes per instruction): bit-identical, qkv 5 % slower, fc1 unchanged -- the whole-row
 // stores are worth their LDS round trip.  s_setprio 1 for waves 4-7 before the main loop, and s_setprio 1 / 0 around every phase's
-// MFMA cluster: both inside +-0.5 %.
+// MFMA cluster: both inside +-0.5 %.  The non-temporal hint on the activation panel's LDS-DMA (so that the six weight panels an XCD
+// re-reads wave after wave stay in its L2): 1.3-2.6 % slower.
 #ifdef AP_G256_ALT
 #define AP_G256_FN(name) name##_alt
 #else

@@ -7,6 +7,7 @@ objective-power property or inferred from MPP, ``read_region(...).convert("RGB")
 from __future__ import annotations
 
 import re
+import threading
 from typing import Literal, Optional, Tuple, Union
 
 import numpy as np
@@ -98,6 +99,7 @@ class OpenSlideWSI(IWSI):
         super().__init__(path=path, mpp=mpp)
         self._slide = None
         self._native = None            # ap_openslide handle of the batched native reader; False = not available
+        self._native_lock = threading.Lock()
 
     def _setup(self) -> None:
         self._slide = openslide.OpenSlide(self.path)
@@ -161,12 +163,16 @@ class OpenSlideWSI(IWSI):
         if self._native is False or os.environ.get("ATLASPATCH_OPENSLIDE_NATIVE", "1") == "0":
             return None
         if self._native is None:
-            handle = C.c_void_p()
-            if _lib.load().ap_host_openslide_open(str(self.path).encode(), C.byref(handle)) != _lib.AP_OK:
-                self._native = False
-                return None
-            self._native = handle
-        return self._native
+            # every TileRing decode thread arrives here on a slide's first batch: one opens, the others wait (an unguarded
+            # check would open one libopenslide handle -- descriptors + tile cache -- per thread and leak all but the last)
+            with self._native_lock:
+                if self._native is None:
+                    handle = C.c_void_p()
+                    if _lib.load().ap_host_openslide_open(str(self.path).encode(), C.byref(handle)) != _lib.AP_OK:
+                        self._native = False
+                    else:
+                        self._native = handle
+        return self._native or None
 
     def read_level_device(self, level: int, wh, device):
         """Whole-level read for the thumbnail (iwsi.py:296-303 is ONE read_region of the full level on one thread):

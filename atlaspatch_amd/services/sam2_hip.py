@@ -390,30 +390,41 @@ class Sam2HipPredictor:
             out = np.asarray(pil, dtype=np.float32) / 255.0
         return out
 
+    RESAMPLER_CACHE = 16
+
+    def _resampler_for(self, h: int, w: int):
+        """(BILINEAR resampler to 1024 x 1024, NEAREST row / column indices back) for a thumbnail shape: an LRU — a hit
+        moves the entry to the young end, eviction takes the oldest.  Callers hold the returned tuple for as long as they
+        need it (a batch with more distinct shapes than the cache holds still works)."""
+        from ..utils.resample import DeviceResampler, pillow_nearest_index
+        S = self.input_size
+        rs = self._resamplers.pop((h, w), None)
+        if rs is None:
+            yi = torch.from_numpy(pillow_nearest_index(S, h)).to(self.device)
+            xi = torch.from_numpy(pillow_nearest_index(S, w)).to(self.device)
+            rs = (DeviceResampler((h, w), (S, S), "bilinear", self.device), yi, xi)
+        self._resamplers[(h, w)] = rs
+        while len(self._resamplers) > self.RESAMPLER_CACHE:
+            self._resamplers.pop(next(iter(self._resamplers)))
+        return rs
+
     @torch.inference_mode()
     def predict_device(self, thumb: torch.Tensor, *, resize_to_input: bool = True) -> np.ndarray:
         """``predict_image`` for a thumbnail that already lives in HBM (uint8 [h, w, 3]): the PIL BILINEAR resize to
         1024 x 1024 (``_resize_input_for_sam``, segmentation.py:104-110) runs on the device bit-identically to Pillow
         (``ap_resample_u8``), the network is the same captured graph, and the mask returns to the thumbnail's shape by
         PIL NEAREST semantics (``_resize_mask``, :112-118) as a device gather.  One D2H copy: the float {0, 1} mask."""
-        from ..utils.resample import DeviceResampler, pillow_nearest_index
         assert thumb.is_cuda and thumb.dtype == torch.uint8 and thumb.dim() == 3 and thumb.shape[2] == 3
         h, w = int(thumb.shape[0]), int(thumb.shape[1])
         S = self.input_size
         with torch.cuda.device(self.device):
             img = thumb.contiguous()
             if (h, w) != (S, S):
-                rs = self._resamplers.get((h, w))
-                if rs is None:
-                    yi = torch.from_numpy(pillow_nearest_index(S, h)).to(self.device)
-                    xi = torch.from_numpy(pillow_nearest_index(S, w)).to(self.device)
-                    rs = self._resamplers[(h, w)] = (DeviceResampler((h, w), (S, S), "bilinear", self.device), yi, xi)
-                    if len(self._resamplers) > 8:                      # bounded: thumbnails of a cohort share a few shapes
-                        self._resamplers.pop(next(iter(self._resamplers)))
+                rs = self._resampler_for(h, w)
                 img = rs[0](img[None])[0]
             mask = self._graph_mask_device(img)
             if resize_to_input and (h, w) != (S, S):
-                _, yi, xi = self._resamplers[(h, w)]
+                _, yi, xi = rs
                 out = self._buf(h, w)
                 _lib.check(self.lib.ap_gather2d_f32(mask.data_ptr(), S, S, yi.data_ptr(), xi.data_ptr(), h, w, out.data_ptr(),
                                                     self._stream()), "ap_gather2d_f32")
@@ -483,7 +494,6 @@ class Sam2HipPredictor:
         """``predict_device`` for several thumbnails (each uint8 [h, w, 3] in HBM, any sizes) in ONE forward: each is resized
         to 1024 x 1024 as Pillow would, the batch goes through the trunk stacked, each mask returns to its thumbnail's shape.
         Element i equals ``predict_device(thumbs[i])`` bit for bit."""
-        from ..utils.resample import DeviceResampler, pillow_nearest_index
         S = self.input_size
         if len(thumbs) > self.MAX_BATCH:            # stage-1 windows: 1024 per image, 65 535 per fused-attention launch
             out = []
@@ -492,28 +502,24 @@ class Sam2HipPredictor:
             return out
         with torch.cuda.device(self.device):
             imgs = torch.empty((len(thumbs), S, S, 3), dtype=torch.uint8, device=self.device)
-            shapes = []
+            shapes, used = [], []              # the batch keeps its own references: cache eviction cannot take them away
             for b, thumb in enumerate(thumbs):
                 assert thumb.is_cuda and thumb.dtype == torch.uint8 and thumb.dim() == 3 and thumb.shape[2] == 3
                 h, w = int(thumb.shape[0]), int(thumb.shape[1])
                 shapes.append((h, w))
                 if (h, w) == (S, S):
                     imgs[b].copy_(thumb)
+                    used.append(None)
                     continue
-                rs = self._resamplers.get((h, w))
-                if rs is None:
-                    yi = torch.from_numpy(pillow_nearest_index(S, h)).to(self.device)
-                    xi = torch.from_numpy(pillow_nearest_index(S, w)).to(self.device)
-                    rs = self._resamplers[(h, w)] = (DeviceResampler((h, w), (S, S), "bilinear", self.device), yi, xi)
-                    while len(self._resamplers) > 8 + len(thumbs):
-                        self._resamplers.pop(next(iter(self._resamplers)))
+                rs = self._resampler_for(h, w)
+                used.append(rs)
                 imgs[b].copy_(rs[0](thumb.contiguous()[None])[0])
             masks = self._graph_masks_device(imgs)
             out = []
             for b, (h, w) in enumerate(shapes):
                 m = masks[b]
                 if resize_to_input and (h, w) != (S, S):
-                    _, yi, xi = self._resamplers[(h, w)]
+                    _, yi, xi = used[b]
                     g = self._buf(h, w)
                     _lib.check(self.lib.ap_gather2d_f32(m.data_ptr(), S, S, yi.data_ptr(), xi.data_ptr(), h, w, g.data_ptr(),
                                                         self._stream()), "ap_gather2d_f32")
@@ -530,16 +536,27 @@ class Sam2HipPredictor:
 
 def load_sam2_state_dict(checkpoint_path) -> dict:
     """The reference's checkpoint layout (``torch.load(path)["model"]``, segmentation.py:66-67); a bare state dict and a
-    DataParallel ``module.`` prefix are accepted too.  Every tensor the image path reads is checked up front so that a
-    checkpoint with other key names fails with the list of what is missing instead of a KeyError mid-construction."""
-    obj = torch.load(str(checkpoint_path), map_location="cpu", weights_only=True)
+    DataParallel ``module.`` prefix are accepted too, and so is the Hugging Face ``Sam2Model`` layout (a torch file or a
+    ``.safetensors`` export), which is renamed through ``sam2_keys.hf_to_facebook`` — that map is pinned against
+    ``transformers.models.sam2`` by tests/golden/gen_golden_hf_sam2.py.  Every tensor the image path reads is checked up
+    front so that a checkpoint with other key names fails with the list of what is missing instead of a KeyError
+    mid-construction."""
+    from .sam2_keys import hf_to_facebook, is_hf_layout
+    path = str(checkpoint_path)
+    if path.endswith(".safetensors"):
+        from safetensors.torch import load_file
+        obj = load_file(path, device="cpu")
+    else:
+        obj = torch.load(path, map_location="cpu", weights_only=True)
     sd = obj["model"] if isinstance(obj, dict) and "model" in obj else obj
     if sd and all(k.startswith("module.") for k in sd):
         sd = {k[len("module."):]: v for k, v in sd.items()}
+    if is_hf_layout(sd):
+        sd = hf_to_facebook(sd)
     missing = [k for k in required_sam2_keys() if k not in sd]
     if missing:
         raise KeyError(f"{checkpoint_path}: {len(missing)} tensors of the SAM2.1 Hiera-T image path are missing, e.g. "
-                       f"{missing[:6]} (expected the sam2 package's state-dict names)")
+                       f"{missing[:6]} (expected the sam2 package's state-dict names or the transformers Sam2Model layout)")
     return sd
 
 

@@ -1,8 +1,13 @@
 """CPU oracle: SAM2.1 Hiera-T image path as the reference drives it (box prompt = whole image).
 
-TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  PARITY UNPINNED: the ``sam2`` package
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  PINNED against an independent implementation: the ``sam2`` package
 (facebookresearch/sam2 @ git HEAD, /root/reference/pyproject.toml:63-64) and the AtlasPatch checkpoint
-(``AtlasAnalyticsLab/AtlasPatch:model.pth``, services/segmentation.py:28-29) are absent from this image.
+(``AtlasAnalyticsLab/AtlasPatch:model.pth``, services/segmentation.py:28-29) are absent from this image, but Hugging Face
+``transformers.models.sam2.Sam2Model`` (default config = Hiera-T) is present: ``tests/golden/gen_golden_hf_sam2.py`` loads
+the seeded weights below into it through ``atlaspatch_amd/services/sam2_keys.py`` and records its feature levels and mask
+logits (``tests/golden/hf_sam2.npz``); ``tests/test_sam2_hf_pin.py`` holds this file to 1e-5 of them (measured 2.8e-7) and the
+HIP path to 1e-4 / 2e-4.  Still unpinned: the real checkpoint's tensors (never seen here) — the key NAMES are checked only
+through the HF map, whose facebook side is from the public sources.
 This file restates, in explicit torch fp32 ops, the modules the reference instantiates from
 ``atlas_patch/configs/sam2.1_hiera_t.yaml`` and the calls it makes (services/segmentation.py:104-140):
 
@@ -12,7 +17,9 @@ This file restates, in explicit torch fp32 ops, the modules the reference instan
                          stride-16 level (directly_add_no_mem_embed)
   predictor.predict      box = [0, 0, w, h] -> two corner points (labels 2, 3) + one padding point (label -1)
                          through the prompt encoder; no mask prompt -> no_mask_embed; mask decoder (two-way
-                         transformer depth 2, high-res features, 4 mask tokens, multimask_output=False -> token 0)
+                         transformer depth 2, high-res features, 4 mask tokens, multimask_output=False -> token 0:
+                         the reference instantiates the yaml directly (segmentation.py:62-64), so build_sam2's
+                         dynamic_multimask_via_stability override is NOT active)
                          -> 256 x 256 logits -> bilinear x4 (align_corners False) -> > mask_threshold (0.0)
   _resize_mask           (:112-118)  mask * 255 -> uint8 -> PIL NEAREST back to the thumbnail -> / 255
 

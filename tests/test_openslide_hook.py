@@ -144,3 +144,32 @@ def test_process_on_an_openslide_slide_native_hook_equals_the_per_tile_path(tmp_
     assert native["embed_calls"] == 0 and pertile["embed_calls"] >= pertile["n"]
     assert np.array_equal(c1, c0) and np.array_equal(f1, f0)
     assert np.isfinite(f1).all() and np.abs(f1).max() > 0
+
+
+def test_decode_threads_racing_on_a_slides_first_batch_share_one_native_handle(tmp_path):
+    """All TileRing decode threads call read_tiles_into on the first batch of a slide: the lazily opened ap_openslide handle
+    must be opened once (an unguarded check leaked one libopenslide handle per thread)."""
+    from tools import stub_openslide as so
+    lib = so.build(str(tmp_path))
+    out = _run_py(f"""
+        import json, threading
+        from tools import stub_openslide as so
+        from atlaspatch_amd.core.wsi import openslide_wsi
+        openslide_wsi.openslide = so.python_module({lib!r})
+        path = so.write_slide({str(tmp_path / 's.svs')!r}, 4000, 3000, seed=5, alpha_period=0)
+        distinct = 0
+        for trial in range(20):
+            wsi = openslide_wsi.OpenSlideWSI(path)
+            wsi._ensure_loaded()
+            gate = threading.Barrier(16)
+            seen = []
+            def go():
+                gate.wait()
+                seen.append(wsi._native_handle().value)
+            ts = [threading.Thread(target=go) for _ in range(16)]
+            [t.start() for t in ts]; [t.join() for t in ts]
+            distinct = max(distinct, len(set(seen)))
+            wsi.cleanup()
+        print(json.dumps(dict(distinct=distinct)))
+        """, {"ATLASPATCH_LIBOPENSLIDE": lib}, tmp_path)
+    assert out["distinct"] == 1

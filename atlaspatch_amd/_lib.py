@@ -129,6 +129,11 @@ SIGNATURES = {
 
 
 def library_path() -> str:
+    """The in-tree product library; ATLASPATCH_HIP_LIB names another build of the same ABI (tools only: the debug
+    library with the GEMM A/B twin, `make -C atlaspatch_amd/csrc twin`)."""
+    override = os.environ.get("ATLASPATCH_HIP_LIB")
+    if override:
+        return override
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
 
 

@@ -466,7 +466,10 @@ int launch_ln_typed(float* x, long stride, const LnAdds& add, int rows, int dim,
         else layernorm16_kernel<TD, TO, 16, true><<<g16, b16, lds, stream>>>(x, stride, add, rows, dim, gamma, beta, eps, o, groups);
     } else {
         if constexpr (std::is_same<TD, float>::value && std::is_same<TO, float>::value) {
-            if (!add.d[0] && !add.d[1]) {
+            // the narrow kernel moves 16 bytes per lane: any pointer or row stride the C ABI hands over that is not
+            // 16-byte aligned takes the general kernel (equal to f32 rounding; the SAM2 path, the only caller at these widths, is always aligned)
+            const bool vec_ok = ((((uintptr_t)x | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0) && stride % 4 == 0;
+            if (!add.d[0] && !add.d[1] && vec_ok) {
 #define AP_LN_NARROW(DIM, LPR, NV)                                                                                       \
                 if (dim == DIM) {                                                                                        \
                     const int per_wg = 4 * (64 / LPR);                                                                   \

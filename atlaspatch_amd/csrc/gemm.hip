@@ -389,7 +389,15 @@ int launch_gemm(int dtype, int epilogue, const GemmArgs& a, hipStream_t stream) 
 int launch_gemm_impl(int dtype, int epilogue, const GemmArgs& a, int impl, int variant, hipStream_t stream) {
     AP_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem %d x %d x %d", a.M, a.N, a.K);
     AP_REQUIRE(impl == 0 || impl == 128 || impl == 256 || impl == 257, "gemm: unknown implementation %d", impl);
-    if (impl == 257) return launch_gemm256_alt(dtype, epilogue, a, variant, stream);
+    if (impl == 257) {
+#ifdef AP_WITH_TWIN
+        return launch_gemm256_alt(dtype, epilogue, a, variant, stream);
+#else
+        set_error("gemm: impl 257 (the A/B twin with its ablation flags) is not part of the product library; "
+                  "build it with `make -C atlaspatch_amd/csrc twin` and load libatlaspatch_hip_twin.so through ATLASPATCH_HIP_LIB");
+        return AP_ERR_UNSUPPORTED;
+#endif
+    }
     const bool fused_epi = epilogue == EPI_NORM_STORE || epilogue == EPI_NORM_GELU || epilogue == EPI_RESID_STATS ||
                            epilogue == EPI_PATCH_STREAM;
     AP_REQUIRE(!fused_epi || dtype != AP_F32, "gemm: the fused-LayerNorm epilogues are f16 / bf16 only");

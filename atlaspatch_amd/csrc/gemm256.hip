@@ -397,9 +397,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
         // ---------------- epilogue
         stamp_clk(ti, 6);
         stamp(ti, 1);
-        // lane-derived epilogue constants are recomputed per tile from an opaque copy of the lane id:
-        // hoisted out of the tile loop they would live (spilled) across the whole K loop
-        int lane_e = lane;
+        // lane-derived epilogue constants are recomputed per tile from a FRESH lane id (v_mbcnt: no register has to stay
+        // live -- or be spilled, as an opaque copy of `lane` was in the BIAS_GELU instantiation -- across the K loop)
+        int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
         asm volatile("" : "+v"(lane_e));
         const int hi = lane_e >> 5, l31 = lane_e & 31;
         const int id = tw.first + ti * tw.stride;

@@ -235,7 +235,9 @@ class HipViT:
                              1 if attn_pool else 0, int(arch.get("pool_dim", 0)), int(arch.get("pool_heads", 0)),
                              float(arch.get("pool_ln_eps", 1e-5)))
         handle = C.c_void_p()
-        with torch.cuda.device(self.device):
+        # hipMalloc / hipMemcpy on the legacy stream must not fall into another thread's stream capture (the SAM2 hipGraph):
+        # both sides hold _lib.HIP_CAPTURE_LOCK for their device section
+        with _lib.HIP_CAPTURE_LOCK, torch.cuda.device(self.device):
             _lib.check(self.lib.ap_vit_create(C.byref(cfg), C.byref(handle)), "ap_vit_create")
             self._handle = handle
             # one native call for the whole checkpoint: the uploads run outside the interpreter lock (the encoder is built

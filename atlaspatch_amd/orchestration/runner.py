@@ -200,11 +200,35 @@ class ProcessingRunner:
             # Pipelined: a helper thread prepares group k + 1's network inputs (level read, cv2 / Pillow resizes) while
             # this thread runs group k's forwards.  Same calls on the same inputs in the same order per slide: same masks.
             prep = futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="seg-input")
+            read_workers = max(1, min(8, max(1, self.config.segmentation.batch_size), os.cpu_count() or 8))
+            readers = futures.ThreadPoolExecutor(max_workers=read_workers, thread_name_prefix="thumb") if read_workers > 1 else None
+            warmed = [not hasattr(seg, "warm_up")]
 
-            def prepare(opened):
+            def warm_up_once():
+                # every hipGraph the run needs (full groups and the remainder group) is captured before the first group's
+                # input is prepared: no coordinate worker and no input thread is issuing HIP calls of its own yet.  (Groups
+                # that lose slides to skip-existing / lock files may still need another size: captured when met, under
+                # capture_error_mode="thread_local" as before.)
+                warmed[0] = True
+                B = max(1, self.config.segmentation.batch_size)
+                try:
+                    seg.warm_up({min(B, len(slides)), len(slides) % B})
+                except Exception as exc:  # noqa: BLE001  (no weights / no device: reported per slide by the forward itself)
+                    logger.debug("segmentation warm-up skipped: %s", exc)
+
+            def prepare_one(w):
                 if self._device_index is not None:
                     torch.cuda.set_device(self._device_index)
-                return [seg.prepare_input(w) for _, w, _, _ in opened]
+                return seg.prepare_input(w)
+
+            def prepare(opened):
+                # the level reads of a group overlap like the reference's 8 thumbnail threads (segmentation.py:216-220)
+                if self._device_index is not None:
+                    torch.cuda.set_device(self._device_index)
+                wsis = [w for _, w, _, _ in opened]
+                if readers is None or len(wsis) == 1:
+                    return [seg.prepare_input(w) for w in wsis]
+                return list(readers.map(prepare_one, wsis))
 
             def finish(item):
                 opened, fut = item
@@ -221,6 +245,8 @@ class ProcessingRunner:
             pending = None
             for group in groups:
                 opened = open_group(group)
+                if opened and not warmed[0]:
+                    warm_up_once()
                 nxt = (opened, prep.submit(prepare, opened)) if opened else None
                 if pending is not None:
                     finish(pending)
@@ -228,6 +254,8 @@ class ProcessingRunner:
             if pending is not None:
                 finish(pending)
             prep.shutdown(wait=True)
+            if readers is not None:
+                readers.shutdown(wait=True)
         else:
             for group in groups:
                 opened = open_group(group)

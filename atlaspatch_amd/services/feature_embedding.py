@@ -280,8 +280,9 @@ class PatchFeatureEmbeddingService(FeatureEmbeddingService):
         def build():
             if device_index is not None:
                 torch.cuda.set_device(device_index)          # the HIP device is per thread
-            from .. import _lib
-            with stage("encoder_create"), _lib.HIP_CAPTURE_LOCK:
+            # the checkpoint load runs unlocked; HipViT takes HIP_CAPTURE_LOCK itself, around its device uploads only, so a
+            # SAM2 graph capture waits for the upload and not for torch.load / a hub download
+            with stage("encoder_create"):
                 return self.registry.create(name)
 
         pool = futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="encoder")

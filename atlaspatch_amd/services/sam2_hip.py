@@ -482,12 +482,26 @@ class Sam2HipPredictor:
                 with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     static_out = self._forward_masks(static_in)
             entry = self._batch_graphs[B] = (graph, static_in, static_out)
-            while len(self._batch_graphs) > 2:                   # a run uses one batch size plus at most one remainder size
+            while len(self._batch_graphs) > 3:                   # a run uses one batch size plus at most two remainder sizes (cohort, MAX_BATCH chunk)
                 self._batch_graphs.pop(next(iter(self._batch_graphs)))
         graph, static_in, static_out = entry
         static_in.copy_(imgs)
         graph.replay()
         return static_out
+
+    @torch.inference_mode()
+    def capture_graphs(self, batch_sizes) -> None:
+        """Capture the graphs of every batch size a run will use BEFORE its worker threads start (the runner calls this
+        with {seg_batch_size, n_slides % seg_batch_size}): stream capture then never coincides with the coordinate workers'
+        legacy-stream calls (hipMalloc / hipFree / hipMemcpyAsync of ap_contours / ap_grid_coords) -- without this the
+        remainder-size graph would be captured during the LAST group, while earlier groups' workers are in flight."""
+        S = self.input_size
+        with torch.cuda.device(self.device):
+            for B in sorted({min(int(b), self.MAX_BATCH) for b in batch_sizes if int(b) > 0}):
+                if (B == 1 and self._graph is not None) or (B > 1 and B in self._batch_graphs):
+                    continue
+                self._graph_masks_device(torch.zeros((B, S, S, 3), dtype=torch.uint8, device=self.device))
+            torch.cuda.synchronize(self.device)
 
     @torch.inference_mode()
     def predict_batch_device(self, thumbs, *, resize_to_input: bool = True) -> list:

@@ -133,6 +133,11 @@ class SAM2SegmentationService(SegmentationService):
     def segment_thumbnail(self, wsi: IWSI) -> Mask:
         return self.segment_prepared(self.prepare_input(wsi))
 
+    def warm_up(self, batch_sizes) -> None:
+        """Build the predictor and capture its hipGraphs for the forward batch sizes of the coming run, before any worker
+        thread exists (``Sam2HipPredictor.capture_graphs``)."""
+        self.predictor.capture_graphs(batch_sizes)
+
     # The two halves of segment_thumbnail, so that a caller can prepare slide k + 1's input (level read, cv2 / Pillow
     # resizes: host work + short device kernels) on another thread while slide k's forward runs (orchestration/runner.py).
     def prepare_input(self, wsi: IWSI):

@@ -114,6 +114,7 @@ SIGNATURES = {
     "ap_contours_points": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "ap_grid_coords": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                  C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p]),
+    "ap_clock_probe": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ap_synth_tiles": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                  C.c_uint32, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "ap_gather2d_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -24,7 +24,7 @@ void set_error(const char* fmt, ...) {
 
 extern "C" {
 
-int ap_abi_version(void) { return 15; }
+int ap_abi_version(void) { return 16; }
 
 const char* ap_last_error(void) { return ap::g_error; }
 

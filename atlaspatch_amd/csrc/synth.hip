@@ -82,3 +82,32 @@ extern "C" int ap_synth_region(int64_t x, int64_t y, int w, int h, int level_ds,
     AP_HIP_CHECK(hipGetLastError());
     return AP_OK;
 }
+
+// ---- measurement aid: shader-clock stamps -------------------------------------------------------------------------------
+// 32 one-wave workgroups (the dispatcher deals consecutive workgroups round-robin over the 8 XCDs); lane 0 of each writes
+// {s_memtime, s_memrealtime} into the slot of the XCD it runs on (HW_REG_XCC_ID).  s_memtime ticks with the shader clock,
+// s_memrealtime with the fixed 100 MHz reference: two probes on one stream around a timed region give the AVERAGE shader
+// clock the governor granted there, per XCD, without a profiler:  GHz = 0.1 * d(memtime) / d(memrealtime).
+namespace ap {
+namespace {
+__global__ __launch_bounds__(64) void clock_probe_kernel(long long* __restrict__ out) {
+    if (threadIdx.x != 0) return;
+    const unsigned xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 15u;      // HW_REG_XCC_ID[3:0]
+    const long long t = (long long)__builtin_amdgcn_s_memtime();
+    const long long r = (long long)__builtin_amdgcn_s_memrealtime();
+    if (xcc < 8) {
+        out[xcc * 4 + 0] = t;
+        out[xcc * 4 + 1] = r;
+        out[xcc * 4 + 2] = (long long)xcc;
+        out[xcc * 4 + 3] = (long long)blockIdx.x;
+    }
+}
+}  // namespace
+}  // namespace ap
+
+extern "C" int ap_clock_probe(long long* out32, ap_stream_t stream) {
+    AP_REQUIRE(out32, "ap_clock_probe: null pointer");
+    ap::clock_probe_kernel<<<32, 64, 0, (hipStream_t)stream>>>(out32);
+    AP_HIP_CHECK(hipGetLastError());
+    return AP_OK;
+}

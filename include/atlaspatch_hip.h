@@ -420,6 +420,12 @@ int ap_synth_region(int64_t x, int64_t y, int w, int h, int level_ds, int level,
                     int64_t width, int64_t height, uint32_t seed,
                     const int64_t* ellipses, int k, uint8_t* dst, ap_stream_t stream);
 
+/* Measurement aid (bench.py): one launch writes, per XCD x (HW_REG_XCC_ID), out32[4x + 0] = s_memtime (shader-clock ticks),
+ * out32[4x + 1] = s_memrealtime (100 MHz ticks), out32[4x + 2] = x, out32[4x + 3] = the workgroup that wrote the slot.
+ * out32: 32 int64 in device memory, zeroed by the caller.  Two probes on one stream around a region give the average
+ * shader clock there: GHz = 0.1 * d(memtime) / d(memrealtime).  No reference counterpart. */
+int ap_clock_probe(long long* out32, ap_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -604,3 +604,23 @@ def test_vit_set_params_equals_per_tensor_uploads_and_rejects_bad_entries(env):
     names = (C.c_char_p * 1)(first.encode())
     assert lib.ap_vit_set_params(h, names, ptrs, counts, 1) != 0 and first.encode() in lib.ap_last_error()
     batched.release(); single.release()
+
+
+def test_clock_probe_reports_a_plausible_shader_clock():
+    """ap_clock_probe (bench.py's clock line): s_memtime / s_memrealtime stamps per XCD around a few GEMM-sized launches give a
+    shader clock inside the part's range, on every XCD the dispatcher used."""
+    from atlaspatch_amd.utils.telemetry import ClockProbe, PowerSampler
+    dev = torch.device("cuda:0")
+    probe = ClockProbe(dev)
+    a = torch.randn(4096, 4096, device=dev, dtype=torch.float16)
+    with PowerSampler(dev) as ps:
+        probe.start()
+        for _ in range(20):
+            a = (a @ a).clamp_(-1, 1)
+        probe.stop()
+        torch.cuda.synchronize(dev)
+    info = probe.read()
+    assert info["xcds"] >= 1 and 0.3 <= info["min_GHz"] <= info["shader_clock_GHz"] <= info["max_GHz"] <= 2.6, info
+    # (the XCDs are separate clock domains: 1.44 ... 1.67 GHz were seen inside one 0.7-s bench region)
+    s = ps.summary()
+    assert s["samples"] == 0 or 20.0 <= s["package_W_mean"] <= 2000.0, s

@@ -34,7 +34,9 @@ class VitConfig(C.Structure):
     _fields_ = [("image_size", C.c_int), ("patch_size", C.c_int), ("dim", C.c_int),
                 ("depth", C.c_int), ("heads", C.c_int), ("mlp_dim", C.c_int),
                 ("ln_eps", C.c_float), ("layer_scale", C.c_int), ("compute_dtype", C.c_int),
-                ("pool", C.c_int), ("pool_dim", C.c_int), ("pool_heads", C.c_int), ("pool_ln_eps", C.c_float)]
+                ("pool", C.c_int), ("pool_dim", C.c_int), ("pool_heads", C.c_int), ("pool_ln_eps", C.c_float),
+                ("reg_tokens", C.c_int), ("no_embed_class", C.c_int), ("mlp_type", C.c_int), ("head_dim", C.c_int),
+                ("attn_scale", C.c_float)]
 
 
 # name -> (restype, argtypes); every symbol include/atlaspatch_hip.h declares

@@ -109,7 +109,11 @@ struct GemmArgs {
     float* partial;          // EPI_RESID_STATS / EPI_PATCH_STREAM: f32 [rows, N / 64, 2]
     const void* pos16;       // EPI_PATCH_STREAM: T [P + 1, N]
     void* out; int ldo;      // T (STORE / GELU) or f32 (RESID / PATCH_EMBED)
-    int P;                   // EPI_PATCH_EMBED: patches per image
+    int P;                   // EPI_PATCH_EMBED / EPI_PATCH_STREAM: patches per image
+    int R;                   //   prefix rows per image in the token stream (class + register tokens): patch row
+                             //   m = img * P + p goes to stream row img * (P + R) + R + p
+    int pos_row0;            //   row of pos / pos16 that belongs to patch 0 (R, or 0 when the position embedding has no
+                             //   rows for the prefix tokens: timm no_embed_class)
     int ablate;              // gemm256 A/B twin only: timing ablation flags (results invalid when set)
     int walk_cols;           // gemm256 only: tile-walk column-group width (0 = kernel default)
     int skew_ticks;          // gemm256 only: start-time spread across an XCD's workgroups (100 MHz ticks)
@@ -147,14 +151,15 @@ int launch_add2_layernorm(int delta_dtype, int out_dtype, float* x, long stride,
 int launch_layernorm_f32out(const float* x, long stride, int rows, int dim, const float* gamma,
                             const float* beta, float eps, float* out, hipStream_t stream);
 // qkv: T [n*tokens, 3*dim] (q | k | v), out: T [n*tokens, dim]
+// head_dim: 64 or 128 (f32: 64); scale: the softmax scale (1 / sqrt(true head width))
 int launch_attention(int dtype, const void* qkv, void* out, int n, int tokens, int heads,
-                     int head_dim, hipStream_t stream);
-int launch_attention_flash(int dtype, const void* qkv, void* out, int n, int tokens, int heads,
+                     int head_dim, float scale, hipStream_t stream);
+int launch_attention_flash(int dtype, const void* qkv, void* out, int n, int tokens, int heads, int head_dim, float scale,
                            hipStream_t stream);
 // attentional pooling (attn_pool.hip): kv T [n*tokens, 2*heads*64] (k | v), q f32 [heads*64] -> out T [n, heads*64]
 // one query row per (image, head) (CLS row of the last block); q packed [n, heads*64], k / v inside rows of `kv`
 int launch_attention_cls(int dtype, const void* q, const void* kv, int ld, int koff, int voff, void* out, int n,
-                         int tokens, int heads, int head_dim, hipStream_t stream);
+                         int tokens, int heads, int head_dim, float scale, hipStream_t stream);
 int launch_attn_pool(int dtype, const void* kv, const float* q, void* out, int n, int tokens, int heads,
                      hipStream_t stream);
 // ---- fused-LayerNorm path (16-bit residual stream) ---------------------------------------
@@ -174,11 +179,16 @@ int launch_fold_ln(int dtype, const float* w32, int rows, int cols, int ld, cons
                    const float* bias_in, void* wout, float* colsum, float* bias_out, hipStream_t stream);
 int launch_fold_ls(int dtype, const float* w32, int rows, int cols, int ld, const float* ls, const float* bias_in,
                    void* wout, float* bias_out, hipStream_t stream);
-// fused path: stream rows of the class token, x[img * tokens] = T(cls + pos[0]), and their partial sums
-int launch_cls_stream(int dtype, const float* cls, const float* pos, int n, int tokens, int dim, void* x, float* partial,
+// prefix rows of the token stream (class token, then register tokens): prefix f32 [prefix_rows, dim] = the token values with
+// their position-embedding rows already added (ap_vit_finalize).  fused path: x[img * tokens + j] = T(prefix[j]) and the rows'
+// partial sums; f32 path: tok[img * tokens + j] = prefix[j]
+int launch_cls_stream(int dtype, const float* prefix, int prefix_rows, int n, int tokens, int dim, void* x, float* partial,
                       hipStream_t stream);
-int launch_cls_init(float* tok, const float* cls, const float* pos, int n, int tokens, int dim,
-                    hipStream_t stream);
+int launch_cls_init(float* tok, const float* prefix, int prefix_rows, int n, int tokens, int dim, hipStream_t stream);
+// out[m][j] = T(silu(x[m][j]) * x[m][h + j]), x: T [rows, 2h] dense, out: T [rows, h] dense (timm SwiGLUPacked; f32 math)
+int launch_swiglu(int dtype, const void* x, int rows, int h, void* out, hipStream_t stream);
+// prefix[j][:] = tokens[j][:] (+ pos[j][:] when pos != nullptr), f32
+int launch_prefix_build(const float* cls, const float* reg, int reg_rows, const float* pos, int dim, float* prefix, hipStream_t stream);
 int launch_convert(int dtype, const float* src, void* dst, size_t count, hipStream_t stream);
 // [n,3,S,S] (f32 or T) -> patch rows T [n*g*g, ld]
 int launch_chw_to_patchrows(int x_dtype, int dtype, const void* x, int n, int S, int ps, void* dst,

@@ -66,7 +66,7 @@ __device__ __forceinline__ f32x16 mma16<bf16>(bf16x8 a, bf16x8 b, f32x16 c) {
 
 template <typename T, int NKT, int NW>
 __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 ? 2 : 1))
-void attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int tokens, int heads) {
+void attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int tokens, int heads, float scale) {
     constexpr int NT = NW * 64;
     using S = AttnSmem<T, NKT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -117,7 +117,7 @@ void attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int tokens
     }
     __syncthreads();
 
-    const float scale_log2 = 0.125f * 1.4426950408889634f;      // log2(e) / sqrt(64)
+    const float scale_log2 = scale * 1.4426950408889634f;       // log2(e) / sqrt(head width)
     const int nqb = (tokens + 31) >> 5;
 
     for (int qb = wave; qb < nqb; qb += NT / 64) {
@@ -275,7 +275,7 @@ void attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int tokens
 }
 
 template <typename T, int NKT, int NW>
-int launch_nw(const void* qkv, void* out, int n, int tokens, int heads, hipStream_t stream) {
+int launch_nw(const void* qkv, void* out, int n, int tokens, int heads, float scale, hipStream_t stream) {
     using S = AttnSmem<T, NKT>;
     static bool configured = false;
     auto kern = attention_kernel<T, NKT, NW>;
@@ -284,22 +284,22 @@ int launch_nw(const void* qkv, void* out, int n, int tokens, int heads, hipStrea
                                          S::total));
         configured = true;
     }
-    kern<<<dim3(n * heads), dim3(NW * 64), S::total, stream>>>((const T*)qkv, (T*)out, tokens, heads);
+    kern<<<dim3(n * heads), dim3(NW * 64), S::total, stream>>>((const T*)qkv, (T*)out, tokens, heads, scale);
     AP_HIP_CHECK(hipGetLastError());
     return AP_OK;
 }
 
 template <typename T, int NKT>
-int launch_one(const void* qkv, void* out, int n, int tokens, int heads, hipStream_t stream) {
+int launch_one(const void* qkv, void* out, int n, int tokens, int heads, float scale, hipStream_t stream) {
     static const int waves = [] { const char* e = getenv("AP_ATTN_WAVES"); return e ? atoi(e) : 4; }();
-    if (sizeof(T) == 2 && waves == 8) return launch_nw<T, NKT, 8>(qkv, out, n, tokens, heads, stream);
-    return launch_nw<T, NKT, 4>(qkv, out, n, tokens, heads, stream);
+    if (sizeof(T) == 2 && waves == 8) return launch_nw<T, NKT, 8>(qkv, out, n, tokens, heads, scale, stream);
+    return launch_nw<T, NKT, 4>(qkv, out, n, tokens, heads, scale, stream);
 }
 
 template <typename T>
-int launch_by_len(const void* qkv, void* out, int n, int tokens, int heads, hipStream_t stream) {
-    if (tokens <= 224) return launch_one<T, 7>(qkv, out, n, tokens, heads, stream);
-    if (tokens <= 288) return launch_one<T, 9>(qkv, out, n, tokens, heads, stream);
+int launch_by_len(const void* qkv, void* out, int n, int tokens, int heads, float scale, hipStream_t stream) {
+    if (tokens <= 224) return launch_one<T, 7>(qkv, out, n, tokens, heads, scale, stream);
+    if (tokens <= 288) return launch_one<T, 9>(qkv, out, n, tokens, heads, scale, stream);
     set_error("attention: %d tokens not supported by this build (max 288)", tokens);
     return AP_ERR_UNSUPPORTED;
 }
@@ -307,21 +307,21 @@ int launch_by_len(const void* qkv, void* out, int n, int tokens, int heads, hipS
 }  // namespace
 
 int launch_attention(int dtype, const void* qkv, void* out, int n, int tokens, int heads,
-                     int head_dim, hipStream_t stream) {
-    AP_REQUIRE(head_dim == kHD, "attention: head_dim %d unsupported (64 only)", head_dim);
-    AP_REQUIRE(tokens > 0 && heads > 0, "attention: bad shape");
+                     int head_dim, float scale, hipStream_t stream) {
+    AP_REQUIRE(head_dim == kHD || (head_dim == 128 && dtype != AP_F32), "attention: head_dim %d unsupported (64; 128 in f16 / bf16)", head_dim);
+    AP_REQUIRE(tokens > 0 && heads > 0 && scale > 0.f, "attention: bad shape");
     if (n <= 0) return AP_OK;
     // f16 / bf16: the tiled online-softmax kernel (attention_flash.hip; any length, 0.37 ms vs 0.49 ms for
     // the strip kernel at n = 1024, T = 197, H = 12).  AP_ATTN_IMPL=strip selects the register-strip kernel
     // below (T <= 288) for A/B timing; f32 always uses it.
     if (dtype != AP_F32) {
         static const bool strip = [] { const char* e = getenv("AP_ATTN_IMPL"); return e && e[0] == 's'; }();
-        if (!strip || tokens > 288) return launch_attention_flash(dtype, qkv, out, n, tokens, heads, stream);
+        if (!strip || tokens > 288 || head_dim != kHD) return launch_attention_flash(dtype, qkv, out, n, tokens, heads, head_dim, scale, stream);
     }
     switch (dtype) {
-        case AP_F16: return launch_by_len<f16>(qkv, out, n, tokens, heads, stream);
-        case AP_BF16: return launch_by_len<bf16>(qkv, out, n, tokens, heads, stream);
-        case AP_F32: return launch_by_len<float>(qkv, out, n, tokens, heads, stream);
+        case AP_F16: return launch_by_len<f16>(qkv, out, n, tokens, heads, scale, stream);
+        case AP_BF16: return launch_by_len<bf16>(qkv, out, n, tokens, heads, scale, stream);
+        case AP_F32: return launch_by_len<float>(qkv, out, n, tokens, heads, scale, stream);
     }
     set_error("attention: unknown dtype %d", dtype);
     return AP_ERR_INVALID;

@@ -1,5 +1,8 @@
-// Tiled ("flash") multi-head attention for f16 / bf16, head_dim 64, any sequence length:
-//     out = softmax(q k^T / sqrt(64)) v      per (image, head), f32 softmax, online rescaling.
+// Tiled ("flash") multi-head attention for f16 / bf16, heads stored 64 or 128 wide, any sequence length:
+//     out = softmax(q k^T * scale) v      per (image, head), f32 softmax, online rescaling.
+// (The text below describes the 64-wide instantiation; HD = 128 -- vit_h_14's 80-wide heads, zero-padded -- has 256-byte
+// rows: two DMA pieces per thread, operand and tile, K chunks XOR-swizzled by row & 15, V 64-byte windows by row & 3, four
+// 32-channel output blocks, 128 KiB of LDS.)
 //
 // One workgroup = 8 waves = eight 32-query blocks of one (image, head); it walks the keys in tiles
 // of 64.  K and V tiles arrive by LDS-DMA (global_load_lds, 16 B per lane, one K and one V piece
@@ -37,9 +40,7 @@
 namespace ap {
 namespace {
 
-constexpr int kHD = 64;
 constexpr int kKV = 64;                 // keys per tile
-constexpr int kTileBytes = kKV * 128;   // one K or V tile (64 rows x 128 B)
 constexpr int kNW = 8;                  // waves per workgroup
 constexpr int kNB = 4;                  // K/V ring buffers (prefetch distance kNB - 1)
 
@@ -100,9 +101,17 @@ __device__ __forceinline__ float half_swap_sum(float v) {
     return lo + hi;
 }
 
-template <typename T>
-__global__ __launch_bounds__(kNW * 64, 4)
-void attention_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int tokens, int heads, int parts, int units) {
+template <typename T, int HD>
+__global__ __launch_bounds__(kNW * 64, HD == 64 ? 4 : 2)
+void attention_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int tokens, int heads, int parts, int units,
+                            float scale) {
+    constexpr int kHD = HD;
+    constexpr int RB = HD * 2;                       // bytes of one K / V row of a head
+    constexpr int kTileBytes = kKV * RB;             // one K or V tile (64 rows)
+    constexpr int NKK = HD / 16;                     // k-steps of S^T = K Q^T
+    constexpr int NIT = HD / 32;                     // 32-channel output blocks
+    constexpr int NPC = kTileBytes / (kNW * 64 * 16);   // DMA pieces per thread, operand and tile (1 or 2)
+    constexpr int CPR = RB / 16;                     // 16-byte chunks per row (8 or 16)
     __shared__ __attribute__((aligned(16))) char smem[kNB * 2 * kTileBytes];     // [buf][K | V]
     using Frag = typename FMma<T>::Frag;
 
@@ -123,18 +132,35 @@ void attention_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int 
     const char* vbase = base + (size_t)dim * 4;
     const int nkv = (tokens + kKV - 1) / kKV;
 
-    // ---- staging plan: thread -> (tile row = tid >> 3, LDS chunk = tid & 7); source chunk swizzled
-    const int srow = tid >> 3, spos = tid & 7;
-    const uint32_t kchunk = (uint32_t)((spos ^ ((srow >> 1) & 7)) << 4);
-    const uint32_t vchunk = (uint32_t)((spos ^ (((srow >> 1) & 1) << 2)) << 4);
+    // ---- staging plan: piece pc of thread tid is the 16-byte LDS chunk (pc * 512 + tid) of the tile, i.e. tile row
+    //      idx / CPR, chunk idx % CPR; the SOURCE chunk is swizzled (K: by row pairs at 128-byte rows, by row & 15 at
+    //      256-byte rows; V: 64-byte windows)
+    uint32_t kchunk[NPC], vchunk[NPC];
+    int srow[NPC];
+#pragma unroll
+    for (int pc = 0; pc < NPC; ++pc) {
+        const int idx = pc * (kNW * 64) + tid;
+        const int row = idx / CPR, spos = idx % CPR;
+        srow[pc] = row;
+        if constexpr (HD == 64) {
+            kchunk[pc] = (uint32_t)((spos ^ ((row >> 1) & 7)) << 4);
+            vchunk[pc] = (uint32_t)((spos ^ (((row >> 1) & 1) << 2)) << 4);
+        } else {
+            kchunk[pc] = (uint32_t)((spos ^ (row & 15)) << 4);
+            vchunk[pc] = (uint32_t)((spos ^ ((row & 3) << 2)) << 4);
+        }
+    }
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + wave * 1024;
     auto stage = [&](int j) {
-        int row = j * kKV + srow;
-        row = row < tokens ? row : tokens - 1;
-        const uint32_t roff = (uint32_t)row * ldb;
-        const uint32_t dst = lds0 + (j % kNB) * 2 * kTileBytes;
-        dma16(kbase, roff + kchunk, dst);
-        dma16(vbase, roff + vchunk, dst + kTileBytes);
+#pragma unroll
+        for (int pc = 0; pc < NPC; ++pc) {
+            int row = j * kKV + srow[pc];
+            row = row < tokens ? row : tokens - 1;
+            const uint32_t roff = (uint32_t)row * ldb;
+            const uint32_t dst = lds0 + (j % kNB) * 2 * kTileBytes + pc * (kNW * 64 * 16);
+            dma16(kbase, roff + kchunk[pc], dst);
+            dma16(vbase, roff + vchunk[pc], dst + kTileBytes);
+        }
     };
 #pragma unroll
     for (int j = 0; j < kNB - 1; ++j)
@@ -148,42 +174,43 @@ void attention_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int 
     int qrow = qb * 32 + l31;
     const bool qvalid = qrow < tokens;
     if (!qvalid) qrow = tokens - 1;
-    Frag qf[4];
+    Frag qf[NKK];
     {
         const T* qp = (const T*)(base + (size_t)qrow * ldb);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const Frag*)(qp + kk * 16 + hi * 8);
+        for (int kk = 0; kk < NKK; ++kk) qf[kk] = *(const Frag*)(qp + kk * 16 + hi * 8);
     }
     // The Q registers are "used" HERE, in front of the tile loop: hipcc's wait-count pass then puts its vmcnt(0) for
     // these four loads at this point.  Without it the wait sits in front of their first real use -- the QK^T MFMAs
     // INSIDE the loop (the pass cannot prove that an earlier iteration already waited) -- and, because the LDS-DMA
     // stream is invisible to the pass, that vmcnt(0) drained every staged tile in every iteration: the tile staged
     // a few instructions earlier was waited for at once and the three-tile prefetch never overlapped anything.
-    asm volatile("" :: "v"(qf[0]), "v"(qf[1]), "v"(qf[2]), "v"(qf[3]));
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) asm volatile("" :: "v"(qf[kk]));
 
     // ---- fragment addresses inside a buffer
-    const int xr = (l31 >> 1) & 7;
-    uint32_t ka[4];                               // K: row l31 (+32 per key block), chunk (2 kk + hi) ^ xr
+    const int xr = HD == 64 ? (l31 >> 1) & 7 : l31 & 15;
+    uint32_t ka[NKK];                             // K: row l31 (+32 per key block), chunk (2 kk + hi) ^ xr
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) ka[kk] = (uint32_t)(l31 * 128 + (((kk * 2 + hi) ^ xr) << 4));
+    for (int kk = 0; kk < NKK; ++kk) ka[kk] = (uint32_t)(l31 * RB + (((kk * 2 + hi) ^ xr) << 4));
     // V (transpose load): lane = (group g = lane >> 4, s = lane & 15) points at 8 bytes of key row
     // 4 * (g >> 1) + (s >> 2) (+ 16 s' + {0, 8}), channels (g & 1) * 16 + 4 * (s & 3) .. + 3 (+ 32 it)
     const int g = lane >> 4, s16 = lane & 15;
     const int vrow = 4 * (g >> 1) + (s16 >> 2);                          // 0 .. 7
     const int vcol = ((g & 1) * 32 + (s16 & 3) * 8);                     // byte offset inside the 64-B half
-    uint32_t va[2];                                                      // it = 0, 1 (row swizzle folded in)
+    uint32_t va[NIT];                                                    // it = 32-channel block (row swizzle folded in)
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int chunk = (it * 4 + (vcol >> 4)) ^ (((vrow >> 1) & 1) << 2);
-        va[it] = (uint32_t)(kTileBytes + vrow * 128 + (chunk << 4) + (vcol & 15));
+    for (int it = 0; it < NIT; ++it) {
+        const int chunk = (it * 4 + (vcol >> 4)) ^ ((HD == 64 ? (vrow >> 1) & 1 : vrow & 3) << 2);
+        va[it] = (uint32_t)(kTileBytes + vrow * RB + (chunk << 4) + (vcol & 15));
     }
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
-    const float c = 0.125f * 1.4426950408889634f;                        // log2(e) / sqrt(64)
+    const float c = scale * 1.4426950408889634f;                         // log2(e) * softmax scale
     float m_run = -INFINITY, l_run = 0.f;
-    f32x16 ot[2];
+    f32x16 ot[NIT];
 #pragma unroll
-    for (int it = 0; it < 2; ++it)
+    for (int it = 0; it < NIT; ++it)
 #pragma unroll
         for (int e = 0; e < 16; ++e) ot[it][e] = 0.f;
 
@@ -201,8 +228,8 @@ void attention_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int 
         for (int kb = 0; kb < 2; ++kb) {
             if (kb == 1 && !full) break;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const Frag kf = *(const Frag*)(buf + kb * 32 * 128 + ka[kk]);
+            for (int kk = 0; kk < NKK; ++kk) {
+                const Frag kf = *(const Frag*)(buf + kb * 32 * RB + ka[kk]);
                 st[kb] = FMma<T>::run(kf, qf[kk], kk == 0 ? zero16 : st[kb]);
             }
         }
@@ -233,7 +260,7 @@ void attention_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int 
             l_run *= alpha;
             if (j > 0) {
 #pragma unroll
-                for (int it = 0; it < 2; ++it)
+                for (int it = 0; it < NIT; ++it)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) ot[it][e] *= alpha;
             }
@@ -263,13 +290,26 @@ void attention_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int 
             Frag pf;
 #pragma unroll
             for (int e = 0; e < 8; ++e) pf[e] = (T)st[sp >> 1][(sp & 1) * 8 + e];
-            u32x2 v0a = tr_read<sp * 16 * 128>(v0), v0b = tr_read<sp * 16 * 128 + 8 * 128>(v0);
-            u32x2 v1a = tr_read<sp * 16 * 128>(v1), v1b = tr_read<sp * 16 * 128 + 8 * 128>(v1);
-            // the loads' destinations count as written only from here on (hipcc does not track asm loads)
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v0a), "+v"(v0b), "+v"(v1a), "+v"(v1b) :: "memory");
-            const u32x4 f0 = {v0a[0], v0a[1], v0b[0], v0b[1]}, f1 = {v1a[0], v1a[1], v1b[0], v1b[1]};
-            ot[0] = FMma<T>::run(__builtin_bit_cast(Frag, f0), pf, ot[0]);
-            ot[1] = FMma<T>::run(__builtin_bit_cast(Frag, f1), pf, ot[1]);
+            u32x2 v0a = tr_read<sp * 16 * RB>(v0), v0b = tr_read<sp * 16 * RB + 8 * RB>(v0);
+            u32x2 v1a = tr_read<sp * 16 * RB>(v1), v1b = tr_read<sp * 16 * RB + 8 * RB>(v1);
+            if constexpr (HD == 64) {
+                // the loads' destinations count as written only from here on (hipcc does not track asm loads)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v0a), "+v"(v0b), "+v"(v1a), "+v"(v1b) :: "memory");
+                const u32x4 f0 = {v0a[0], v0a[1], v0b[0], v0b[1]}, f1 = {v1a[0], v1a[1], v1b[0], v1b[1]};
+                ot[0] = FMma<T>::run(__builtin_bit_cast(Frag, f0), pf, ot[0]);
+                ot[1] = FMma<T>::run(__builtin_bit_cast(Frag, f1), pf, ot[1]);
+            } else {
+                const uint32_t v2 = bufa + va[NIT - 2], v3 = bufa + va[NIT - 1];
+                u32x2 v2a = tr_read<sp * 16 * RB>(v2), v2b = tr_read<sp * 16 * RB + 8 * RB>(v2);
+                u32x2 v3a = tr_read<sp * 16 * RB>(v3), v3b = tr_read<sp * 16 * RB + 8 * RB>(v3);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v0a), "+v"(v0b), "+v"(v1a), "+v"(v1b), "+v"(v2a), "+v"(v2b), "+v"(v3a), "+v"(v3b) :: "memory");
+                const u32x4 f0 = {v0a[0], v0a[1], v0b[0], v0b[1]}, f1 = {v1a[0], v1a[1], v1b[0], v1b[1]};
+                const u32x4 f2 = {v2a[0], v2a[1], v2b[0], v2b[1]}, f3 = {v3a[0], v3a[1], v3b[0], v3b[1]};
+                ot[0] = FMma<T>::run(__builtin_bit_cast(Frag, f0), pf, ot[0]);
+                ot[1] = FMma<T>::run(__builtin_bit_cast(Frag, f1), pf, ot[1]);
+                ot[NIT - 2] = FMma<T>::run(__builtin_bit_cast(Frag, f2), pf, ot[NIT - 2]);
+                ot[NIT - 1] = FMma<T>::run(__builtin_bit_cast(Frag, f3), pf, ot[NIT - 1]);
+            }
         };
         pv_step(IntC<0>{});
         pv_step(IntC<1>{});
@@ -299,11 +339,15 @@ void attention_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int 
     const float inv = 1.0f / half_swap_sum(l_run);
     {
         if (!active) return;
-        // buffer nkv % kNB is free (every wave has left iteration nkv - 2, nothing is staged any more); wave w
-        // owns 4 KiB of it: row = query, 16-byte chunk c at (c ^ (row & 7)) * 16
-        char* stg = smem + (nkv % kNB) * 2 * kTileBytes + wave * 4096;
+        // buffers nkv % kNB and (nkv + 1) % kNB held tiles nkv - 4 and nkv - 3: free (every wave has left iteration
+        // nkv - 2, nothing is staged any more).  The eight waves' 32 x RB-byte blocks fill exactly these two buffers,
+        // WRAPPING around the ring's end (nkv % 4 == 3: before round 4 waves 4-7 then wrote past the allocation, where LDS
+        // drops the writes -- 129..192 and 385..448 tokens gave zero rows for their queries; no shape in use hit it).
+        // row = query, 16-byte chunk c at (c ^ (row & (CPR - 1))) * 16
+        constexpr int kStg = 32 * RB;
+        char* stg = smem + ((nkv % kNB) * 2 * kTileBytes + wave * kStg) % (kNB * 2 * kTileBytes);
 #pragma unroll
-        for (int it = 0; it < 2; ++it)
+        for (int it = 0; it < NIT; ++it)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const T a = (T)(ot[it][g4 * 4 + 0] * inv), b = (T)(ot[it][g4 * 4 + 1] * inv);
@@ -311,15 +355,16 @@ void attention_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int 
                 u32x2 o;
                 o[0] = (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
                 o[1] = (uint32_t)__builtin_bit_cast(uint16_t, cc) | ((uint32_t)__builtin_bit_cast(uint16_t, d) << 16);
-                *(u32x2*)(stg + l31 * 128 + (((it * 4 + g4) ^ (l31 & 7)) << 4) + hi * 8) = o;
+                *(u32x2*)(stg + l31 * RB + (((it * 4 + g4) ^ (l31 & (CPR - 1))) << 4) + hi * 8) = o;
             }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        constexpr int kRowsPer = 64 / CPR;            // rows one wave-wide 16-byte read covers (8 or 4)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = (lane >> 3) + 8 * i, ch = lane & 7;
-            const u32x4 v = *(const u32x4*)(stg + row * 128 + ((ch ^ (row & 7)) << 4));
+        for (int i = 0; i < 32 / kRowsPer; ++i) {
+            const int row = lane / CPR + kRowsPer * i, ch = lane % CPR;
+            const u32x4 v = *(const u32x4*)(stg + row * RB + ((ch ^ (row & (CPR - 1))) << 4));
             const int q = qb * 32 + row;
             if (q < tokens) *(u32x4*)(out + ((size_t)img * tokens + q) * dim + head * kHD + ch * 8) = v;
         }
@@ -328,16 +373,19 @@ void attention_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int 
 
 }  // namespace
 
-int launch_attention_flash(int dtype, const void* qkv, void* out, int n, int tokens, int heads,
+int launch_attention_flash(int dtype, const void* qkv, void* out, int n, int tokens, int heads, int head_dim, float scale,
                            hipStream_t stream) {
     AP_REQUIRE(dtype == AP_F16 || dtype == AP_BF16, "attention_flash: f16 / bf16 only");
-    AP_REQUIRE((size_t)tokens * 3 * heads * kHD * 2 < 0xffffffffull, "attention_flash: sequence too long");
+    AP_REQUIRE(head_dim == 64 || head_dim == 128, "attention_flash: head_dim %d (64 / 128)", head_dim);
+    AP_REQUIRE((size_t)tokens * 3 * heads * head_dim * 2 < 0xffffffffull, "attention_flash: sequence too long");
     if (n <= 0) return AP_OK;
     const int nqb = (tokens + 31) / 32;
     const int parts = (nqb + kNW - 1) / kNW, units = n * heads;
     dim3 grid((unsigned)((units + 7) / 8 * 8 * parts)), block(kNW * 64);
-    if (dtype == AP_F16) attention_flash_kernel<f16><<<grid, block, 0, stream>>>((const f16*)qkv, (f16*)out, tokens, heads, parts, units);
-    else attention_flash_kernel<bf16><<<grid, block, 0, stream>>>((const bf16*)qkv, (bf16*)out, tokens, heads, parts, units);
+#define AP_FLASH(T, HD) attention_flash_kernel<T, HD><<<grid, block, 0, stream>>>((const T*)qkv, (T*)out, tokens, heads, parts, units, scale)
+    if (head_dim == 64) { if (dtype == AP_F16) AP_FLASH(f16, 64); else AP_FLASH(bf16, 64); }
+    else { if (dtype == AP_F16) AP_FLASH(f16, 128); else AP_FLASH(bf16, 128); }
+#undef AP_FLASH
     AP_HIP_CHECK(hipGetLastError());
     return AP_OK;
 }

@@ -91,29 +91,30 @@ __global__ __launch_bounds__(256) void attn_pool_kernel(const T* __restrict__ kv
 template <typename T> struct RowVec { using v8 = typename PoolVec<T>::v8; };
 template <> struct RowVec<float> { typedef float v8 __attribute__((ext_vector_type(8))); };
 
-template <typename T>
+template <typename T, int HD>
 __global__ __launch_bounds__(256) void attn_cls_kernel(const T* __restrict__ q, const T* __restrict__ kv, int ld, int koff,
-                                                       int voff, T* __restrict__ out, int tokens, int heads) {
-    // thread = (row slot r of 32, channel octet sub of 8): every K / V access is a 16-byte load and a wave covers eight
-    // whole 128-byte rows per step
-    extern __shared__ __attribute__((aligned(16))) float sm[];       // scores[tokens] | red[4] | part[32][64]
+                                                       int voff, T* __restrict__ out, int tokens, int heads, float scale) {
+    // thread = (row slot r of kRows, channel octet sub of kSub): every K / V access is a 16-byte load and a wave covers
+    // whole rows per step (HD = 64: eight 128-byte rows; HD = 128: four 256-byte rows)
+    constexpr int kSub = HD / 8, kRows = 256 / kSub;
+    extern __shared__ __attribute__((aligned(16))) float sm[];       // scores[tokens] | red[4] | part[kRows][HD]
     float* scores = sm;
     float* red = sm + ((tokens + 3) & ~3);
     float* part = red + 4;
     using V8 = typename RowVec<T>::v8;
     const int img = blockIdx.x / heads, head = blockIdx.x - img * heads;
-    const int P = heads * 64;
-    const int sub = threadIdx.x & 7, r = threadIdx.x >> 3;
-    const T* kbase = kv + (size_t)img * tokens * ld + koff + head * 64 + sub * 8;
-    const T* vbase = kv + (size_t)img * tokens * ld + voff + head * 64 + sub * 8;
+    const int P = heads * HD;
+    const int sub = threadIdx.x & (kSub - 1), r = threadIdx.x / kSub;
+    const T* kbase = kv + (size_t)img * tokens * ld + koff + head * HD + sub * 8;
+    const T* vbase = kv + (size_t)img * tokens * ld + voff + head * HD + sub * 8;
     float qr[8];
     {
-        const V8 qq = *(const V8*)(q + (size_t)img * P + head * 64 + sub * 8);
+        const V8 qq = *(const V8*)(q + (size_t)img * P + head * HD + sub * 8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) qr[e] = (float)qq[e];
     }
     float mx = -INFINITY;
-    for (int t = r; t < tokens; t += 32) {
+    for (int t = r; t < tokens; t += kRows) {
         const V8 kk = *(const V8*)(kbase + (size_t)t * ld);
         float s = 0.f;
 #pragma unroll
@@ -121,7 +122,8 @@ __global__ __launch_bounds__(256) void attn_cls_kernel(const T* __restrict__ q, 
         s += __shfl_xor(s, 1, 64);
         s += __shfl_xor(s, 2, 64);
         s += __shfl_xor(s, 4, 64);
-        s *= 0.125f;
+        if constexpr (kSub == 16) s += __shfl_xor(s, 8, 64);
+        s *= scale;
         if (sub == 0) scores[t] = s;
         mx = fmaxf(mx, s);
     }
@@ -134,21 +136,21 @@ __global__ __launch_bounds__(256) void attn_cls_kernel(const T* __restrict__ q, 
     }
     sum = block_reduce(sum, red, false);
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int t = r; t < tokens; t += 32) {
+    for (int t = r; t < tokens; t += kRows) {
         const float p = scores[t];
         const V8 vv = *(const V8*)(vbase + (size_t)t * ld);
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = __builtin_fmaf(p, (float)vv[e], acc[e]);
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) part[r * 64 + sub * 8 + e] = acc[e];
+    for (int e = 0; e < 8; ++e) part[r * HD + sub * 8 + e] = acc[e];
     __syncthreads();
-    if (threadIdx.x < 64) {
+    if (threadIdx.x < HD) {
         const int c = threadIdx.x;
         float o = 0.f;
 #pragma unroll
-        for (int g = 0; g < 32; ++g) o += part[g * 64 + c];
-        out[(size_t)img * P + head * 64 + c] = (T)(o / sum);
+        for (int g = 0; g < kRows; ++g) o += part[g * HD + c];
+        out[(size_t)img * P + head * HD + c] = (T)(o / sum);
     }
 }
 
@@ -168,18 +170,20 @@ int launch_attn_pool(int dtype, const void* kv, const float* q, void* out, int n
 }
 
 int launch_attention_cls(int dtype, const void* q, const void* kv, int ld, int koff, int voff, void* out, int n,
-                         int tokens, int heads, int head_dim, hipStream_t stream) {
-    AP_REQUIRE(head_dim == 64, "attention_cls: head_dim %d unsupported (64 only)", head_dim);
+                         int tokens, int heads, int head_dim, float scale, hipStream_t stream) {
+    AP_REQUIRE(head_dim == 64 || head_dim == 128, "attention_cls: head_dim %d unsupported (64 / 128)", head_dim);
     AP_REQUIRE(tokens > 0 && tokens <= 12000, "attention_cls: %d tokens unsupported", tokens);
     AP_REQUIRE(ld % 8 == 0 && koff % 8 == 0 && voff % 8 == 0, "attention_cls: misaligned layout");
     if (n <= 0) return AP_OK;
-    const size_t lds = ((size_t)((tokens + 3) & ~3) + 4 + 32 * 64) * sizeof(float);
+    const size_t lds = ((size_t)((tokens + 3) & ~3) + 4 + 32 * 64) * sizeof(float);       // part: kRows * HD = 2048 floats either way
     dim3 grid(n * heads), block(256);
-#define AP_CLS(T) attn_cls_kernel<T><<<grid, block, lds, stream>>>((const T*)q, (const T*)kv, ld, koff, voff, (T*)out, tokens, heads)
-    if (dtype == AP_F16) AP_CLS(f16);
-    else if (dtype == AP_BF16) AP_CLS(bf16);
-    else if (dtype == AP_F32) AP_CLS(float);
+#define AP_CLS(T, HD) attn_cls_kernel<T, HD><<<grid, block, lds, stream>>>((const T*)q, (const T*)kv, ld, koff, voff, (T*)out, tokens, heads, scale)
+#define AP_CLS_HD(T) do { if (head_dim == 64) AP_CLS(T, 64); else AP_CLS(T, 128); } while (0)
+    if (dtype == AP_F16) AP_CLS_HD(f16);
+    else if (dtype == AP_BF16) AP_CLS_HD(bf16);
+    else if (dtype == AP_F32) AP_CLS_HD(float);
     else { set_error("attention_cls: unsupported dtype %d", dtype); return AP_ERR_INVALID; }
+#undef AP_CLS_HD
 #undef AP_CLS
     AP_HIP_CHECK(hipGetLastError());
     return AP_OK;

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <vector>
 #include <zlib.h>
+#include <cmath>
 #include "ap_common.h"
 
 namespace ap {
@@ -24,7 +25,7 @@ void set_error(const char* fmt, ...) {
 
 extern "C" {
 
-int ap_abi_version(void) { return 16; }
+int ap_abi_version(void) { return 17; }
 
 const char* ap_last_error(void) { return ap::g_error; }
 
@@ -213,7 +214,8 @@ int ap_layernorm(int out_dtype, const float* x, long stride, int rows, int dim, 
 int ap_attention(int dtype, const void* qkv, void* out, int n, int tokens, int heads, int head_dim,
                  ap_stream_t stream) {
     AP_REQUIRE(qkv && out, "ap_attention: null pointer");
-    return ap::launch_attention(dtype, qkv, out, n, tokens, heads, head_dim, (hipStream_t)stream);
+    AP_REQUIRE(head_dim > 0, "ap_attention: head_dim %d", head_dim);
+    return ap::launch_attention(dtype, qkv, out, n, tokens, heads, head_dim, 1.0f / sqrtf((float)head_dim), (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -329,11 +329,11 @@ __global__ __launch_bounds__(256) void rowstats_finalize_kernel(const float* __r
 // class-token rows of the fused path: x[img * tokens][:] = T(cls + pos[0]) and the row's partial sums per 64-column group
 // (one wave per (image, group): lane = column).  Only this kernel ever produces these rows, so its summation order is theirs.
 template <typename T>
-__global__ __launch_bounds__(64) void cls_stream_kernel(const float* __restrict__ cls, const float* __restrict__ pos, int tokens,
+__global__ __launch_bounds__(64) void cls_stream_kernel(const float* __restrict__ prefix, int prefix_rows, int tokens,
                                                         int dim, T* __restrict__ x, float* __restrict__ partial) {
-    const int img = blockIdx.x, grp = blockIdx.y, col = grp * 64 + threadIdx.x;
-    const size_t row = (size_t)img * tokens;
-    const T v = from_f32<T>(cls[col] + pos[col]);
+    const int img = blockIdx.x / prefix_rows, j = blockIdx.x - img * prefix_rows, grp = blockIdx.y, col = grp * 64 + threadIdx.x;
+    const size_t row = (size_t)img * tokens + j;
+    const T v = from_f32<T>(prefix[(size_t)j * dim + col]);
     x[row * dim + col] = v;
     const float f = (float)v;
     const float s = wave_sum(f), q = wave_sum(f * f);
@@ -493,12 +493,46 @@ int launch_ln_typed(float* x, long stride, const LnAdds& add, int rows, int dim,
     return AP_OK;
 }
 
-__global__ void cls_init_kernel(float* tok, const float* cls, const float* pos, int n, int tokens,
-                                int dim) {
+__global__ void cls_init_kernel(float* tok, const float* prefix, int prefix_rows, int n, int tokens, int dim) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n * dim) return;
-    const int img = i / dim, d = i - img * dim;
-    tok[(size_t)img * tokens * dim + d] = cls[d] + pos[d];
+    const int per = prefix_rows * dim;
+    if (i >= n * per) return;
+    const int img = i / per, r = i - img * per;             // r = j * dim + d
+    tok[(size_t)img * tokens * dim + r] = prefix[r];
+}
+
+__global__ void prefix_build_kernel(const float* cls, const float* reg, int reg_rows, const float* pos, int dim, float* prefix) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (1 + reg_rows) * dim) return;
+    const float t = i < dim ? cls[i] : reg[i - dim];
+    prefix[i] = pos ? t + pos[i] : t;
+}
+
+// timm SwiGLUPacked (GluMlp, gate_last = False): x1, x2 = fc1(x).chunk(2, -1); silu(x1) * x2.  f32 math on the T values,
+// one rounding; 8 elements per lane (16-byte loads / stores)
+template <typename T>
+__global__ __launch_bounds__(256) void swiglu_kernel(const T* __restrict__ x, int rows, int h, T* __restrict__ out) {
+    const size_t per = (size_t)(h >> 3);
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)rows * per) return;
+    const size_t row = i / per, c = (i - row * per) * 8;
+    const T* p = x + row * (size_t)(2 * h) + c;
+    const u32x4 a4 = *(const u32x4*)p, b4 = *(const u32x4*)(p + h);
+    const T* a = (const T*)&a4; const T* b = (const T*)&b4;
+    T y[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x1 = (float)a[e], x2 = (float)b[e];
+        y[e] = from_f32<T>((x1 / (1.0f + expf(-x1))) * x2);
+    }
+    *(u32x4*)(out + row * (size_t)h + c) = *(const u32x4*)y;
+}
+__global__ __launch_bounds__(256) void swiglu_f32_kernel(const float* __restrict__ x, int rows, int h, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)rows * h) return;
+    const size_t row = i / h, c = i - row * h;
+    const float x1 = x[row * (size_t)(2 * h) + c], x2 = x[row * (size_t)(2 * h) + h + c];
+    out[i] = (x1 / (1.0f + expf(-x1))) * x2;
 }
 
 template <typename T>
@@ -526,6 +560,19 @@ __global__ void chw_to_patchrows_kernel(const TI* __restrict__ x, int n, int S, 
     TO* d = dst + ((size_t)(img * g + py) * g + px) * ld + (c * ps + ky) * ps + quad * 4;
     f32x4 v = {(float)s[0], (float)s[1], (float)s[2], (float)s[3]};
     store_vec4<TO>(d, v);
+}
+// any patch size (14: rows of 14 elements are not 8- or 16-byte aligned): one thread per element
+template <typename TI, typename TO>
+__global__ void chw_to_patchrows_any_kernel(const TI* __restrict__ x, int n, int S, int ps, TO* __restrict__ dst, int ld) {
+    const int g = S / ps;
+    const size_t total = (size_t)n * 3 * S * S;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int xx = i % S; size_t r = i / S;
+    const int y = r % S; r /= S;
+    const int c = r % 3; const int img = r / 3;
+    const int py = y / ps, ky = y - py * ps, px = xx / ps, kx = xx - px * ps;
+    dst[((size_t)(img * g + py) * g + px) * ld + (c * ps + ky) * ps + kx] = from_f32<TO>((float)x[i]);
 }
 
 }  // namespace
@@ -581,13 +628,13 @@ int launch_stream_init(int dtype, const float* tok, int rows, int dim, float eps
     return AP_OK;
 }
 
-int launch_cls_stream(int dtype, const float* cls, const float* pos, int n, int tokens, int dim, void* x, float* partial,
+int launch_cls_stream(int dtype, const float* prefix, int prefix_rows, int n, int tokens, int dim, void* x, float* partial,
                       hipStream_t stream) {
-    AP_REQUIRE(dim % 64 == 0, "cls_stream: dim %d must be a multiple of 64", dim);
+    AP_REQUIRE(dim % 64 == 0 && prefix_rows > 0, "cls_stream: dim %d must be a multiple of 64", dim);
     if (n <= 0) return AP_OK;
-    dim3 grid(n, dim / 64), block(64);
-    if (dtype == AP_F16) cls_stream_kernel<f16><<<grid, block, 0, stream>>>(cls, pos, tokens, dim, (f16*)x, partial);
-    else if (dtype == AP_BF16) cls_stream_kernel<bf16><<<grid, block, 0, stream>>>(cls, pos, tokens, dim, (bf16*)x, partial);
+    dim3 grid(n * prefix_rows, dim / 64), block(64);
+    if (dtype == AP_F16) cls_stream_kernel<f16><<<grid, block, 0, stream>>>(prefix, prefix_rows, tokens, dim, (f16*)x, partial);
+    else if (dtype == AP_BF16) cls_stream_kernel<bf16><<<grid, block, 0, stream>>>(prefix, prefix_rows, tokens, dim, (bf16*)x, partial);
     else { set_error("cls_stream: dtype %d (f16 / bf16 only)", dtype); return AP_ERR_INVALID; }
     AP_HIP_CHECK(hipGetLastError());
     return AP_OK;
@@ -632,11 +679,31 @@ int launch_fold_ls(int dtype, const float* w32, int rows, int cols, int ld, cons
     return AP_OK;
 }
 
-int launch_cls_init(float* tok, const float* cls, const float* pos, int n, int tokens, int dim,
-                    hipStream_t stream) {
+int launch_cls_init(float* tok, const float* prefix, int prefix_rows, int n, int tokens, int dim, hipStream_t stream) {
     if (n <= 0) return AP_OK;
-    const int total = n * dim;
-    cls_init_kernel<<<(total + 255) / 256, 256, 0, stream>>>(tok, cls, pos, n, tokens, dim);
+    const int total = n * prefix_rows * dim;
+    cls_init_kernel<<<(total + 255) / 256, 256, 0, stream>>>(tok, prefix, prefix_rows, n, tokens, dim);
+    AP_HIP_CHECK(hipGetLastError());
+    return AP_OK;
+}
+
+int launch_prefix_build(const float* cls, const float* reg, int reg_rows, const float* pos, int dim, float* prefix, hipStream_t stream) {
+    AP_REQUIRE(cls && prefix && (reg || reg_rows == 0), "prefix_build: null pointer");
+    const int total = (1 + reg_rows) * dim;
+    prefix_build_kernel<<<(total + 255) / 256, 256, 0, stream>>>(cls, reg, reg_rows, pos, dim, prefix);
+    AP_HIP_CHECK(hipGetLastError());
+    return AP_OK;
+}
+
+int launch_swiglu(int dtype, const void* x, int rows, int h, void* out, hipStream_t stream) {
+    AP_REQUIRE(x && out && h > 0 && h % 8 == 0, "swiglu: bad arguments (h %d)", h);
+    if (rows <= 0) return AP_OK;
+    const size_t total = dtype == AP_F32 ? (size_t)rows * h : (size_t)rows * (h >> 3);
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (dtype == AP_F16) swiglu_kernel<f16><<<blocks, 256, 0, stream>>>((const f16*)x, rows, h, (f16*)out);
+    else if (dtype == AP_BF16) swiglu_kernel<bf16><<<blocks, 256, 0, stream>>>((const bf16*)x, rows, h, (bf16*)out);
+    else if (dtype == AP_F32) swiglu_f32_kernel<<<blocks, 256, 0, stream>>>((const float*)x, rows, h, (float*)out);
+    else { set_error("swiglu: dtype %d", dtype); return AP_ERR_INVALID; }
     AP_HIP_CHECK(hipGetLastError());
     return AP_OK;
 }
@@ -658,6 +725,18 @@ template <typename TI>
 static int chw_rows_typed(int dtype, const TI* x, int n, int S, int ps, void* dst, int ld,
                           hipStream_t stream) {
     const int g = S / ps;
+    if (ps % 4 != 0) {
+        const size_t total_any = (size_t)n * 3 * S * S;
+        const unsigned blocks_any = (unsigned)((total_any + 255) / 256);
+        switch (dtype) {
+            case AP_F16: chw_to_patchrows_any_kernel<TI, f16><<<blocks_any, 256, 0, stream>>>(x, n, S, ps, (f16*)dst, ld); break;
+            case AP_BF16: chw_to_patchrows_any_kernel<TI, bf16><<<blocks_any, 256, 0, stream>>>(x, n, S, ps, (bf16*)dst, ld); break;
+            case AP_F32: chw_to_patchrows_any_kernel<TI, float><<<blocks_any, 256, 0, stream>>>(x, n, S, ps, (float*)dst, ld); break;
+            default: set_error("chw_to_patchrows: unknown dtype %d", dtype); return AP_ERR_INVALID;
+        }
+        AP_HIP_CHECK(hipGetLastError());
+        return AP_OK;
+    }
     const size_t total = (size_t)n * 3 * S * g * (ps >> 2);
     const unsigned blocks = (unsigned)((total + 255) / 256);
     switch (dtype) {
@@ -672,7 +751,7 @@ static int chw_rows_typed(int dtype, const TI* x, int n, int S, int ps, void* ds
 
 int launch_chw_to_patchrows(int x_dtype, int dtype, const void* x, int n, int S, int ps, void* dst,
                             int ld, hipStream_t stream) {
-    AP_REQUIRE(S % ps == 0 && ps % 4 == 0, "chw_to_patchrows: image %d / patch %d unsupported", S, ps);
+    AP_REQUIRE(S % ps == 0, "chw_to_patchrows: image %d / patch %d unsupported", S, ps);
     if (n <= 0) return AP_OK;
     switch (x_dtype) {
         case AP_F32: return chw_rows_typed<float>(dtype, (const float*)x, n, S, ps, dst, ld, stream);

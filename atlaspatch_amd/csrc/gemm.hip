@@ -268,10 +268,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
             if (!live) m = g.M - 1;                              // every lane takes part in the lane exchanges
             size_t orow = (size_t)m;                             // output (stream) row
             const T* srow = (const T*)g.out + (size_t)m * (size_t)g.ldo;        // where the "residual" comes from
-            if constexpr (kPatch) {                              // patch row m = img * P + p -> stream row img * (P + 1) + 1 + p
+            if constexpr (kPatch) {                              // patch row m = img * P + p -> stream row img * (P + R) + R + p
                 const int img = m / g.P, p = m - img * g.P;
-                orow = (size_t)m + img + 1;
-                srow = (const T*)g.pos16 + (size_t)(1 + p) * g.N;
+                orow = (size_t)m + (size_t)(img + 1) * g.R;
+                srow = (const T*)g.pos16 + (size_t)(g.pos_row0 + p) * g.N;
             }
             float cs8[8], cq8[8];
 #pragma unroll
@@ -311,8 +311,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
         const float* posrow = nullptr;
         if constexpr (EPI == EPI_PATCH_EMBED) {
             const int img = m / g.P, p = m - img * g.P;
-            orow = ((size_t)img * (g.P + 1) + 1 + p) * (size_t)g.ldo;
-            posrow = g.pos + (size_t)(1 + p) * g.N;
+            orow = ((size_t)img * (g.P + g.R) + g.R + p) * (size_t)g.ldo;
+            posrow = g.pos + (size_t)(g.pos_row0 + p) * g.N;
         } else {
             orow = (size_t)m * (size_t)g.ldo;
         }
@@ -402,7 +402,7 @@ int launch_gemm_impl(int dtype, int epilogue, const GemmArgs& a, int impl, int v
                            epilogue == EPI_PATCH_STREAM;
     AP_REQUIRE(!fused_epi || dtype != AP_F32, "gemm: the fused-LayerNorm epilogues are f16 / bf16 only");
     AP_REQUIRE(!fused_epi || (epilogue == EPI_RESID_STATS ? a.partial != nullptr :
-                              epilogue == EPI_PATCH_STREAM ? (a.partial && a.pos16 && a.P > 0) : (a.colsum && a.rowstats)),
+                              epilogue == EPI_PATCH_STREAM ? (a.partial && a.pos16 && a.P > 0 && a.R > 0) : (a.colsum && a.rowstats)),
                "gemm: missing operand for the fused-LayerNorm epilogue %d", epilogue);
     // Kernel choice (results are bit-identical either way).  The persistent 256 x 256 kernel needs about one tile per CU to
     // pay: with few row tiles and a narrow N (proj / fc2 of a 32-tile extract_batch: 75 tiles for 256 CUs) the 128 x 128

@@ -449,7 +449,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
                     int q = (int)((float)m * inv_p);                 // m / P for m < 2^24 (float estimate, corrected)
                     int p = m - q * g.P;
                     p = p < 0 ? p + g.P : (p >= g.P ? p - g.P : p);
-                    res[j] = *(const u32x4*)((const T*)g.pos16 + (size_t)(1 + p) * g.N + n0 + rc * 8);
+                    res[j] = *(const u32x4*)((const T*)g.pos16 + (size_t)(g.pos_row0 + p) * g.N + n0 + rc * 8);
                 } else {
                     res[j] = *(const u32x4*)((const T*)g.out + (size_t)m * g.ldo + n0 + rc * 8);
                 }
@@ -565,11 +565,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
                     u32x4 v = *(const u32x4*)(scr + row * 128 + ((rc ^ (row & 7)) << 4));
                     const int m = m0 + mb * 32 + row;
                     size_t orow = (size_t)m;
-                    if constexpr (kPatch) {                          // patch row -> stream row img * (P + 1) + 1 + p
+                    if constexpr (kPatch) {                          // patch row -> stream row img * (P + R) + R + p
                         int q = (int)((float)m * inv_p);
                         const int p = m - q * g.P;
                         q = p < 0 ? q - 1 : (p >= g.P ? q + 1 : q);
-                        orow = (size_t)m + q + 1;
+                        orow = (size_t)m + (size_t)(q + 1) * g.R;
                     }
                     if constexpr (kRes) {
                         float s = 0.f, q = 0.f;
@@ -637,7 +637,7 @@ bool AP_G256_FN(gemm256_supports)(int dtype, int epilogue, const GemmArgs& a) {
     if (epilogue != EPI_BIAS_STORE && epilogue != EPI_BIAS_GELU && epilogue != EPI_BIAS_RESID &&
         epilogue != EPI_NORM_STORE && epilogue != EPI_NORM_GELU && epilogue != EPI_RESID_STATS && epilogue != EPI_PATCH_STREAM)
         return false;
-    if (epilogue == EPI_PATCH_STREAM && (!a.partial || !a.pos16 || a.P <= 0 || a.M >= (1 << 24))) return false;
+    if (epilogue == EPI_PATCH_STREAM && (!a.partial || !a.pos16 || a.P <= 0 || a.R <= 0 || a.M >= (1 << 24))) return false;
     if ((epilogue == EPI_NORM_STORE || epilogue == EPI_NORM_GELU) && (!a.colsum || !a.rowstats)) return false;
     if (epilogue == EPI_RESID_STATS && !a.partial) return false;
     if (a.N % kBN != 0 || a.K % 128 != 0 || a.K < 128) return false;

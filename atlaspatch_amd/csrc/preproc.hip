@@ -23,7 +23,7 @@
 namespace ap {
 namespace {
 
-constexpr int kMaxBand = 16;
+constexpr int kMaxBand = 32;
 
 enum Layout { LAYOUT_CHW = 0, LAYOUT_PATCHROWS = 1 };
 
@@ -98,6 +98,23 @@ __global__ __launch_bounds__(256) void preproc_kernel(PreArgs a) {
         const int gw = a.ow / a.ps, gh = a.oh / a.ps, halves = a.ps >> 3;
         const int per_px = a.ps * halves;
         const int py = bnd;
+        if (a.ps & 7) {
+            // patch sizes that are not multiples of 8 (14: vit_h_14, uni_v2): one task per (patch, row, channel, pixel pair);
+            // consecutive lanes write consecutive pairs of one (patch, channel) plane.  K1 is < 0.5 % of a forward: the
+            // 4-byte stores are good enough
+            const int pairs = a.ps >> 1, per_patch = a.ps * 3 * pairs;
+            for (int t = tid; t < gw * per_patch; t += 256) {
+                const int px = t / per_patch, rem = t - px * per_patch;
+                const int c = rem / (a.ps * pairs), rem2 = rem - c * (a.ps * pairs);
+                const int ky = rem2 / pairs, kx = (rem2 - ky * pairs) * 2;
+                if (ky >= nrows) continue;
+                const uint8_t* p = rows + ky * rowStride + (px * a.ps + kx) * 3 + c;
+                T* d = (T*)a.dst + ((size_t)(img * gh + py) * gw + px) * (size_t)a.ld + (c * a.ps + ky) * a.ps + kx;
+                d[0] = lut[c * 256 + p[0]];
+                d[1] = lut[c * 256 + p[3]];
+            }
+            return;
+        }
         for (int t = tid; t < gw * per_px; t += 256) {
             const int px = t / per_px, rem = t - px * per_px;
             const int ky = rem / halves, hf = rem - ky * halves;
@@ -202,15 +219,16 @@ int preproc_common(int layout, const uint8_t* src, int n, int h, int w, int top,
     AP_REQUIRE(n >= 0 && h > 0 && w > 0 && oh > 0 && ow > 0, "preproc: bad shape");
     AP_REQUIRE(top >= 0 && left >= 0 && top + oh <= h && left + ow <= w,
                "preproc: crop window %d,%d+%dx%d outside %dx%d", top, left, oh, ow, h, w);
-    AP_REQUIRE(ow % 8 == 0, "preproc: output width %d must be a multiple of 8", ow);
+    AP_REQUIRE(ow % 8 == 0 || (layout == LAYOUT_PATCHROWS && (ps & 7) != 0),
+               "preproc: output width %d must be a multiple of 8", ow);
     AP_REQUIRE(ow * 3 <= 16384, "preproc: output width %d too large", ow);
     if (n == 0) return AP_OK;
     PreArgs a;
     a.src = src; a.n = n; a.h = h; a.w = w; a.top = top; a.left = left; a.oh = oh; a.ow = ow;
     a.dst = dst; a.ps = ps; a.ld = ld;
     if (layout == LAYOUT_PATCHROWS) {
-        AP_REQUIRE(ps > 0 && ps % 8 == 0 && ps <= kMaxBand && oh % ps == 0 && ow % ps == 0,
-                   "preproc: patch size %d unsupported for %dx%d", ps, oh, ow);
+        AP_REQUIRE(ps > 0 && ps % 2 == 0 && ps <= kMaxBand && oh % ps == 0 && ow % ps == 0,
+                   "preproc: patch size %d unsupported for %dx%d (even, <= 32, dividing the crop)", ps, oh, ow);
         AP_REQUIRE(ld >= 3 * ps * ps && (ld * dtype_size(dtype)) % 16 == 0, "preproc: bad row length %d", ld);
         a.band = ps;
     } else {

@@ -10,6 +10,7 @@
 //   delta, delta2 T [M, D] branch outputs (fc2 / proj) waiting to be folded into tok by a LayerNorm launch
 //   hid   T   [M, mlp]    GELU(fc1) ; the patch-row matrix [n*P, Kpe] aliases it
 // Weights are converted once to T, K-contiguous ([out, in], exactly the checkpoint layout).
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <string>
@@ -51,6 +52,12 @@ struct PoolParams {
 struct ap_vit {
     ap_vit_config cfg;
     int grid = 0, patches = 0, tokens = 0, kpe = 0;
+    int prefix = 1;                         // class token + register tokens
+    int pos_rows = 0, pos_row0 = 1;         // rows of pos_embed; the row that belongs to patch 0
+    int hd = 64, dattn = 0;                 // head width as stored (64 / 128), heads * hd = width of q, k, v and of proj's input
+    int fc1_rows = 0;                       // mlp_dim (GELU) or 2 * mlp_dim (SwiGLU packed)
+    float attn_scale = 0.125f;
+    float* prefix_dev = nullptr;            // f32 [prefix, dim]: class / register tokens (+ their position rows), built at finalize
     std::map<std::string, ap::Param> params;
     bool finalized = false;
     // resolved at finalize
@@ -120,7 +127,7 @@ const Param* find(const ap_vit* m, const std::string& name) {
 }
 
 struct Workspace {
-    float* tok; void* xn; void* qkv; void* att; void* hid; void* delta; void* delta2;
+    float* tok; void* xn; void* qkv; void* att; void* hid; void* hid2; void* delta; void* delta2;
     void* x16; float* rowstats; float* partial;      // fused-LayerNorm path: T stream [M, D], f32 [M, 2], f32 [M, D / 64, 2]
     size_t total;
 };
@@ -133,11 +140,12 @@ Workspace carve(const ap_vit* m, int n, char* base) {
     Workspace w;
     const size_t o_tok = take(M * D * 4);
     const size_t o_xn = take(M * D * es);
-    const size_t o_qkv = take(M * 3 * D * es);
-    const size_t o_att = take(M * D * es);
+    const size_t o_qkv = take(M * 3 * (size_t)m->dattn * es);
+    const size_t o_att = take(M * (size_t)m->dattn * es);
     const size_t o_delta = take(M * D * es);
     const size_t o_delta2 = take(M * D * es);
-    size_t hid_bytes = M * (size_t)m->cfg.mlp_dim * es;
+    // SwiGLU: fc1 output [M, 2 mlp] followed by the gated product [M, mlp] (ws.hid2)
+    size_t hid_bytes = M * (size_t)(m->cfg.mlp_type == AP_MLP_SWIGLU ? 3 * m->cfg.mlp_dim : m->cfg.mlp_dim) * es;
     const size_t pe_bytes = (size_t)n * m->patches * m->kpe * es;
     if (pe_bytes > hid_bytes) hid_bytes = pe_bytes;
     const size_t o_hid = take(hid_bytes);
@@ -150,6 +158,7 @@ Workspace carve(const ap_vit* m, int n, char* base) {
     w.partial = has_fused ? (float*)(base + o_part) : nullptr;
     w.tok = (float*)(base + o_tok); w.xn = base + o_xn; w.qkv = base + o_qkv;
     w.att = base + o_att; w.hid = base + o_hid; w.delta = base + o_delta; w.delta2 = base + o_delta2; w.total = off;
+    w.hid2 = m->cfg.mlp_type == AP_MLP_SWIGLU ? (char*)w.hid + M * (size_t)(2 * m->cfg.mlp_dim) * es : w.hid;
     return w;
 }
 
@@ -171,10 +180,10 @@ int patch_embed(ap_vit* m, int n, const Workspace& w, hipStream_t stream) {
         g.M = n * m->patches; g.N = D; g.K = m->kpe;
         g.bias = m->pe_b;
         g.pos = m->pos;
-        g.out = w.tok; g.ldo = D; g.P = m->patches;
+        g.out = w.tok; g.ldo = D; g.P = m->patches; g.R = m->prefix; g.pos_row0 = m->pos_row0;
         { ScopedTimer t(m, AP_PROF_GEMM_PATCH_EMBED, stream);
           if ((rc = ap::launch_gemm(dt, ap::EPI_PATCH_EMBED, g, stream)) != AP_OK) return rc; }
-        if ((rc = ap::launch_cls_init(w.tok, m->cls, m->pos, n, m->tokens, D, stream)) != AP_OK) return rc;
+        if ((rc = ap::launch_cls_init(w.tok, m->prefix_dev, m->prefix, n, m->tokens, D, stream)) != AP_OK) return rc;
     }
     return AP_OK;
 }
@@ -188,12 +197,12 @@ int patch_embed_stream(ap_vit* m, int n, const Workspace& w, hipStream_t stream)
     ap::GemmArgs g{};
     g.A = w.hid; g.lda = m->kpe; g.W = m->pe_w->dev; g.ldw = m->pe_w->ld;
     g.M = n * m->patches; g.N = D; g.K = m->kpe;
-    g.bias = m->pe_b; g.pos16 = m->pos16; g.P = m->patches;
+    g.bias = m->pe_b; g.pos16 = m->pos16; g.P = m->patches; g.R = m->prefix; g.pos_row0 = m->pos_row0;
     g.out = w.x16; g.ldo = D; g.partial = w.partial;
     { ScopedTimer t(m, AP_PROF_GEMM_PATCH_EMBED, stream);
       if ((rc = ap::launch_gemm(dt, ap::EPI_PATCH_STREAM, g, stream)) != AP_OK) return rc; }
     ScopedTimer t(m, AP_PROF_LAYERNORM, stream);
-    if ((rc = ap::launch_cls_stream(dt, m->cls, m->pos, n, m->tokens, D, w.x16, w.partial, stream)) != AP_OK) return rc;
+    if ((rc = ap::launch_cls_stream(dt, m->prefix_dev, m->prefix, n, m->tokens, D, w.x16, w.partial, stream)) != AP_OK) return rc;
     return ap::launch_rowstats_finalize(w.partial, n * m->tokens, D / 64, D, c.ln_eps, w.rowstats, stream);
 }
 
@@ -201,6 +210,8 @@ int patch_embed_stream(ap_vit* m, int n, const Workspace& w, hipStream_t stream)
 int blocks_f32_stream(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipStream_t stream) {
     const ap_vit_config& c = m->cfg;
     const int dt = c.compute_dtype, D = c.dim, M = n * m->tokens;
+    const int DA = m->dattn, H = c.mlp_dim, F1 = m->fc1_rows;
+    const bool swiglu = c.mlp_type == AP_MLP_SWIGLU;
     int rc;
     // Residual stream: tok (f32) is only ever touched by the add+LayerNorm kernel.  A branch GEMM
     // (proj, fc2) stores its output delta = acc + bias in T; LayerNorm launches fold it into the
@@ -210,7 +221,7 @@ int blocks_f32_stream(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipS
     const void* pending = nullptr;       // branch output not yet added to tok
     long pending_stride = D;             // its row stride as seen from the final CLS LayerNorm
     // AP_VIT_OPT_FULL_LAST_BLOCK computes the last block for every token (A/B of the CLS-only tail; same features)
-    const bool cls_tail = c.pool == AP_POOL_CLS && !m->full_last_block && D / c.heads == 64;
+    const bool cls_tail = c.pool == AP_POOL_CLS && !m->full_last_block;
     const float* pending_ls = nullptr;   // ... and its LayerScale vector (applied in f32 by the add)
     for (int i = 0; i < c.depth; ++i) {
         const ap::BlockParams& bp = m->blocks[i];
@@ -225,13 +236,13 @@ int blocks_f32_stream(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipS
             const size_t es = ap::dtype_size(dt);
             const Param* wq = bp.qkv;
             const long cls_stride = (long)m->tokens * D;
-            char* q_cls = (char*)w.att;                                   // T [n, D]
-            char* a_cls = (char*)w.att + (size_t)n * D * es;              // T [n, D]
+            char* q_cls = (char*)w.att;                                   // T [n, DA]
+            char* a_cls = (char*)w.att + (size_t)n * DA * es;             // T [n, DA]
             {
                 ap::GemmArgs g{};                                          // k | v for all rows
-                g.A = w.xn; g.lda = D; g.W = (const char*)wq->dev + (size_t)D * wq->ld * es; g.ldw = wq->ld;
-                g.M = M; g.N = 2 * D; g.K = D; g.bias = bp.qkv_b + D;
-                g.out = (char*)w.qkv + (size_t)D * es; g.ldo = 3 * D;
+                g.A = w.xn; g.lda = D; g.W = (const char*)wq->dev + (size_t)DA * wq->ld * es; g.ldw = wq->ld;
+                g.M = M; g.N = 2 * DA; g.K = D; g.bias = bp.qkv_b + DA;
+                g.out = (char*)w.qkv + (size_t)DA * es; g.ldo = 3 * DA;
                 ScopedTimer t(m, AP_PROF_GEMM_QKV, stream);
                 if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_STORE, g, stream)) != AP_OK) return rc;
             }
@@ -240,15 +251,15 @@ int blocks_f32_stream(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipS
             {
                 ap::GemmArgs g{};                                          // q for the CLS rows
                 g.A = w.xn; g.lda = (int)cls_stride; g.W = wq->dev; g.ldw = wq->ld;
-                g.M = n; g.N = D; g.K = D; g.bias = bp.qkv_b; g.out = q_cls; g.ldo = D;
+                g.M = n; g.N = DA; g.K = D; g.bias = bp.qkv_b; g.out = q_cls; g.ldo = DA;
                 if ((rc = ap::launch_gemm_impl(dt, ap::EPI_BIAS_STORE, g, 128, 0, stream)) != AP_OK) return rc;
             }
-            if ((rc = ap::launch_attention_cls(dt, q_cls, w.qkv, 3 * D, D, 2 * D, a_cls, n, m->tokens, c.heads,
-                                               D / c.heads, stream)) != AP_OK) return rc;
+            if ((rc = ap::launch_attention_cls(dt, q_cls, w.qkv, 3 * DA, DA, 2 * DA, a_cls, n, m->tokens, c.heads,
+                                               m->hd, m->attn_scale, stream)) != AP_OK) return rc;
             {
                 ap::GemmArgs g{};
-                g.A = a_cls; g.lda = D; g.W = bp.proj->dev; g.ldw = bp.proj->ld;
-                g.M = n; g.N = D; g.K = D; g.bias = bp.proj_b; g.out = w.delta2; g.ldo = D;
+                g.A = a_cls; g.lda = DA; g.W = bp.proj->dev; g.ldw = bp.proj->ld;
+                g.M = n; g.N = D; g.K = DA; g.bias = bp.proj_b; g.out = w.delta2; g.ldo = D;
                 if ((rc = ap::launch_gemm_impl(dt, ap::EPI_BIAS_STORE, g, 128, 0, stream)) != AP_OK) return rc;
             }
             if ((rc = ap::launch_add2_layernorm(dt, dt, w.tok, cls_stride, pending, cls_stride, pending_ls, w.delta2, D,
@@ -258,13 +269,14 @@ int blocks_f32_stream(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipS
             {
                 ap::GemmArgs g{};
                 g.A = w.xn; g.lda = D; g.W = bp.fc1->dev; g.ldw = bp.fc1->ld;
-                g.M = n; g.N = c.mlp_dim; g.K = D; g.bias = bp.fc1_b; g.out = w.hid; g.ldo = c.mlp_dim;
-                if ((rc = ap::launch_gemm_impl(dt, ap::EPI_BIAS_GELU, g, 128, 0, stream)) != AP_OK) return rc;
+                g.M = n; g.N = F1; g.K = D; g.bias = bp.fc1_b; g.out = w.hid; g.ldo = F1;
+                if ((rc = ap::launch_gemm_impl(dt, swiglu ? ap::EPI_BIAS_STORE : ap::EPI_BIAS_GELU, g, 128, 0, stream)) != AP_OK) return rc;
+                if (swiglu && (rc = ap::launch_swiglu(dt, w.hid, n, H, w.hid2, stream)) != AP_OK) return rc;
             }
             {
                 ap::GemmArgs g{};
-                g.A = w.hid; g.lda = c.mlp_dim; g.W = bp.fc2->dev; g.ldw = bp.fc2->ld;
-                g.M = n; g.N = D; g.K = c.mlp_dim; g.bias = bp.fc2_b; g.out = w.delta; g.ldo = D;
+                g.A = w.hid2; g.lda = H; g.W = bp.fc2->dev; g.ldw = bp.fc2->ld;
+                g.M = n; g.N = D; g.K = H; g.bias = bp.fc2_b; g.out = w.delta; g.ldo = D;
                 if ((rc = ap::launch_gemm_impl(dt, ap::EPI_BIAS_STORE, g, 128, 0, stream)) != AP_OK) return rc;
             }
             pending = w.delta;
@@ -275,17 +287,17 @@ int blocks_f32_stream(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipS
         {
             ap::GemmArgs g{};
             g.A = w.xn; g.lda = D; g.W = bp.qkv->dev; g.ldw = bp.qkv->ld;
-            g.M = M; g.N = 3 * D; g.K = D; g.bias = bp.qkv_b; g.out = w.qkv; g.ldo = 3 * D;
+            g.M = M; g.N = 3 * DA; g.K = D; g.bias = bp.qkv_b; g.out = w.qkv; g.ldo = 3 * DA;
             ScopedTimer t(m, AP_PROF_GEMM_QKV, stream);
             if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_STORE, g, stream)) != AP_OK) return rc;
         }
         { ScopedTimer t(m, AP_PROF_ATTENTION, stream);
-          if ((rc = ap::launch_attention(dt, w.qkv, w.att, n, m->tokens, c.heads, D / c.heads,
+          if ((rc = ap::launch_attention(dt, w.qkv, w.att, n, m->tokens, c.heads, m->hd, m->attn_scale,
                                          stream)) != AP_OK) return rc; }
         {
             ap::GemmArgs g{};
-            g.A = w.att; g.lda = D; g.W = bp.proj->dev; g.ldw = bp.proj->ld;
-            g.M = M; g.N = D; g.K = D; g.bias = bp.proj_b;
+            g.A = w.att; g.lda = DA; g.W = bp.proj->dev; g.ldw = bp.proj->ld;
+            g.M = M; g.N = D; g.K = DA; g.bias = bp.proj_b;
             g.out = w.delta2; g.ldo = D;
             ScopedTimer t(m, AP_PROF_GEMM_PROJ, stream);
             if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_STORE, g, stream)) != AP_OK) return rc;
@@ -297,14 +309,15 @@ int blocks_f32_stream(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipS
         {
             ap::GemmArgs g{};
             g.A = w.xn; g.lda = D; g.W = bp.fc1->dev; g.ldw = bp.fc1->ld;
-            g.M = M; g.N = c.mlp_dim; g.K = D; g.bias = bp.fc1_b; g.out = w.hid; g.ldo = c.mlp_dim;
+            g.M = M; g.N = F1; g.K = D; g.bias = bp.fc1_b; g.out = w.hid; g.ldo = F1;
             ScopedTimer t(m, AP_PROF_GEMM_FC1, stream);
-            if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_GELU, g, stream)) != AP_OK) return rc;
+            if ((rc = ap::launch_gemm(dt, swiglu ? ap::EPI_BIAS_STORE : ap::EPI_BIAS_GELU, g, stream)) != AP_OK) return rc;
+            if (swiglu && (rc = ap::launch_swiglu(dt, w.hid, M, H, w.hid2, stream)) != AP_OK) return rc;
         }
         {
             ap::GemmArgs g{};
-            g.A = w.hid; g.lda = c.mlp_dim; g.W = bp.fc2->dev; g.ldw = bp.fc2->ld;
-            g.M = M; g.N = D; g.K = c.mlp_dim; g.bias = bp.fc2_b;
+            g.A = w.hid2; g.lda = H; g.W = bp.fc2->dev; g.ldw = bp.fc2->ld;
+            g.M = M; g.N = D; g.K = H; g.bias = bp.fc2_b;
             g.out = w.delta; g.ldo = D;
             ScopedTimer t(m, AP_PROF_GEMM_FC2, stream);
             if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_STORE, g, stream)) != AP_OK) return rc;
@@ -326,9 +339,11 @@ int blocks_f32_stream(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipS
 int blocks_fused(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipStream_t stream) {
     const ap_vit_config& c = m->cfg;
     const int dt = c.compute_dtype, D = c.dim, M = n * m->tokens, G = D / 64;
+    const int DA = m->dattn, H = c.mlp_dim, F1 = m->fc1_rows;
+    const bool swiglu = c.mlp_type == AP_MLP_SWIGLU;
     const size_t es = ap::dtype_size(dt);
     int rc;
-    const bool cls_tail = c.pool == AP_POOL_CLS && !m->full_last_block && D / c.heads == 64;
+    const bool cls_tail = c.pool == AP_POOL_CLS && !m->full_last_block;
     auto finalize_stats = [&]() -> int {
         ScopedTimer t(m, AP_PROF_LAYERNORM, stream);
         return ap::launch_rowstats_finalize(w.partial, M, G, D, c.ln_eps, w.rowstats, stream);
@@ -342,9 +357,9 @@ int blocks_fused(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipStream
             // weights on the 128x128 kernel).
             {
                 ap::GemmArgs g{};
-                g.A = w.x16; g.lda = D; g.W = (const char*)fb.qkv_w + (size_t)D * bp.qkv->ld * es; g.ldw = bp.qkv->ld;
-                g.M = M; g.N = 2 * D; g.K = D; g.bias = fb.qkv_b + D; g.colsum = fb.qkv_cs + D; g.rowstats = w.rowstats;
-                g.out = (char*)w.qkv + (size_t)D * es; g.ldo = 3 * D;
+                g.A = w.x16; g.lda = D; g.W = (const char*)fb.qkv_w + (size_t)DA * bp.qkv->ld * es; g.ldw = bp.qkv->ld;
+                g.M = M; g.N = 2 * DA; g.K = D; g.bias = fb.qkv_b + DA; g.colsum = fb.qkv_cs + DA; g.rowstats = w.rowstats;
+                g.out = (char*)w.qkv + (size_t)DA * es; g.ldo = 3 * DA;
                 ScopedTimer t(m, AP_PROF_GEMM_QKV, stream);
                 if ((rc = ap::launch_gemm(dt, ap::EPI_NORM_STORE, g, stream)) != AP_OK) return rc;
             }
@@ -352,20 +367,20 @@ int blocks_fused(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipStream
             if ((rc = ap::launch_stream_to_f32(dt, w.x16, (long)m->tokens * D, n, D, w.tok, stream)) != AP_OK) return rc;
             if ((rc = ap::launch_add2_layernorm(dt, dt, w.tok, D, nullptr, 0, nullptr, nullptr, 0, nullptr, /*store=*/0,
                                                 n, D, bp.ln1_w, bp.ln1_b, c.ln_eps, w.xn, stream)) != AP_OK) return rc;
-            char* q_cls = (char*)w.att;                                   // T [n, D]
-            char* a_cls = (char*)w.att + (size_t)n * D * es;              // T [n, D]
+            char* q_cls = (char*)w.att;                                   // T [n, DA]
+            char* a_cls = (char*)w.att + (size_t)n * DA * es;             // T [n, DA]
             {
                 ap::GemmArgs g{};                                          // q for the CLS rows
                 g.A = w.xn; g.lda = D; g.W = bp.qkv->dev; g.ldw = bp.qkv->ld;
-                g.M = n; g.N = D; g.K = D; g.bias = bp.qkv_b; g.out = q_cls; g.ldo = D;
+                g.M = n; g.N = DA; g.K = D; g.bias = bp.qkv_b; g.out = q_cls; g.ldo = DA;
                 if ((rc = ap::launch_gemm_impl(dt, ap::EPI_BIAS_STORE, g, 128, 0, stream)) != AP_OK) return rc;
             }
-            if ((rc = ap::launch_attention_cls(dt, q_cls, w.qkv, 3 * D, D, 2 * D, a_cls, n, m->tokens, c.heads,
-                                               D / c.heads, stream)) != AP_OK) return rc;
+            if ((rc = ap::launch_attention_cls(dt, q_cls, w.qkv, 3 * DA, DA, 2 * DA, a_cls, n, m->tokens, c.heads,
+                                               m->hd, m->attn_scale, stream)) != AP_OK) return rc;
             {
                 ap::GemmArgs g{};
-                g.A = a_cls; g.lda = D; g.W = bp.proj->dev; g.ldw = bp.proj->ld;
-                g.M = n; g.N = D; g.K = D; g.bias = bp.proj_b; g.out = w.delta2; g.ldo = D;
+                g.A = a_cls; g.lda = DA; g.W = bp.proj->dev; g.ldw = bp.proj->ld;
+                g.M = n; g.N = D; g.K = DA; g.bias = bp.proj_b; g.out = w.delta2; g.ldo = D;
                 if ((rc = ap::launch_gemm_impl(dt, ap::EPI_BIAS_STORE, g, 128, 0, stream)) != AP_OK) return rc;
             }
             if ((rc = ap::launch_add2_layernorm(dt, dt, w.tok, D, nullptr, 0, nullptr, w.delta2, D, bp.ls1, /*store=*/1, n, D,
@@ -373,13 +388,14 @@ int blocks_fused(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipStream
             {
                 ap::GemmArgs g{};
                 g.A = w.xn; g.lda = D; g.W = bp.fc1->dev; g.ldw = bp.fc1->ld;
-                g.M = n; g.N = c.mlp_dim; g.K = D; g.bias = bp.fc1_b; g.out = w.hid; g.ldo = c.mlp_dim;
-                if ((rc = ap::launch_gemm_impl(dt, ap::EPI_BIAS_GELU, g, 128, 0, stream)) != AP_OK) return rc;
+                g.M = n; g.N = F1; g.K = D; g.bias = bp.fc1_b; g.out = w.hid; g.ldo = F1;
+                if ((rc = ap::launch_gemm_impl(dt, swiglu ? ap::EPI_BIAS_STORE : ap::EPI_BIAS_GELU, g, 128, 0, stream)) != AP_OK) return rc;
+                if (swiglu && (rc = ap::launch_swiglu(dt, w.hid, n, H, w.hid2, stream)) != AP_OK) return rc;
             }
             {
                 ap::GemmArgs g{};
-                g.A = w.hid; g.lda = c.mlp_dim; g.W = bp.fc2->dev; g.ldw = bp.fc2->ld;
-                g.M = n; g.N = D; g.K = c.mlp_dim; g.bias = bp.fc2_b; g.out = w.delta; g.ldo = D;
+                g.A = w.hid2; g.lda = H; g.W = bp.fc2->dev; g.ldw = bp.fc2->ld;
+                g.M = n; g.N = D; g.K = H; g.bias = bp.fc2_b; g.out = w.delta; g.ldo = D;
                 if ((rc = ap::launch_gemm_impl(dt, ap::EPI_BIAS_STORE, g, 128, 0, stream)) != AP_OK) return rc;
             }
             st.pending = w.delta; st.pending_ls = bp.ls2; st.pending_stride = D; st.tok_stride = D;
@@ -388,17 +404,17 @@ int blocks_fused(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipStream
         {
             ap::GemmArgs g{};
             g.A = w.x16; g.lda = D; g.W = fb.qkv_w; g.ldw = bp.qkv->ld;
-            g.M = M; g.N = 3 * D; g.K = D; g.bias = fb.qkv_b; g.colsum = fb.qkv_cs; g.rowstats = w.rowstats;
-            g.out = w.qkv; g.ldo = 3 * D;
+            g.M = M; g.N = 3 * DA; g.K = D; g.bias = fb.qkv_b; g.colsum = fb.qkv_cs; g.rowstats = w.rowstats;
+            g.out = w.qkv; g.ldo = 3 * DA;
             ScopedTimer t(m, AP_PROF_GEMM_QKV, stream);
             if ((rc = ap::launch_gemm(dt, ap::EPI_NORM_STORE, g, stream)) != AP_OK) return rc;
         }
         { ScopedTimer t(m, AP_PROF_ATTENTION, stream);
-          if ((rc = ap::launch_attention(dt, w.qkv, w.att, n, m->tokens, c.heads, D / c.heads, stream)) != AP_OK) return rc; }
+          if ((rc = ap::launch_attention(dt, w.qkv, w.att, n, m->tokens, c.heads, m->hd, m->attn_scale, stream)) != AP_OK) return rc; }
         {
             ap::GemmArgs g{};
-            g.A = w.att; g.lda = D; g.W = fb.proj_w; g.ldw = bp.proj->ld;
-            g.M = M; g.N = D; g.K = D; g.bias = fb.proj_b; g.out = w.x16; g.ldo = D; g.partial = w.partial;
+            g.A = w.att; g.lda = DA; g.W = fb.proj_w; g.ldw = bp.proj->ld;
+            g.M = M; g.N = D; g.K = DA; g.bias = fb.proj_b; g.out = w.x16; g.ldo = D; g.partial = w.partial;
             ScopedTimer t(m, AP_PROF_GEMM_PROJ, stream);
             if ((rc = ap::launch_gemm(dt, ap::EPI_RESID_STATS, g, stream)) != AP_OK) return rc;
         }
@@ -406,15 +422,18 @@ int blocks_fused(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipStream
         {
             ap::GemmArgs g{};
             g.A = w.x16; g.lda = D; g.W = fb.fc1_w; g.ldw = bp.fc1->ld;
-            g.M = M; g.N = c.mlp_dim; g.K = D; g.bias = fb.fc1_b; g.colsum = fb.fc1_cs; g.rowstats = w.rowstats;
-            g.out = w.hid; g.ldo = c.mlp_dim;
+            g.M = M; g.N = F1; g.K = D; g.bias = fb.fc1_b; g.colsum = fb.fc1_cs; g.rowstats = w.rowstats;
+            g.out = w.hid; g.ldo = F1;
             ScopedTimer t(m, AP_PROF_GEMM_FC1, stream);
-            if ((rc = ap::launch_gemm(dt, ap::EPI_NORM_GELU, g, stream)) != AP_OK) return rc;
+            if ((rc = ap::launch_gemm(dt, swiglu ? ap::EPI_NORM_STORE : ap::EPI_NORM_GELU, g, stream)) != AP_OK) return rc;
+            // SwiGLU: the gate needs columns j and mlp + j of one row, which live in different tiles of the GEMM: a streaming
+            // pass (HBM-bound, 6 B read + 2 B written per gated value) instead of an epilogue
+            if (swiglu && (rc = ap::launch_swiglu(dt, w.hid, M, H, w.hid2, stream)) != AP_OK) return rc;
         }
         {
             ap::GemmArgs g{};
-            g.A = w.hid; g.lda = c.mlp_dim; g.W = fb.fc2_w; g.ldw = bp.fc2->ld;
-            g.M = M; g.N = D; g.K = c.mlp_dim; g.bias = fb.fc2_b; g.out = w.x16; g.ldo = D; g.partial = w.partial;
+            g.A = w.hid2; g.lda = H; g.W = fb.fc2_w; g.ldw = bp.fc2->ld;
+            g.M = M; g.N = D; g.K = H; g.bias = fb.fc2_b; g.out = w.x16; g.ldo = D; g.partial = w.partial;
             ScopedTimer t(m, AP_PROF_GEMM_FC2, stream);
             if ((rc = ap::launch_gemm(dt, ap::EPI_RESID_STATS, g, stream)) != AP_OK) return rc;
         }
@@ -498,11 +517,16 @@ int ap_vit_create(const ap_vit_config* cfg, ap_vit** out) {
     const ap_vit_config& c = *cfg;
     AP_REQUIRE(c.image_size > 0 && c.patch_size > 0 && c.image_size % c.patch_size == 0,
                "vit_create: image %d / patch %d", c.image_size, c.patch_size);
-    AP_REQUIRE(c.patch_size % 8 == 0 && c.patch_size <= 16,
-               "vit_create: patch size %d unsupported by this build (8 or 16)", c.patch_size);
-    AP_REQUIRE(c.dim > 0 && c.heads > 0 && c.dim % c.heads == 0 && c.dim / c.heads == 64,
-               "vit_create: dim %d / heads %d: head_dim must be 64", c.dim, c.heads);
+    AP_REQUIRE(c.patch_size >= 4 && c.patch_size <= 32 && c.patch_size % 2 == 0,
+               "vit_create: patch size %d unsupported by this build (even, 4 .. 32)", c.patch_size);
+    AP_REQUIRE(c.dim > 0 && c.heads > 0 && c.dim % c.heads == 0, "vit_create: dim %d / heads %d", c.dim, c.heads);
+    const int hd = c.head_dim > 0 ? c.head_dim : c.dim / c.heads;
+    AP_REQUIRE(hd == 64 || hd == 128,
+               "vit_create: head_dim %d: q / k / v heads must be stored 64 or 128 wide (zero-pad other widths and set attn_scale)", hd);
     AP_REQUIRE(c.dim % 128 == 0 && c.mlp_dim % 128 == 0, "vit_create: dim and mlp_dim must be multiples of 128");
+    AP_REQUIRE(c.reg_tokens >= 0 && c.reg_tokens <= 64, "vit_create: reg_tokens %d", c.reg_tokens);
+    AP_REQUIRE(c.mlp_type == AP_MLP_GELU || c.mlp_type == AP_MLP_SWIGLU, "vit_create: mlp_type %d", c.mlp_type);
+    AP_REQUIRE(c.attn_scale >= 0.f, "vit_create: attn_scale %g", (double)c.attn_scale);
     AP_REQUIRE(c.depth > 0, "vit_create: depth %d", c.depth);
     AP_REQUIRE(c.compute_dtype == AP_F16 || c.compute_dtype == AP_BF16 || c.compute_dtype == AP_F32,
                "vit_create: compute dtype %d", c.compute_dtype);
@@ -514,11 +538,18 @@ int ap_vit_create(const ap_vit_config* cfg, ap_vit** out) {
                    "vit_create: pool_dim %d / pool_heads %d (heads of 64, multiple of 128)", c.pool_dim, c.pool_heads);
     }
     const int g = c.image_size / c.patch_size;
-    AP_REQUIRE(c.compute_dtype != AP_F32 || 1 + g * g <= 288,
-               "vit_create: %d tokens exceed the float32 attention kernel's limit (288); use float16 / bfloat16", 1 + g * g);
+    const int prefix = 1 + c.reg_tokens;
+    AP_REQUIRE(c.compute_dtype != AP_F32 || (prefix + g * g <= 288 && hd == 64),
+               "vit_create: %d tokens / head width %d exceed the float32 attention kernel's limits (288 tokens, 64 wide); use "
+               "float16 / bfloat16", prefix + g * g, hd);
     ap_vit* m = new ap_vit();
     m->cfg = c;
-    m->grid = g; m->patches = g * g; m->tokens = 1 + g * g;
+    m->grid = g; m->patches = g * g; m->prefix = prefix; m->tokens = prefix + g * g;
+    m->pos_rows = c.no_embed_class ? g * g : m->tokens;
+    m->pos_row0 = c.no_embed_class ? 0 : prefix;
+    m->hd = hd; m->dattn = c.heads * hd;
+    m->attn_scale = c.attn_scale > 0.f ? c.attn_scale : 1.0f / sqrtf((float)hd);
+    m->fc1_rows = c.mlp_type == AP_MLP_SWIGLU ? 2 * c.mlp_dim : c.mlp_dim;
     m->kpe = (int)ap::align_up(3 * c.patch_size * c.patch_size, 64);
     AP_HIP_CHECK(hipGetDevice(&m->device));
     m->full_last_block = getenv("AP_VIT_FULL_LAST_BLOCK") != nullptr;     // defaults only; ap_vit_set_option changes them
@@ -532,16 +563,17 @@ int ap_vit_create(const ap_vit_config* cfg, ap_vit** out) {
     add("patch_embed.weight", D, 3 * c.patch_size * c.patch_size, true);
     add("patch_embed.bias", 1, D, false);
     add("cls_token", 1, D, false);
-    add("pos_embed", m->tokens, D, false);
+    if (c.reg_tokens > 0) add("reg_tokens", c.reg_tokens, D, false);
+    add("pos_embed", m->pos_rows, D, false);
     add("norm.weight", 1, D, false);
     add("norm.bias", 1, D, false);
     for (int i = 0; i < c.depth; ++i) {
         const std::string b = "blocks." + std::to_string(i) + ".";
         add(b + "ln1.weight", 1, D, false); add(b + "ln1.bias", 1, D, false);
-        add(b + "qkv.weight", 3 * D, D, true); add(b + "qkv.bias", 1, 3 * D, false);
-        add(b + "proj.weight", D, D, true); add(b + "proj.bias", 1, D, false);
+        add(b + "qkv.weight", 3 * m->dattn, D, true); add(b + "qkv.bias", 1, 3 * m->dattn, false);
+        add(b + "proj.weight", D, m->dattn, true); add(b + "proj.bias", 1, D, false);
         add(b + "ln2.weight", 1, D, false); add(b + "ln2.bias", 1, D, false);
-        add(b + "fc1.weight", c.mlp_dim, D, true); add(b + "fc1.bias", 1, c.mlp_dim, false);
+        add(b + "fc1.weight", m->fc1_rows, D, true); add(b + "fc1.bias", 1, m->fc1_rows, false);
         add(b + "fc2.weight", D, c.mlp_dim, true); add(b + "fc2.bias", 1, D, false);
         if (c.layer_scale) { add(b + "ls1", 1, D, false); add(b + "ls2", 1, D, false); }
     }
@@ -565,6 +597,7 @@ void ap_vit_destroy(ap_vit* m) {
         if (kv.second.dev32) (void)hipFree(kv.second.dev32);
     }
     for (void* p : m->fused_allocs) (void)hipFree(p);
+    if (m->prefix_dev) (void)hipFree(m->prefix_dev);
     for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->ev_join) (void)hipEventDestroy(m->ev_join);
@@ -597,7 +630,10 @@ int ap_vit_set_param(ap_vit* m, const char* name, const float* host, size_t coun
         else AP_HIP_CHECK(hipFree(tmp));
     }
     p.set = true;
-    if (m->finalized && m->cfg.compute_dtype != AP_F32 &&
+    const bool was_finalized = m->finalized;
+    if (strcmp(name, "cls_token") == 0 || strcmp(name, "reg_tokens") == 0 || strcmp(name, "pos_embed") == 0)
+        m->finalized = false;              // the prefix rows (class / register tokens + position rows) are rebuilt by finalize
+    if (was_finalized && m->cfg.compute_dtype != AP_F32 &&
         (strncmp(name, "blocks.", 7) == 0 || strcmp(name, "pos_embed") == 0)) {
         // the folded weights / the T copy of the position embedding are stale now: a forward needs a new ap_vit_finalize
         m->fold_dirty = true;
@@ -665,7 +701,10 @@ int ap_vit_set_params(ap_vit* m, const char* const* names, const float* const* h
         if (fail(hipEventRecord(b.done, stream), "hipEventRecord")) break;
         b.busy = true;
         p.set = true;
-        if (m->finalized && m->cfg.compute_dtype != AP_F32 &&
+        const bool was_finalized = m->finalized;
+        if (strcmp(names[i], "cls_token") == 0 || strcmp(names[i], "reg_tokens") == 0 || strcmp(names[i], "pos_embed") == 0)
+            m->finalized = false;
+        if (was_finalized && m->cfg.compute_dtype != AP_F32 &&
             (strncmp(names[i], "blocks.", 7) == 0 || strcmp(names[i], "pos_embed") == 0)) {
             m->fold_dirty = true;
             m->finalized = false;
@@ -696,6 +735,12 @@ int ap_vit_finalize(ap_vit* m) {
     m->pe_w = find(m, "patch_embed.weight");
     m->pe_b = vec("patch_embed.bias"); m->cls = vec("cls_token"); m->pos = vec("pos_embed");
     m->norm_w = vec("norm.weight"); m->norm_b = vec("norm.bias");
+    {   // class / register token rows with their position rows folded in (f32; rebuilt on every finalize: it is tiny)
+        if (!m->prefix_dev) AP_HIP_CHECK(hipMalloc((void**)&m->prefix_dev, (size_t)m->prefix * m->cfg.dim * sizeof(float)));
+        int prc = ap::launch_prefix_build(m->cls, vec("reg_tokens"), m->cfg.reg_tokens, m->cfg.no_embed_class ? nullptr : m->pos,
+                                          m->cfg.dim, m->prefix_dev, nullptr);
+        if (prc != AP_OK) return prc;
+    }
     m->blocks.resize(m->cfg.depth);
     for (int i = 0; i < m->cfg.depth; ++i) {
         const std::string b = "blocks." + std::to_string(i) + ".";
@@ -727,7 +772,7 @@ int ap_vit_finalize(ap_vit* m) {
     m->fused_allocs.clear();
     m->fused.clear();
     if (m->cfg.compute_dtype != AP_F32) {
-        const int dt = m->cfg.compute_dtype, D = m->cfg.dim, H = m->cfg.mlp_dim;
+        const int dt = m->cfg.compute_dtype, D = m->cfg.dim, H = m->cfg.mlp_dim, DA = m->dattn, F1 = m->fc1_rows;
         const size_t es = ap::dtype_size(dt);
         m->fused.resize(m->cfg.depth);
         int rc = AP_OK;
@@ -742,19 +787,19 @@ int ap_vit_finalize(ap_vit* m) {
             ap::FusedBlock& fb = m->fused[i];
             for (const Param* p : {bp.qkv, bp.proj, bp.fc1, bp.fc2})
                 if (!p->dev32) { ap::set_error("vit_finalize: block %d: a block parameter (or pos_embed) changed after a finalize -- the LayerNorm / LayerScale folding needs the float32 values of all four matrices of every block again: upload qkv / proj / fc1 / fc2 weights before finalizing", i); return AP_ERR_STATE; }
-            fb.qkv_w = dalloc((size_t)3 * D * bp.qkv->ld * es); fb.qkv_cs = (float*)dalloc(3 * D * 4); fb.qkv_b = (float*)dalloc(3 * D * 4);
-            fb.fc1_w = dalloc((size_t)H * bp.fc1->ld * es); fb.fc1_cs = (float*)dalloc(H * 4); fb.fc1_b = (float*)dalloc(H * 4);
+            fb.qkv_w = dalloc((size_t)3 * DA * bp.qkv->ld * es); fb.qkv_cs = (float*)dalloc(3 * DA * 4); fb.qkv_b = (float*)dalloc(3 * DA * 4);
+            fb.fc1_w = dalloc((size_t)F1 * bp.fc1->ld * es); fb.fc1_cs = (float*)dalloc(F1 * 4); fb.fc1_b = (float*)dalloc(F1 * 4);
             fb.proj_w = dalloc((size_t)D * bp.proj->ld * es); fb.proj_b = (float*)dalloc(D * 4);
             fb.fc2_w = dalloc((size_t)D * bp.fc2->ld * es); fb.fc2_b = (float*)dalloc(D * 4);
             if (rc != AP_OK) break;
-            if ((rc = ap::launch_fold_ln(dt, bp.qkv->dev32, 3 * D, D, bp.qkv->ld, bp.ln1_w, bp.ln1_b, bp.qkv_b, fb.qkv_w, fb.qkv_cs, fb.qkv_b, nullptr)) != AP_OK) break;
-            if ((rc = ap::launch_fold_ln(dt, bp.fc1->dev32, H, D, bp.fc1->ld, bp.ln2_w, bp.ln2_b, bp.fc1_b, fb.fc1_w, fb.fc1_cs, fb.fc1_b, nullptr)) != AP_OK) break;
-            if ((rc = ap::launch_fold_ls(dt, bp.proj->dev32, D, D, bp.proj->ld, bp.ls1, bp.proj_b, fb.proj_w, fb.proj_b, nullptr)) != AP_OK) break;
+            if ((rc = ap::launch_fold_ln(dt, bp.qkv->dev32, 3 * DA, D, bp.qkv->ld, bp.ln1_w, bp.ln1_b, bp.qkv_b, fb.qkv_w, fb.qkv_cs, fb.qkv_b, nullptr)) != AP_OK) break;
+            if ((rc = ap::launch_fold_ln(dt, bp.fc1->dev32, F1, D, bp.fc1->ld, bp.ln2_w, bp.ln2_b, bp.fc1_b, fb.fc1_w, fb.fc1_cs, fb.fc1_b, nullptr)) != AP_OK) break;
+            if ((rc = ap::launch_fold_ls(dt, bp.proj->dev32, D, DA, bp.proj->ld, bp.ls1, bp.proj_b, fb.proj_w, fb.proj_b, nullptr)) != AP_OK) break;
             if ((rc = ap::launch_fold_ls(dt, bp.fc2->dev32, D, H, bp.fc2->ld, bp.ls2, bp.fc2_b, fb.fc2_w, fb.fc2_b, nullptr)) != AP_OK) break;
         }
         if (rc == AP_OK) {
-            m->pos16 = dalloc((size_t)m->tokens * D * es);
-            if (rc == AP_OK) rc = ap::launch_convert(dt, m->pos, m->pos16, (size_t)m->tokens * D, nullptr);
+            m->pos16 = dalloc((size_t)m->pos_rows * D * es);
+            if (rc == AP_OK) rc = ap::launch_convert(dt, m->pos, m->pos16, (size_t)m->pos_rows * D, nullptr);
         }
         if (rc != AP_OK) return rc;
         AP_HIP_CHECK(hipDeviceSynchronize());

@@ -17,7 +17,8 @@ __all__ = ["FeatureExtractor", "HipViTFeatureExtractor", "PatchFeatureExtractor"
 
 def build_default_registry(*, device="cuda", num_workers: int = 0,
                            dtype: torch.dtype = torch.float32) -> PatchFeatureExtractorRegistry:
-    """Built-in extractors of this build: the ViT family (vit_b_16, vit_l_16, uni_v1, conch_v1) on the native HIP path.  Builders are
+    """Built-in extractors of this build: the ViT family (vit_b_16 / b_32 / l_16 / l_32 / h_14, uni_v1, uni_v2, conch_v1) on the
+    native HIP path.  Builders are
     lazy (nothing touches the GPU until ``create``), so this is safe on a CPU-only host, exactly
     like the reference's registry which the CLI instantiates at import (cli.py:50)."""
     dev = torch.device(device)

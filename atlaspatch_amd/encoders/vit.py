@@ -34,10 +34,18 @@ OPENAI_CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
 #   ViT_B_16_Weights.IMAGENET1K_V1 = ImageClassification(crop_size=224)                  -> resize_size 256 (default), bilinear
 #   ViT_L_16_Weights.IMAGENET1K_V1 = ImageClassification(crop_size=224, resize_size=242) -> 256-px tiles ARE resampled to 242
 # timm / open_clip: uni_v1 Resize(224, bicubic), conch_v1 Resize(448, bicubic).
+#   ViT_B_32 / ViT_L_32 IMAGENET1K_V1 = ImageClassification(crop_size=224)               -> resize 256, bilinear
+#   ViT_H_14 has no IMAGENET1K_V1: base.py:131-137 falls back to DEFAULT = IMAGENET1K_SWAG_E2E_V1 =
+#     ImageClassification(crop_size=518, resize_size=518, interpolation=BICUBIC), model image_size 518 (1370 tokens)
+# uni_v2 (uni.py:62-125): timm create_transform of the hub config = Resize(224, bicubic) + CenterCrop(224) (unverifiable offline)
 TRANSFORM_RESIZE = {
     "vit_b_16": (256, "bilinear"),
+    "vit_b_32": (256, "bilinear"),
     "vit_l_16": (242, "bilinear"),
+    "vit_l_32": (256, "bilinear"),
+    "vit_h_14": (518, "bicubic"),
     "uni_v1": (224, "bicubic"),
+    "uni_v2": (224, "bicubic"),
     "conch_v1": (448, "bicubic"),
 }
 
@@ -49,6 +57,19 @@ ARCHS = {
                      ln_eps=1e-6, layer_scale=False),
     "uni_v1": dict(image_size=224, patch_size=16, dim=1024, depth=24, heads=16, mlp_dim=4096,
                    ln_eps=1e-6, layer_scale=True),
+    # the rest of models/patch/vit.py:9-15 (torchvision): patch 32 (50 tokens); ViT-H/14 at the SWAG end-to-end weights'
+    # 518 px (37 x 37 + 1 = 1370 tokens), heads 80 wide (stored zero-padded to 128 on the device, softmax scale 1/sqrt(80))
+    "vit_b_32": dict(image_size=224, patch_size=32, dim=768, depth=12, heads=12, mlp_dim=3072,
+                     ln_eps=1e-6, layer_scale=False),
+    "vit_l_32": dict(image_size=224, patch_size=32, dim=1024, depth=24, heads=16, mlp_dim=4096,
+                     ln_eps=1e-6, layer_scale=False),
+    "vit_h_14": dict(image_size=518, patch_size=14, dim=1280, depth=32, heads=16, mlp_dim=5120,
+                     ln_eps=1e-6, layer_scale=False),
+    # UNI2-h (models/patch/uni.py:62-125, timm kwargs :82-96): ViT-H/14 at 224 px, 8 register tokens, no_embed_class (the
+    # position embedding covers the 256 patch tokens only), SwiGLUPacked MLP (fc1 1536 -> 2 x 4096, silu(x1) * x2, fc2
+    # 4096 -> 1536; mlp_ratio 2.66667 * 2 -> int(1536 * 5.33334) = 8192 packed), LayerScale 1e-5, class-token pooling
+    "uni_v2": dict(image_size=224, patch_size=14, dim=1536, depth=24, heads=24, mlp_dim=4096,
+                   ln_eps=1e-6, layer_scale=True, reg_tokens=8, no_embed_class=True, mlp="swiglu"),
     # CONCH v1 visual tower (models/patch/conch.py:20-64 -> conch.open_clip_custom "conch_ViT-B-16" [3P, package
     # absent offline]): timm ViT-B/16 trunk at 448 px (785 tokens) + open_clip AttentionalPooler with ONE
     # contrastive query (d_model 512, 8 heads, context 768) + LayerNorm; encode_image(proj_contrast=False,
@@ -65,6 +86,8 @@ def _detect_source(sd: dict) -> str:
         return "torchvision"
     if "patch_embed.proj.weight" in keys:
         return "timm"
+    if "embeddings.register_tokens" in keys or any(".layer_scale1.lambda1" in k for k in keys):
+        return "hf_dinov2"
     if any(k.startswith("embeddings.patch_embeddings") for k in keys):
         return "hf"
     if "patch_embed.weight" in keys:
@@ -104,6 +127,8 @@ def canonical_state_dict(sd: dict, *, depth: int, layer_scale: bool, source: str
     elif source == "timm":
         put("patch_embed.weight", sd["patch_embed.proj.weight"]); put("patch_embed.bias", sd["patch_embed.proj.bias"])
         put("cls_token", sd["cls_token"].reshape(-1)); put("pos_embed", sd["pos_embed"][0])
+        if "reg_token" in sd:                                         # timm reg_tokens > 0: [1, R, D]
+            put("reg_tokens", sd["reg_token"][0])
         put("norm.weight", sd["norm.weight"]); put("norm.bias", sd["norm.bias"])
         for i in range(depth):
             p, b = f"blocks.{i}.", f"blocks.{i}."
@@ -138,8 +163,66 @@ def canonical_state_dict(sd: dict, *, depth: int, layer_scale: bool, source: str
             put(b + "ln2.weight", sd[p + "layernorm_after.weight"]); put(b + "ln2.bias", sd[p + "layernorm_after.bias"])
             put(b + "fc1.weight", sd[f1 + ".weight"]); put(b + "fc1.bias", sd[f1 + ".bias"])
             put(b + "fc2.weight", sd[f2 + ".weight"]); put(b + "fc2.bias", sd[f2 + ".bias"])
+    elif source == "hf_dinov2":
+        # transformers Dinov2Model / Dinov2WithRegistersModel: the position embedding has a class row and patch rows but none
+        # for the register tokens, which are inserted AFTER it is added -> canonical no_embed_class form with the class row
+        # folded into the class token (one f32 add, the same one the model performs)
+        pos = sd["embeddings.position_embeddings"][0]
+        put("patch_embed.weight", sd["embeddings.patch_embeddings.projection.weight"])
+        put("patch_embed.bias", sd["embeddings.patch_embeddings.projection.bias"])
+        put("cls_token", (sd["embeddings.cls_token"].reshape(-1).float() + pos[0].float()))
+        if "embeddings.register_tokens" in sd:
+            put("reg_tokens", sd["embeddings.register_tokens"][0])
+        put("pos_embed", pos[1:])
+        put("norm.weight", sd["layernorm.weight"]); put("norm.bias", sd["layernorm.bias"])
+        for i in range(depth):
+            p, b = f"encoder.layer.{i}.", f"blocks.{i}."
+            a = p + "attention.attention."
+            put(b + "ln1.weight", sd[p + "norm1.weight"]); put(b + "ln1.bias", sd[p + "norm1.bias"])
+            put(b + "qkv.weight", torch.cat([sd[a + "query.weight"], sd[a + "key.weight"], sd[a + "value.weight"]], 0))
+            put(b + "qkv.bias", torch.cat([sd[a + "query.bias"], sd[a + "key.bias"], sd[a + "value.bias"]], 0))
+            put(b + "proj.weight", sd[p + "attention.output.dense.weight"]); put(b + "proj.bias", sd[p + "attention.output.dense.bias"])
+            put(b + "ln2.weight", sd[p + "norm2.weight"]); put(b + "ln2.bias", sd[p + "norm2.bias"])
+            f1, f2 = (("mlp.weights_in", "mlp.weights_out") if p + "mlp.weights_in.weight" in sd else ("mlp.fc1", "mlp.fc2"))
+            put(b + "fc1.weight", sd[p + f1 + ".weight"]); put(b + "fc1.bias", sd[p + f1 + ".bias"])
+            put(b + "fc2.weight", sd[p + f2 + ".weight"]); put(b + "fc2.bias", sd[p + f2 + ".bias"])
+            if layer_scale:
+                put(b + "ls1", sd[p + "layer_scale1.lambda1"]); put(b + "ls2", sd[p + "layer_scale2.lambda1"])
     else:
         raise ValueError(f"unknown state-dict source '{source}'")
+    return out
+
+
+def stored_head_dim(dim: int, heads: int) -> int:
+    """Width of one q / k / v head as the device stores it: 64 or 128 (other true widths are zero-padded up)."""
+    hd = dim // heads
+    if hd <= 64:
+        return 64
+    if hd <= 128:
+        return 128
+    raise ValueError(f"head width {hd} (dim {dim} / heads {heads}) exceeds 128")
+
+
+def pad_heads(state: dict, *, dim: int, heads: int, depth: int) -> dict:
+    """Canonical state dict -> the same model with every attention head zero-padded from dim / heads to
+    ``stored_head_dim`` channels: qkv rows [3, heads, hd, :] -> [3, heads, hdp, :], proj columns likewise.  Zero q / k
+    channels add nothing to q.k, zero v channels give zero outputs that meet zero proj columns: the function is unchanged
+    as long as the softmax scale stays 1 / sqrt(hd) (``attn_scale``)."""
+    hd, hdp = dim // heads, stored_head_dim(dim, heads)
+    if hd == hdp:
+        return state
+    out = dict(state)
+    for i in range(depth):
+        b = f"blocks.{i}."
+        w = state[b + "qkv.weight"].reshape(3, heads, hd, -1)
+        wp = torch.zeros((3, heads, hdp, w.shape[-1]), dtype=w.dtype); wp[:, :, :hd] = w
+        out[b + "qkv.weight"] = wp.reshape(3 * heads * hdp, -1).contiguous()
+        bb = state[b + "qkv.bias"].reshape(3, heads, hd)
+        bp = torch.zeros((3, heads, hdp), dtype=bb.dtype); bp[:, :, :hd] = bb
+        out[b + "qkv.bias"] = bp.reshape(-1).contiguous()
+        pw = state[b + "proj.weight"].reshape(-1, heads, hd)
+        pp = torch.zeros((pw.shape[0], heads, hdp), dtype=pw.dtype); pp[:, :, :hd] = pw
+        out[b + "proj.weight"] = pp.reshape(pw.shape[0], heads * hdp).contiguous()
     return out
 
 
@@ -192,20 +275,25 @@ def random_canonical_state_dict(arch: dict, seed: int = 0) -> dict:
     pretrained checkpoints offline."""
     g = torch.Generator().manual_seed(seed)
     d, mlp, ps = arch["dim"], arch["mlp_dim"], arch["patch_size"]
-    tokens = 1 + (arch["image_size"] // ps) ** 2
+    reg = int(arch.get("reg_tokens", 0))
+    patches = (arch["image_size"] // ps) ** 2
+    tokens = patches if arch.get("no_embed_class") else 1 + reg + patches          # rows of the position embedding
+    f1 = 2 * mlp if arch.get("mlp") == "swiglu" else mlp
 
     def w(*shape, s=0.02):
         return torch.randn(*shape, generator=g) * s
 
     sd = {"patch_embed.weight": w(d, 3, ps, ps), "patch_embed.bias": w(d), "cls_token": w(d),
           "pos_embed": w(tokens, d), "norm.weight": 1.0 + w(d, s=0.1), "norm.bias": w(d)}
+    if reg:
+        sd["reg_tokens"] = w(reg, d)
     for i in range(arch["depth"]):
         b = f"blocks.{i}."
         sd[b + "ln1.weight"] = 1.0 + w(d, s=0.1); sd[b + "ln1.bias"] = w(d)
         sd[b + "qkv.weight"] = w(3 * d, d); sd[b + "qkv.bias"] = w(3 * d)
         sd[b + "proj.weight"] = w(d, d); sd[b + "proj.bias"] = w(d)
         sd[b + "ln2.weight"] = 1.0 + w(d, s=0.1); sd[b + "ln2.bias"] = w(d)
-        sd[b + "fc1.weight"] = w(mlp, d); sd[b + "fc1.bias"] = w(mlp)
+        sd[b + "fc1.weight"] = w(f1, d); sd[b + "fc1.bias"] = w(f1)
         sd[b + "fc2.weight"] = w(d, mlp); sd[b + "fc2.bias"] = w(d)
         if arch.get("layer_scale"):
             sd[b + "ls1"] = torch.full((d,), 1e-5) + w(d, s=1e-6)
@@ -229,11 +317,17 @@ class HipViT:
         self.arch = dict(arch)
         attn_pool = arch.get("pool") == "attn"
         self.embed_dim = int(arch["pool_dim"] if attn_pool else arch["dim"])
+        hd_true = arch["dim"] // arch["heads"]
+        hd_stored = stored_head_dim(arch["dim"], arch["heads"])
         cfg = _lib.VitConfig(arch["image_size"], arch["patch_size"], arch["dim"], arch["depth"],
                              arch["heads"], arch["mlp_dim"], float(arch["ln_eps"]),
                              1 if arch.get("layer_scale") else 0, _lib.torch_dtype_code(dtype),
                              1 if attn_pool else 0, int(arch.get("pool_dim", 0)), int(arch.get("pool_heads", 0)),
-                             float(arch.get("pool_ln_eps", 1e-5)))
+                             float(arch.get("pool_ln_eps", 1e-5)),
+                             int(arch.get("reg_tokens", 0)), 1 if arch.get("no_embed_class") else 0,
+                             1 if arch.get("mlp") == "swiglu" else 0, hd_stored,
+                             0.0 if hd_stored == hd_true else float(1.0 / np.sqrt(np.float32(hd_true))))
+        state = pad_heads(state, dim=arch["dim"], heads=arch["heads"], depth=arch["depth"])
         handle = C.c_void_p()
         # hipMalloc / hipMemcpy on the legacy stream must not fall into another thread's stream capture (the SAM2 hipGraph):
         # both sides hold _lib.HIP_CAPTURE_LOCK for their device section
@@ -413,6 +507,13 @@ def register_vits(registry, *, device, dtype=torch.float32, num_workers: int = 0
         registry.register(name, lambda n=name: build_hip_vit_extractor(
             name=n, arch=n, device=device, dtype=dtype, random_init_seed=_env_seed(), resize=TRANSFORM_RESIZE[n],
             expect_size=None, max_batch=2048))
+    # the other three names of models/patch/vit.py:9-15.  vit_b_32 / vit_l_32: 32-px patches, 50 tokens, same transform as
+    # vit_b_16.  vit_h_14: torchvision has no IMAGENET1K_V1 entry for it, so the reference (base.py:123-143) takes DEFAULT =
+    # IMAGENET1K_SWAG_E2E_V1: 518-px input (Pillow BICUBIC resize of the tile, on the device), 1370 tokens, 80-wide heads
+    for name, cap in (("vit_b_32", 4096), ("vit_l_32", 4096), ("vit_h_14", 128)):
+        registry.register(name, lambda n=name, c=cap: build_hip_vit_extractor(
+            name=n, arch=n, device=device, dtype=dtype, random_init_seed=_env_seed(), resize=TRANSFORM_RESIZE[n],
+            expect_size=None, max_batch=c))
 
 
 def register_uni(registry, *, device, dtype=torch.float32, num_workers: int = 0) -> None:
@@ -421,3 +522,8 @@ def register_uni(registry, *, device, dtype=torch.float32, num_workers: int = 0)
     registry.register("uni_v1", lambda: build_hip_vit_extractor(
         name="uni_v1", arch="uni_v1", device=device, dtype=dtype, random_init_seed=_env_seed(),
         resize=TRANSFORM_RESIZE["uni_v1"], expect_size=None, max_batch=2048))
+    # uni_v2 = UNI2-h (uni.py:62-125): ViT-H/14 at 224 px with 8 register tokens, SwiGLUPacked MLP, LayerScale; same timm
+    # transform as uni_v1.  Checkpoint: timm key names (pytorch_model.bin of MahmoodLab/UNI2-h) in ATLASPATCH_WEIGHTS_DIR
+    registry.register("uni_v2", lambda: build_hip_vit_extractor(
+        name="uni_v2", arch="uni_v2", device=device, dtype=dtype, random_init_seed=_env_seed(),
+        resize=TRANSFORM_RESIZE["uni_v2"], expect_size=None, max_batch=1024))

@@ -188,7 +188,21 @@ typedef struct ap_vit_config {
     int pool_dim;        /* 512 (conch_v1); heads of 64 */
     int pool_heads;      /* 8 */
     float pool_ln_eps;   /* 1e-5 (open_clip LayerNorm) */
+    /* ---- ABI v17: the rest of the reference's ViT zoo (models/patch/vit.py:9-15 vit_b_32 / vit_l_32 / vit_h_14,
+     *      models/patch/uni.py:62-125 uni_v2).  All zero = the v16 behaviour. */
+    int reg_tokens;      /* register tokens between the class token and the patches (timm reg_tokens; uni_v2: 8) */
+    int no_embed_class;  /* 1: pos_embed has image_size^2 / patch_size^2 rows and is added to the PATCH tokens only (timm
+                            no_embed_class, uni_v2); 0: pos_embed covers class (+ register) tokens too */
+    int mlp_type;        /* AP_MLP_GELU: fc1 [mlp_dim, dim] -> GELU(erf) -> fc2 [dim, mlp_dim];
+                            AP_MLP_SWIGLU: timm SwiGLUPacked -- fc1 [2 * mlp_dim, dim], silu(x[:, :mlp_dim]) * x[:, mlp_dim:],
+                            fc2 [dim, mlp_dim] (uni_v2: mlp_dim 4096) */
+    int head_dim;        /* 0 = dim / heads (must be 64); else the width of one head of q / k / v as STORED: qkv.weight has
+                            3 * heads * head_dim rows, proj.weight heads * head_dim columns (64 or 128).  A model whose true
+                            head width is not 64 / 128 (vit_h_14: 80) is uploaded zero-padded to 128 with attn_scale set */
+    float attn_scale;    /* 0 = 1 / sqrt(head_dim); else the softmax scale (vit_h_14: 1 / sqrt(80)) */
 } ap_vit_config;
+#define AP_MLP_GELU 0
+#define AP_MLP_SWIGLU 1
 #define AP_POOL_CLS 0
 #define AP_POOL_ATTN 1
 

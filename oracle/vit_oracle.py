@@ -150,12 +150,30 @@ OPENAI_CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
 
 @torch.inference_mode()
 def vit_tokens_canonical(sd: dict, x: torch.Tensor, *, heads: int, depth: int, eps: float = 1e-6) -> torch.Tensor:
-    """timm ``VisionTransformer.forward_features`` from canonical parameter names: [n,3,S,S] -> [n, 1+P, D]."""
+    """timm ``VisionTransformer.forward_features`` from canonical parameter names: [n,3,S,S] -> [n, prefix+P, D].
+
+    Covers what the reference's encoder files instantiate (models/patch/vit.py:9-15, uni.py:13-125):
+      * ``reg_tokens`` [R, D] present: register tokens between the class token and the patches (timm ``reg_tokens``);
+      * ``pos_embed`` with exactly P rows: timm ``no_embed_class`` -- the position embedding is added to the patch tokens
+        only (``_pos_embed``: x = x + pos_embed, THEN the prefix tokens are concatenated); with prefix + P rows it is added
+        to every token after the concatenation (torchvision, timm default);
+      * ``fc1.weight`` with twice as many rows as ``fc2.weight`` has columns: timm ``SwiGLUPacked`` (GluMlp with
+        gate_last=False): x1, x2 = fc1(x).chunk(2, -1); fc2(silu(x1) * x2); otherwise fc2(gelu_erf(fc1(x)));
+      * ``ls1`` / ``ls2``: LayerScale.
+    Pinned against transformers' ViTModel (patch 16 / 32 / 14, 80-wide heads) and Dinov2WithRegistersModel (register tokens,
+    SwiGLU, LayerScale) by tests/test_encoder_zoo.py."""
     w, b = sd["patch_embed.weight"], sd["patch_embed.bias"]
     d = w.shape[0]
     n = x.shape[0]
     pe = F.conv2d(x, w, b, stride=w.shape[-1]).flatten(2).transpose(1, 2)
-    tok = torch.cat([sd["cls_token"].view(1, 1, d).expand(n, -1, -1), pe], dim=1) + sd["pos_embed"][None]
+    prefix = [sd["cls_token"].view(1, 1, d).expand(n, -1, -1)]
+    if "reg_tokens" in sd:
+        prefix.append(sd["reg_tokens"].view(1, -1, d).expand(n, -1, -1))
+    pos = sd["pos_embed"]
+    if pos.shape[0] == pe.shape[1]:
+        tok = torch.cat(prefix + [pe + pos[None]], dim=1)
+    else:
+        tok = torch.cat(prefix + [pe], dim=1) + pos[None]
     dh = d // heads
     for i in range(depth):
         p = f"blocks.{i}."
@@ -170,11 +188,46 @@ def vit_tokens_canonical(sd: dict, x: torch.Tensor, *, heads: int, depth: int, e
             out = out * sd[p + "ls1"]
         tok = tok + out
         h = F.layer_norm(tok, (d,), sd[p + "ln2.weight"], sd[p + "ln2.bias"], eps)
-        m = F.gelu(h @ sd[p + "fc1.weight"].T + sd[p + "fc1.bias"]) @ sd[p + "fc2.weight"].T + sd[p + "fc2.bias"]
+        m = h @ sd[p + "fc1.weight"].T + sd[p + "fc1.bias"]
+        if sd[p + "fc1.weight"].shape[0] == 2 * sd[p + "fc2.weight"].shape[1]:
+            x1, x2 = m.chunk(2, dim=-1)
+            m = F.silu(x1) * x2
+        else:
+            m = F.gelu(m)
+        m = m @ sd[p + "fc2.weight"].T + sd[p + "fc2.bias"]
         if p + "ls2" in sd:
             m = m * sd[p + "ls2"]
         tok = tok + m
     return F.layer_norm(tok, (d,), sd["norm.weight"], sd["norm.bias"], eps)
+
+
+def transform_resize_crop(patches_u8, *, resize, crop: int, mean=IMAGENET_MEAN, std=IMAGENET_STD) -> torch.Tensor:
+    """torchvision ``ImageClassification`` / timm ``create_transform`` on a PIL tile (base.py:42-45 hands the transform a PIL
+    image): Resize(shorter side -> size, Pillow filter) unless the shorter side already has it, CenterCrop(crop), ToTensor,
+    Normalize.  resize = (size, "bilinear" | "bicubic") or None."""
+    from PIL import Image
+    arrs = []
+    for p in patches_u8:
+        img = Image.fromarray(np.asarray(p))
+        if resize is not None:
+            size, filt = resize
+            w, h = img.size
+            if min(w, h) != size:
+                nw, nh = (size, int(size * h / w)) if w <= h else (int(size * w / h), size)
+                img = img.resize((nw, nh), Image.Resampling.BICUBIC if filt == "bicubic" else Image.Resampling.BILINEAR)
+        arrs.append(np.asarray(img))
+    return preprocess_center_crop(np.stack(arrs, 0), crop=crop, mean=mean, std=std)
+
+
+@torch.inference_mode()
+def canonical_extract(sd: dict, patches_u8, *, heads: int, depth: int, image_size: int, resize=None, eps: float = 1e-6,
+                      batch: int = 8) -> np.ndarray:
+    """extract_batch of a class-token-pooled encoder from canonical parameters: transform -> tokens -> LN -> token 0."""
+    outs = []
+    for s in range(0, len(patches_u8), batch):
+        x = transform_resize_crop(patches_u8[s:s + batch], resize=resize, crop=image_size)
+        outs.append(vit_tokens_canonical(sd, x, heads=heads, depth=depth, eps=eps)[:, 0])
+    return torch.cat(outs, 0).to(torch.float32).numpy()
 
 
 @torch.inference_mode()

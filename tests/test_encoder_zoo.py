@@ -1,0 +1,211 @@
+"""The rest of the reference's ViT encoder files (SURVEY §8 a14-a15 widened, VERDICT r03 "missing #3"):
+vit_b_32 / vit_l_32 / vit_h_14 (models/patch/vit.py:9-15) and uni_v2 (models/patch/uni.py:62-125).
+
+CPU (not gpu):
+  * ``oracle/vit_oracle.py::vit_tokens_canonical`` -- the restatement the GPU tests compare with -- is pinned against
+    INDEPENDENT implementations that are importable here: transformers' ``ViTModel`` (patch 32; patch 14 with 80-wide heads)
+    and ``Dinov2WithRegistersModel`` (register tokens + SwiGLU + LayerScale = UNI2-h's block structure), through the product's
+    key adapters (``canonical_state_dict``), small depth, seeded weights;
+  * head padding (80 -> 128) leaves the function unchanged; registry names; transform table.
+GPU (-m gpu): each encoder at its REAL size through the C ABI against the oracle, bounds = measured x headroom.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import pytest
+import torch
+
+
+def _rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def _seed_params(model, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if ("norm" in name and name.endswith("weight")) or "lambda1" in name:
+                p.copy_((0.3 if "lambda1" in name else 1.0) + 0.1 * torch.randn(p.shape, generator=g))
+            elif name.endswith("bias") or "position_embeddings" in name or "cls_token" in name or "register_tokens" in name:
+                p.copy_(0.05 * torch.randn(p.shape, generator=g))
+            elif p.dim() >= 2:
+                p.copy_(0.05 * torch.randn(p.shape, generator=g))
+    return model
+
+
+# ----------------------------------------------------------------------------- CPU: the oracle vs independent implementations
+@pytest.mark.parametrize("patch,hidden,heads,image", [(32, 128, 2, 224), (14, 160, 2, 56), (16, 128, 2, 64)])
+def test_oracle_matches_hf_vit_for_other_patch_sizes_and_head_widths(patch, hidden, heads, image):
+    """transformers ViTModel (what G1 pins the oracle with at patch 16) at patch 32 (vit_b_32 / vit_l_32) and at patch 14 with
+    80-wide heads (vit_h_14: 1280 / 16 = 80; here 160 / 2)."""
+    from transformers import ViTConfig, ViTModel
+    from atlaspatch_amd.encoders.vit import canonical_state_dict
+    from oracle import vit_oracle
+    torch.manual_seed(0)
+    cfg = ViTConfig(hidden_size=hidden, num_hidden_layers=2, num_attention_heads=heads, intermediate_size=4 * hidden,
+                    image_size=image, patch_size=patch, layer_norm_eps=1e-6, hidden_act="gelu")
+    model = _seed_params(ViTModel(cfg, add_pooling_layer=False).eval())
+    x = torch.randn(3, 3, image, image, generator=torch.Generator().manual_seed(2))
+    with torch.inference_mode():
+        want = model(pixel_values=x).last_hidden_state
+    sd = canonical_state_dict(dict(model.state_dict()), depth=2, layer_scale=False, source="hf")
+    got = vit_oracle.vit_tokens_canonical(sd, x, heads=heads, depth=2)
+    assert got.shape == want.shape == (3, 1 + (image // patch) ** 2, hidden)
+    assert _rel(got.numpy(), want.numpy()) <= 2e-6
+
+
+@pytest.mark.parametrize("swiglu", [True, False])
+def test_oracle_matches_hf_dinov2_with_registers(swiglu):
+    """UNI2-h's block structure (uni.py:82-96: register tokens, no_embed_class, SwiGLUPacked, LayerScale) as implemented by
+    transformers' Dinov2WithRegistersModel; the adapter folds its class position row into the class token."""
+    from transformers import Dinov2WithRegistersConfig, Dinov2WithRegistersModel
+    from atlaspatch_amd.encoders.vit import canonical_state_dict
+    from oracle import vit_oracle
+    torch.manual_seed(0)
+    cfg = Dinov2WithRegistersConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, mlp_ratio=4,
+                                    use_swiglu_ffn=swiglu, num_register_tokens=8, patch_size=14, image_size=56,
+                                    layerscale_value=1e-5, layer_norm_eps=1e-6)
+    model = _seed_params(Dinov2WithRegistersModel(cfg).eval())
+    x = torch.randn(3, 3, 56, 56, generator=torch.Generator().manual_seed(3))
+    with torch.inference_mode():
+        out = model(pixel_values=x)
+    sd = canonical_state_dict(dict(model.state_dict()), depth=2, layer_scale=True)           # auto-detected: hf_dinov2
+    assert sd["reg_tokens"].shape == (8, 128) and sd["pos_embed"].shape == (16, 128)
+    if swiglu:
+        assert sd["blocks.0.fc1.weight"].shape[0] == 2 * sd["blocks.0.fc2.weight"].shape[1]
+    got = vit_oracle.vit_tokens_canonical(sd, x, heads=2, depth=2)
+    assert got.shape == out.last_hidden_state.shape == (3, 1 + 8 + 16, 128)
+    assert _rel(got.numpy(), out.last_hidden_state.numpy()) <= 2e-6
+    assert _rel(got[:, 0].numpy(), out.pooler_output.numpy()) <= 2e-6                       # class token = what uni_v2 returns
+
+
+def test_head_padding_leaves_the_function_unchanged():
+    """pad_heads: 80-wide heads stored 128 wide (zero rows in q / k / v, zero columns in proj) with the softmax scale kept at
+    1 / sqrt(80) -- checked with an explicit attention on the padded tensors."""
+    from atlaspatch_amd.encoders.vit import pad_heads, random_canonical_state_dict, stored_head_dim
+    arch = dict(image_size=28, patch_size=14, dim=160, depth=1, heads=2, mlp_dim=320, ln_eps=1e-6)
+    sd = random_canonical_state_dict(arch, seed=5)
+    assert stored_head_dim(160, 2) == 128 and stored_head_dim(768, 12) == 64 and stored_head_dim(1280, 16) == 128
+    pad = pad_heads(sd, dim=160, heads=2, depth=1)
+    assert pad["blocks.0.qkv.weight"].shape == (3 * 2 * 128, 160) and pad["blocks.0.proj.weight"].shape == (160, 256)
+    h = torch.randn(2, 5, 160, generator=torch.Generator().manual_seed(6))
+
+    def attn(s, hd, scale):
+        qkv = h @ s["blocks.0.qkv.weight"].T + s["blocks.0.qkv.bias"]
+        q, k, v = qkv.view(2, 5, 3, 2, hd).permute(2, 0, 3, 1, 4)
+        ctx = (torch.softmax(q @ k.transpose(-1, -2) * scale, -1) @ v).transpose(1, 2).reshape(2, 5, 2 * hd)
+        return ctx @ s["blocks.0.proj.weight"].T + s["blocks.0.proj.bias"]
+    assert _rel(attn(pad, 128, 1 / math.sqrt(80)).numpy(), attn(sd, 80, 1 / math.sqrt(80)).numpy()) <= 1e-6
+    assert pad_heads(sd | {}, dim=128, heads=2, depth=0) is not None          # 64-wide: returned as is
+
+
+def test_registry_has_the_reference_names_of_the_three_encoder_files():
+    """models/patch/vit.py:9-15 (five names), uni.py (uni_v1, uni_v2), conch.py (conch_v1; conch_v15 = code downloaded from the
+    gated MahmoodLab/TITAN repository at run time, conch.py:82-86 -- nothing in the reference to restate)."""
+    from atlaspatch_amd.encoders import build_default_registry
+    from atlaspatch_amd.encoders.vit import ARCHS, TRANSFORM_RESIZE
+    names = build_default_registry(device="cpu").available()
+    for n in ("vit_b_16", "vit_b_32", "vit_l_16", "vit_l_32", "vit_h_14", "uni_v1", "uni_v2", "conch_v1"):
+        assert n in names and n in ARCHS and n in TRANSFORM_RESIZE
+    assert ARCHS["vit_h_14"]["image_size"] == 518 and TRANSFORM_RESIZE["vit_h_14"] == (518, "bicubic")
+    a = ARCHS["uni_v2"]
+    assert (a["dim"], a["depth"], a["heads"], a["mlp_dim"], a["reg_tokens"], a["patch_size"]) == (1536, 24, 24, 4096, 8, 14)
+    assert int(1536 * 2.66667 * 2) == 2 * a["mlp_dim"]                       # timm: hidden_features = int(dim * mlp_ratio)
+
+
+# ----------------------------------------------------------------------------- GPU: real sizes through the C ABI
+# measured on MI355X (profiles/r04_parity_lines.txt): (norm-wise, element-wise max, q99.9)
+MEASURED = {}
+HEADROOM = (1.2, 1.5, 1.25)
+FALLBACK = {"float32": (3.0e-6, 6e-5, 4e-5), "float16": (2.2e-3, 4e-2, 2.4e-2)}
+
+
+def _elem(a, b, floor=0.05, q=None):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    e = np.abs(a - b) / (np.abs(b) + floor * np.abs(b).max())
+    return float(e.max() if q is None else np.quantile(e, q))
+
+
+def _check(got, want, dtype, what):
+    key = str(dtype).split(".")[-1]
+    r, e, eq = _rel(got, want), _elem(got, want), _elem(got, want, q=0.999)
+    m = MEASURED.get((what, key))
+    br, be, bq = (tuple(v * h for v, h in zip(m, HEADROOM)) if m else FALLBACK[key])
+    print(f"PARITY {what} {key}: norm-wise {r:.3e} (bound {br:.2e}) element-wise max {e:.3e} ({be:.2e}) q99.9 {eq:.3e} ({bq:.2e})")
+    assert r <= br and e <= be and eq <= bq, (what, key, (r, br), (e, be), (eq, bq))
+    if dtype == torch.float32:
+        assert max(r, e, eq) <= 1e-3
+
+
+def _tiles(n, seed):
+    rng = np.random.default_rng(seed)
+    return [rng.integers(0, 256, (256, 256, 3), dtype=np.uint8) for _ in range(n)]
+
+
+def _with_layer_scale(sd, arch, seed):
+    g = torch.Generator().manual_seed(seed)
+    if arch.get("layer_scale"):
+        for i in range(arch["depth"]):
+            sd[f"blocks.{i}.ls1"] = torch.rand(arch["dim"], generator=g) * 0.5 + 0.2
+            sd[f"blocks.{i}.ls2"] = torch.rand(arch["dim"], generator=g) * 0.5 + 0.2
+    return sd
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,dtype,n", [("vit_b_32", torch.float16, 8), ("vit_b_32", torch.float32, 8), ("vit_l_32", torch.float16, 8),
+                                          ("uni_v2", torch.float16, 6), ("uni_v2", torch.float32, 4), ("vit_h_14", torch.float16, 3)])
+def test_encoder_at_real_size_vs_fp32_oracle(name, dtype, n):
+    from atlaspatch_amd.encoders.vit import ARCHS, TRANSFORM_RESIZE, build_hip_vit_extractor, random_canonical_state_dict
+    from oracle import vit_oracle
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    arch = dict(ARCHS[name])
+    sd = _with_layer_scale(random_canonical_state_dict(arch, seed=41), arch, 42)
+    ex = build_hip_vit_extractor(name=name, arch=arch, state_dict=sd, source="canonical", device=torch.device("cuda:0"), dtype=dtype,
+                                 resize=TRANSFORM_RESIZE[name], expect_size=None, max_batch=64)
+    tiles = _tiles(n, 43)
+    got = ex.extract_batch(tiles, batch_size=32)
+    got_f32s = None
+    if dtype != torch.float32:
+        ex.vit.set_option("f32_stream", True)
+        got_f32s = ex.extract_batch(tiles, batch_size=32)
+        ex.vit.set_option("f32_stream", False)
+        ex.vit.set_option("full_last_block", True)
+        got_full = ex.extract_batch(tiles, batch_size=32)
+        assert _rel(got_full, got) <= 2e-3                          # the CLS-only tail and the full last block agree
+    ex.cleanup()
+    want = vit_oracle.canonical_extract(sd, tiles, heads=arch["heads"], depth=arch["depth"], image_size=arch["image_size"],
+                                        resize=TRANSFORM_RESIZE[name], batch=2)
+    assert got.shape == want.shape == (n, arch["dim"]) and got.dtype == np.float32
+    _check(got, want, dtype, f"{name} L{arch['depth']}")
+    if got_f32s is not None:
+        _check(got_f32s, want, dtype, f"{name} L{arch['depth']}, f32_stream")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float16, 4e-3)])
+def test_dinov2_with_registers_checkpoint_layout_on_the_device_vs_the_hf_model(dtype, tol):
+    """The path a DINOv2-with-registers export takes (HF key names -> canonical -> device) against the HF model ITSELF: an
+    independent implementation of register tokens + SwiGLU + LayerScale checks the device kernels directly (3 blocks, dim 384)."""
+    from transformers import Dinov2WithRegistersConfig, Dinov2WithRegistersModel
+    from atlaspatch_amd.encoders.vit import build_hip_vit_extractor
+    from oracle import vit_oracle
+    torch.manual_seed(0)
+    cfg = Dinov2WithRegistersConfig(hidden_size=384, num_hidden_layers=3, num_attention_heads=6, mlp_ratio=4, use_swiglu_ffn=True,
+                                    num_register_tokens=8, patch_size=14, image_size=224, layerscale_value=1e-5, layer_norm_eps=1e-6)
+    model = _seed_params(Dinov2WithRegistersModel(cfg).eval())
+    assert model.state_dict()["encoder.layer.0.mlp.weights_out.weight"].shape == (384, 1024)
+    arch = dict(image_size=224, patch_size=14, dim=384, depth=3, heads=6, mlp_dim=1024, ln_eps=1e-6, layer_scale=True,
+                reg_tokens=8, no_embed_class=True, mlp="swiglu")
+    ex = build_hip_vit_extractor(name="dinov2_small", arch=arch, state_dict=dict(model.state_dict()), device=torch.device("cuda:0"),
+                                 dtype=dtype, resize=(224, "bicubic"), expect_size=None, max_batch=64)
+    tiles = _tiles(5, 47)
+    got = ex.extract_batch(tiles, batch_size=32)
+    ex.cleanup()
+    x = vit_oracle.transform_resize_crop(tiles, resize=(224, "bicubic"), crop=224)
+    with torch.inference_mode():
+        want = model(pixel_values=x).pooler_output.numpy()
+    assert got.shape == want.shape == (5, 384)
+    assert _rel(got, want) <= tol, _rel(got, want)

@@ -234,15 +234,17 @@ def test_layernorm_vs_torch(env, dt, tol, rows, dim):
     assert (out.float() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item() / 2)
 
 
-def _attn_ref(qkv, n, T, H):
-    q, k, v = qkv.float().view(n, T, 3, H, 64).permute(2, 0, 3, 1, 4)
-    p = torch.softmax(q @ k.transpose(-1, -2) / 8.0, -1)
-    return (p @ v).permute(0, 2, 1, 3).reshape(n * T, H * 64)
+def _attn_ref(qkv, n, T, H, hd=64):
+    q, k, v = qkv.float().view(n, T, 3, H, hd).permute(2, 0, 3, 1, 4)
+    p = torch.softmax(q @ k.transpose(-1, -2) / (hd ** 0.5), -1)
+    return (p @ v).permute(0, 2, 1, 3).reshape(n * T, H * hd)
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.float16, 4e-3), (torch.bfloat16, 3e-2), (torch.float32, 2e-5)])
 @pytest.mark.parametrize("shape", [(3, 197, 12), (2, 50, 16), (1, 257, 12), (5, 1, 12), (2, 785, 12), (1, 1025, 4),
-                                   (3, 785, 3), (1, 300, 13), (7, 64, 1)])     # (image, head) counts off the XCD walk's 8
+                                   (3, 785, 3), (1, 300, 13), (7, 64, 1),      # (image, head) counts off the XCD walk's 8
+                                   (2, 150, 12), (1, 192, 5), (1, 400, 6), (2, 265, 24)])   # key-tile counts = 3 (mod 4): the
+                                   # output staging wraps around the ring (round 4 fix); 265 = uni_v2
 def test_attention_vs_torch(env, dt, tol, shape):
     """|out| <= 6: half an ulp of the output + the rounding of P to the MFMA operand type."""
     _lib, lib, dev, stream = env
@@ -255,6 +257,21 @@ def test_attention_vs_torch(env, dt, tol, shape):
     _lib.check(lib.ap_attention(_lib.torch_dtype_code(dt), qkv.data_ptr(), out.data_ptr(), n, T, H, 64, stream))
     torch.cuda.synchronize()
     assert (out.float() - _attn_ref(qkv, n, T, H)).abs().max().item() <= tol
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float16, 4e-3), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("shape", [(2, 197, 4), (1, 1370, 16), (3, 50, 2), (1, 150, 3), (2, 448, 5), (9, 1, 1), (1, 2000, 1)])
+def test_attention_128_wide_heads_vs_torch(env, dt, tol, shape):
+    """The HD = 128 instantiation of the tiled kernel (vit_h_14's 80-wide heads are stored zero-padded to 128): full 128-wide
+    random heads against torch, incl. 1370 tokens (vit_h_14 at 518 px) and key-tile counts of every residue mod 4."""
+    _lib, lib, dev, stream = env
+    n, T, H = shape
+    g = torch.Generator(device=dev).manual_seed(T + 7)
+    qkv = (torch.randn((n * T, 3 * H * 128), device=dev, generator=g) * 1.2).to(dt)
+    out = torch.full((n * T, H * 128), float("nan"), device=dev, dtype=dt)
+    _lib.check(lib.ap_attention(_lib.torch_dtype_code(dt), qkv.data_ptr(), out.data_ptr(), n, T, H, 128, stream))
+    torch.cuda.synchronize()
+    assert (out.float() - _attn_ref(qkv, n, T, H, 128)).abs().max().item() <= tol
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.float16, 4e-3), (torch.bfloat16, 3e-2)])
@@ -281,7 +298,8 @@ def test_operator_error_paths(env):
     assert lib.ap_gemm(1, 0, None, 0, None, 0, 1, 1, 1, None, None, None, 0, 0, 0, stream) == -1
     assert lib.ap_gemm(1, 7, x.data_ptr(), 128, x.data_ptr(), 128, 4, 128, 128, x.data_ptr(), None, x.data_ptr(), 128, 0, 0,
                        stream) == -1
-    assert lib.ap_attention(1, x.data_ptr(), x.data_ptr(), 1, 4, 1, 32, stream) == -1     # head_dim != 64
+    assert lib.ap_attention(1, x.data_ptr(), x.data_ptr(), 1, 4, 1, 32, stream) == -1     # head_dim not 64 / 128
+    assert lib.ap_attention(0, x.data_ptr(), x.data_ptr(), 1, 4, 1, 128, stream) == -1    # 128-wide heads: f16 / bf16 only
     assert b"head_dim" in lib.ap_last_error()
     # fused-LayerNorm operators: missing operands, float32, bad kernel choice, shapes the persistent kernel cannot take
     h = torch.zeros((256, 256), device=dev, dtype=torch.float16)

@@ -36,6 +36,13 @@ ENCODERS = {
     "uni_v1": {"label": "UNI v1 (ViT-L/16 + LayerScale, Resize(224, bicubic) on the device)", "batch": 2048},
     "conch_v1": {"label": "CONCH v1 visual tower (ViT-B/16 at 448 px = 785 tokens + attentional pooler, Resize(448, bicubic) "
                           "on the device)", "batch": 256, "mean": OPENAI_CLIP_MEAN, "std": OPENAI_CLIP_STD},
+    # the rest of the reference's three encoder files (round 4)
+    "vit_b_32": {"label": "ViT-B/32 (50 tokens)", "batch": 4096},
+    "vit_l_32": {"label": "ViT-L/32 (50 tokens)", "batch": 4096},
+    "vit_h_14": {"label": "ViT-H/14 at torchvision's SWAG_E2E 518 px (1370 tokens, 80-wide heads stored 128 wide, Resize(518, "
+                          "bicubic) on the device)", "batch": 128},
+    "uni_v2": {"label": "UNI2-h (ViT-H/14 at 224 px, 8 register tokens, SwiGLU, LayerScale; Resize(224, bicubic) on the device)",
+               "batch": 1024},
 }
 
 
@@ -43,18 +50,20 @@ def encoder_geometry(arch):
     """Tokens and algorithmic FLOP per tile (2*M*N*K per linear, 4*T^2*D per attention): `model` = every
     block for every token, `executed` = what this build runs (CLS-pooled encoders: the last block computes K / V for every
     token and everything after that for the CLS row only -- DESIGN.md section 3 -- identical features)."""
-    T = 1 + (arch["image_size"] // arch["patch_size"]) ** 2
+    P_ = (arch["image_size"] // arch["patch_size"]) ** 2
+    T = 1 + int(arch.get("reg_tokens", 0)) + P_
     D, mlp, L = arch["dim"], arch["mlp_dim"], arch["depth"]
-    patch_embed = 2.0 * (T - 1) * D * 3 * arch["patch_size"] ** 2
-    block = 2.0 * T * (4 * D * D + 2 * D * mlp) + 4.0 * T * T * D
+    mlp_w = 3 * D * mlp if arch.get("mlp") == "swiglu" else 2 * D * mlp          # SwiGLU packed: fc1 is [2 mlp, D]
+    patch_embed = 2.0 * P_ * D * 3 * arch["patch_size"] ** 2
+    block = 2.0 * T * (4 * D * D + mlp_w) + 4.0 * T * T * D                      # algorithmic: true head width
     model = patch_embed + L * block
     executed = model
     if arch.get("pool") == "attn":
         P = arch["pool_dim"]
         model += 2.0 * T * D * 2 * P + 4.0 * T * P + 2.0 * P * P
         executed = model
-    elif D // arch["heads"] == 64:
-        executed = model - block + 2.0 * T * D * 2 * D + 2.0 * (2 * D * D + 2 * D * mlp) + 4.0 * T * D
+    else:
+        executed = model - block + 2.0 * T * D * 2 * D + 2.0 * (2 * D * D + mlp_w) + 4.0 * T * D
     return {"tokens": T, "model": model, "executed": executed}
 
 
@@ -73,7 +82,8 @@ def parse_args():
                     help="synthetic slide side in pixels (default: 40000 = BASELINE config 2 at N = 1, "
                          "100000 = config 4 for N > 1)")
     ap.add_argument("--encoder", default="vit_b_16", choices=sorted(ENCODERS),
-                    help="registered encoder of the forward (vit_b_16 = configs 2 / 4, uni_v1 = config 3, conch_v1 = config 5)")
+                    help="registered encoder of the forward (vit_b_16 = configs 2 / 4, uni_v1 = config 3, conch_v1 = config 5; "
+                         "vit_b_32 / vit_l_32 / vit_h_14 / uni_v2 = the rest of the reference's encoder files)")
     ap.add_argument("--slide-seed", type=int, default=1234, help="rank r embeds the synthetic slide of seed SLIDE_SEED + r")
     ap.add_argument("--dump-features", default=None,
                     help="rank 0 saves the float32 feature matrix of the timed steps (the gathered [N*K*B, D] matrix for N > 1) "
@@ -625,7 +635,7 @@ def main():
     if args.batch is None:
         args.batch = enc["batch"]
     geo = encoder_geometry(arch)
-    T, D, MLP = geo["tokens"], arch["dim"], arch["mlp_dim"]
+    T, D, MLP = geo["tokens"], arch["dim"], arch["mlp_dim"] * (2 if arch.get("mlp") == "swiglu" else 1)   # fc1 rows
     ex = build_hip_vit_extractor(name=args.encoder, arch=args.encoder, device=device, dtype=dtype,
                                  random_init_seed=0, max_batch=args.batch, resize=TRANSFORM_RESIZE[args.encoder],
                                  expect_size=None, mean=enc.get("mean"), std=enc.get("std"))
@@ -846,7 +856,8 @@ def main():
         line["all_gather"] = {"bytes_per_rank": int(K * B * ex.embedding_dim * 4), "ms_max_over_ranks": max(r["all_gather_ms"] for r in per_rank),
                               "what": "one all_gather_into_tensor of every rank's float32 [K*B, D] block, inside the timed region"}
     if not args.no_cpu_baseline and world == 1:          # the CPU leg runs at N = 1 only
-        sample = args.cpu_sample if args.cpu_sample else {"vit_b_16": 192, "uni_v1": 64, "conch_v1": 32}[args.encoder]
+        sample = args.cpu_sample if args.cpu_sample else {"vit_b_16": 192, "uni_v1": 64, "conch_v1": 32, "vit_b_32": 256,
+                                                          "vit_l_32": 128, "vit_h_14": 4, "uni_v2": 24}[args.encoder]
         out_cpu, patches, cpu_rate, cpu_threads = cpu_baseline(args.encoder, sample, seed=0)
         # parity of the measured path against the CPU oracle on the same sample (reported, not timed)
         relf = lambda got: float(np.linalg.norm(got.astype(np.float64) - out_cpu) / np.linalg.norm(out_cpu))
@@ -865,7 +876,8 @@ def main():
                 errs["f32_stream_" + short] = relf(ex.extract_batch(patches, batch_size=32))
             finally:
                 ex.vit.set_option("f32_stream", False)
-        if short != "f32" and arch.get("pool") != "attn":          # conch_v1 is registered for f16 / bf16 only
+        f32_ok = arch.get("pool") != "attn" and geo["tokens"] <= 288 and arch["dim"] // arch["heads"] == 64
+        if short != "f32" and f32_ok:          # conch_v1 / vit_h_14: f16 / bf16 only (the f32 attention kernel: 288 tokens, 64 wide)
             ex32 = build_hip_vit_extractor(name=args.encoder, arch=args.encoder, device=device, dtype=torch.float32,
                                            random_init_seed=0, max_batch=min(B, 256), resize=TRANSFORM_RESIZE[args.encoder],
                                            expect_size=None, mean=enc.get("mean"), std=enc.get("std"))

@@ -147,6 +147,14 @@ class ProcessingRunner:
         open_cap = max(1, int(self.config.extraction.max_open_slides or 200))
         pool = futures.ThreadPoolExecutor(max_workers=max(1, int(workers)), thread_name_prefix="coords")
         inflight: list = []
+        # cohorts: the per-slide coords files are written by helper processes (one libhdf5 lock per process instead of one for
+        # all coordinate workers); started in the background now, used as soon as they answer (services/h5_writer_proc.py)
+        if len(slides) >= 8 and hasattr(self.extractor, "h5_pool"):
+            from ..services.h5_writer_proc import shared_pool
+            h5_pool = shared_pool()
+            if h5_pool is not None:
+                h5_pool.prestart()
+                self.extractor.h5_pool = h5_pool
 
         def drain(item):
             slide, fut = item

@@ -80,6 +80,7 @@ class PatchExtractionService(ExtractionService):
     def __init__(self, extraction_cfg: ExtractionConfig, output_cfg: OutputConfig) -> None:
         self.cfg = extraction_cfg.validated()
         self.output_cfg = output_cfg.validated()
+        self.h5_pool = None            # services/h5_writer_proc.H5WriterPool for cohort runs (set by the runner), else in-process
 
     def geometry(self, wsi: IWSI) -> PatchGeometry:
         return prepare_geometry(wsi, patch_size=self.cfg.patch_size, step_size=self.cfg.step_size,
@@ -115,7 +116,14 @@ class PatchExtractionService(ExtractionService):
                                overlap=max(0, int(self.cfg.patch_size) - int(step)),
                                slide_stem=slide.stem, wsi_path=str(wsi.path), extra_file_attrs=extra)
         with stage("h5_coords"):
-            total = writer.write_coords_array(out_h5, coords)
+            # cohort runs hand the file to a helper process (libhdf5 is one lock per process: services/h5_writer_proc.py);
+            # same writer class, same bytes.  No helper ready / pool off: written here
+            total = None
+            pool = self.h5_pool
+            if pool is not None and pool.ready():
+                total = pool.write(writer.to_kwargs(), str(out_h5), coords, writer.passports_array(coords))
+            if total is None:
+                total = writer.write_coords_array(out_h5, coords)
         logger.debug("Wrote %d coords for %s to %s", total, slide.path.name, out_h5)
         return ExtractionResult(slide=slide, h5_path=Path(out_h5), num_patches=int(total), image_dir=img_dir,
                                 coords=None, patch_size_level0=geometry.patch_size_level0)

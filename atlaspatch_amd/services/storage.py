@@ -42,6 +42,13 @@ class H5PatchWriter:
         self.extra_file_attrs = dict(extra_file_attrs) if extra_file_attrs else {}
         self._passport_dtype = np.dtype("S160")
 
+    def to_kwargs(self) -> dict:
+        """Constructor arguments of an equal writer (what a helper process needs: services/h5_writer_proc.py)."""
+        return dict(chunk_rows=self.chunk_rows, patch_size=self.patch_size, patch_size_level0=self.patch_size_level0,
+                    level0_mag=self.level0_mag, target_mag=self.target_mag, level0_wh=tuple(int(v) for v in self.level0_wh),
+                    overlap=self.overlap, slide_stem=self.slide_stem, wsi_path=self.wsi_path, total_patches=self.total_patches,
+                    extra_file_attrs=dict(self.extra_file_attrs))
+
     # ------------------------------------------------------------------ coords
     def _passport(self, x: int, y: int, rw: int, rh: int, lv: int) -> str:
         if self.total_patches is None:
@@ -85,16 +92,27 @@ class H5PatchWriter:
         writer.update_file_attrs(attrs)
         return writer
 
-    def write_coords_array(self, output_path, coords: np.ndarray) -> int:
-        """Bulk form of ``write_coords``: coords int32 [N, 5] already in the reference's order."""
+    def passports_array(self, coords: np.ndarray) -> np.ndarray:
+        """S160 passports of all rows (``total_patches`` = the row count), as ``write_coords_array`` writes them."""
         coords = np.ascontiguousarray(coords, dtype=np.int32).reshape(-1, 5)
         self.total_patches = int(coords.shape[0])
+        if coords.shape[0] == 0:
+            return np.empty((0,), dtype=self._passport_dtype)
+        return self._passports(coords)
+
+    def write_coords_array(self, output_path, coords: np.ndarray, passports: np.ndarray | None = None) -> int:
+        """Bulk form of ``write_coords``: coords int32 [N, 5] already in the reference's order.  ``passports``: the S160
+        strings of these rows when the caller has formatted them already (the helper processes of a cohort run)."""
+        coords = np.ascontiguousarray(coords, dtype=np.int32).reshape(-1, 5)
+        self.total_patches = int(coords.shape[0])
+        if passports is not None and (passports.shape != (coords.shape[0],) or passports.dtype != self._passport_dtype):
+            raise ValueError("passports must be S160 [N]")
         writer = self._open_seeded(Path(output_path))
         try:
             for start in range(0, coords.shape[0], self.chunk_rows):
                 block = coords[start:start + self.chunk_rows]
-                passports = self._passports(block)
-                writer.append({"coords": block, "passports": passports})
+                pp = self._passports(block) if passports is None else passports[start:start + self.chunk_rows]
+                writer.append({"coords": block, "passports": pp})
             writer.update_file_attrs({"num_patches": int(coords.shape[0])})
             writer.close()
         except Exception:

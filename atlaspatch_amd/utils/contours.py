@@ -8,6 +8,7 @@ border following in host C++); there is no Python/NumPy fallback.
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import Optional, Sequence
 
 import numpy as np
@@ -16,6 +17,26 @@ from .. import _lib
 
 DEFAULT_FILTER_PARAMS = {"a_h": 16, "max_n_holes": 10}
 
+_tls = threading.local()
+
+
+def worker_stream() -> int:
+    """HIP stream of the coordinate kernels for the calling thread.  The main thread stays on stream 0 (ordered with everything
+    else it launches).  A worker thread (the runner's coordinate pool) gets its own NON-blocking stream, created once per
+    thread: on the legacy stream its threshold / grid kernels and copies queued behind the segmenter's graph replays -- a
+    worker's stream synchronisation then waited for forwards it has nothing to do with (18 ms of thread time per slide for
+    2 ms of work).  The inputs are host arrays and every call ends with its own synchronisation, so no cross-stream ordering
+    is needed."""
+    if threading.current_thread() is threading.main_thread():
+        return 0
+    st = getattr(_tls, "stream", None)
+    if st is None:
+        import torch
+        if not torch.cuda.is_available():
+            return 0
+        st = _tls.stream = torch.cuda.Stream()          # hipStreamNonBlocking
+    return int(st.cuda_stream)
+
 
 class DeviceContours:
     """Owns an ``ap_contours`` handle: filtered, ordered tissue contours + holes, with their
@@ -23,8 +44,9 @@ class DeviceContours:
 
     def __init__(self, mask: np.ndarray, *, tissue_area_thresh: float = 0.01,
                  filter_params: Optional[dict] = None, sx: float = 1.0, sy: float = 1.0,
-                 stream: int = 0) -> None:
+                 stream: Optional[int] = None) -> None:
         self.lib = _lib.load()
+        self._stream = worker_stream() if stream is None else int(stream)
         params = dict(DEFAULT_FILTER_PARAMS if filter_params is None else filter_params)
         mask = np.ascontiguousarray(mask, dtype=np.float32)
         if mask.ndim != 2:
@@ -34,7 +56,7 @@ class DeviceContours:
         _lib.check(self.lib.ap_contours_from_mask(
             mask.ctypes.data_as(C.c_void_p), mask.shape[0], mask.shape[1], float(tissue_area_thresh),
             int(params.get("a_h", 0)), int(params.get("max_n_holes", 0)), float(sx), float(sy),
-            C.byref(handle), C.c_void_p(stream)), "ap_contours_from_mask")
+            C.byref(handle), C.c_void_p(self._stream)), "ap_contours_from_mask")
         self._handle = handle
 
     def __len__(self) -> int:
@@ -61,8 +83,9 @@ class DeviceContours:
         return tissue, holes
 
     def grid_coords(self, *, patch_size_src: int, step_src: int, read_wh: Sequence[int], level: int,
-                    stream: int = 0) -> np.ndarray:
+                    stream: Optional[int] = None) -> np.ndarray:
         """int32 [N, 5] rows (x, y, read_w, read_h, level) in the reference's order."""
+        stream = self._stream if stream is None else int(stream)
         total = C.c_size_t(0)
         cap = 1 << 16
         while True:

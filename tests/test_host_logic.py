@@ -684,3 +684,47 @@ def test_h5_backend_survives_concurrent_writers_and_readers(tmp_path):
 
     with futures.ThreadPoolExecutor(16) as pool:
         assert all(n > 0 for n in pool.map(work, range(32)))
+
+
+def test_h5_writer_processes_write_the_same_file_as_the_in_process_writer(tmp_path):
+    """services/h5_writer_proc.py: cohort runs hand each slide's coords file to a helper process (libhdf5 is one lock per
+    process).  Same H5PatchWriter code in the child -> same datasets, chunking and attributes; a broken pool means None (the
+    caller writes in-process)."""
+    import time
+    from atlaspatch_amd.services.h5_writer_proc import H5WriterPool
+    from atlaspatch_amd.services.storage import H5PatchWriter
+    from atlaspatch_amd.utils.h5 import h5
+    rng = np.random.default_rng(5)
+    n = 20001
+    coords = np.stack([rng.integers(0, 99000, n), rng.integers(0, 99000, n), np.full(n, 256), np.full(n, 256), np.zeros(n, int)], 1).astype(np.int32)
+
+    def mk():
+        return H5PatchWriter(chunk_rows=8192, patch_size=256, patch_size_level0=256, level0_mag=20, target_mag=20,
+                             level0_wh=(100000, 99000), overlap=0, slide_stem="slide_a", wsi_path="/data/slide_a.svs",
+                             extra_file_attrs={"filename": "slide_a.svs", "mpp": 0.5, "vendor": "synthetic"})
+    pool = H5WriterPool(2)
+    assert pool.write({}, "x", coords, np.zeros(n, "S160")) is None and not pool.ready()      # nothing started yet: in-process
+    pool.prestart()
+    t0 = time.time()
+    while not pool.ready() and time.time() - t0 < 60:
+        time.sleep(0.02)
+    assert pool.ready()
+    w = mk()
+    assert pool.write(w.to_kwargs(), str(tmp_path / "proc.h5"), coords, w.passports_array(coords)) == n
+    assert pool.write(mk().to_kwargs(), str(tmp_path / "empty.h5"), coords[:0], mk().passports_array(coords[:0])) == 0
+    with pytest.raises(RuntimeError, match="h5 writer process"):                               # an error in the child is reported
+        pool.write(mk().to_kwargs(), str(tmp_path / "no_such_dir" / "x.h5"), coords, mk().passports_array(coords))
+    assert pool.write(mk().to_kwargs(), str(tmp_path / "again.h5"), coords[:7], mk().passports_array(coords[:7])) == 7   # and the child lives on
+    pool.close()
+    assert mk().write_coords_array(tmp_path / "here.h5", coords) == n
+    with h5.File(tmp_path / "proc.h5", "r") as a, h5.File(tmp_path / "here.h5", "r") as b:
+        for name in ("coords", "passports"):
+            assert a[name].shape == b[name].shape and a[name].dtype == b[name].dtype and a[name].chunks == b[name].chunks
+            assert a[name].maxshape == b[name].maxshape and np.array_equal(a[name][:], b[name][:])
+        assert sorted(a.attrs.keys()) == sorted(b.attrs.keys())
+        for k in a.attrs.keys():
+            if k != "creation_date":
+                assert a.attrs[k] == b.attrs[k], k
+    with h5.File(tmp_path / "empty.h5", "r") as e:
+        assert e["coords"].shape == (0, 5) and e.attrs["num_patches"] == 0
+    assert not [p for p in tmp_path.iterdir() if ".tmp." in p.name]

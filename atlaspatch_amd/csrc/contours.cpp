@@ -84,19 +84,6 @@ void follow(std::vector<int32_t>& img, int stride, int start, bool is_hole, int 
     }
 }
 
-double shoelace_area(const std::vector<int32_t>& xy) {
-    const size_t n = xy.size() / 2;
-    if (n == 0) return 0.0;
-    double a = 0.0;
-    double px = (double)xy[2 * (n - 1)], py = (double)xy[2 * (n - 1) + 1];
-    for (size_t i = 0; i < n; ++i) {
-        const double x = (double)xy[2 * i], y = (double)xy[2 * i + 1];
-        a += px * y - py * x;
-        px = x; py = y;
-    }
-    return std::fabs(a * 0.5);
-}
-
 }  // namespace
 
 // binary: h*w bytes (non-zero = tissue).  Fills `out` with the filtered, ordered contour set.
@@ -143,6 +130,28 @@ void contours_from_binary(const uint8_t* binary, int h, int w, double tissue_are
         }
     }
 
+    std::vector<BorderSummary> summary(found.size());
+    for (size_t k = 0; k < found.size(); ++k) {
+        const std::vector<int32_t>& xy = found[k].xy;
+        const size_t n = xy.size() / 2;
+        long long a2 = 0;
+        if (n) {
+            long long px = xy[2 * (n - 1)], py = xy[2 * (n - 1) + 1];
+            for (size_t i = 0; i < n; ++i) {
+                const long long x = xy[2 * i], y = xy[2 * i + 1];
+                a2 += px * y - py * x;
+                px = x; py = y;
+            }
+        }
+        summary[k] = {0, found[k].is_hole ? 1 : 0, (int)n, found[k].parent, a2};
+    }
+    Selection sel;
+    select_contours(summary, h, w, tissue_area_thresh, min_hole_area, max_n_holes, sel);
+    build_contour_set(sel, sx, sy, [&](int d) { return found[d].xy; }, out);
+}
+
+void select_contours(const std::vector<BorderSummary>& found, int h, int w, double tissue_area_thresh, int min_hole_area,
+                     int max_n_holes, Selection& sel) {
     // RETR_CCOMP: a hole's parent (Suzuki tree) is already the outer border of its component.
     // flat order: outer borders in reverse discovery order, each followed by its holes reversed.
     const int nb = (int)found.size();
@@ -151,7 +160,7 @@ void contours_from_binary(const uint8_t* binary, int h, int w, double tissue_are
     for (int k = 0; k < nb; ++k) {
         if (!found[k].is_hole) { top.push_back(k); continue; }
         int par = found[k].parent;
-        if (par < 0 || found[par].is_hole) {       // cannot happen for a well-formed scan; stay safe
+        if (par < 0 || par >= nb || found[par].is_hole) {       // cannot happen for a well-formed scan; stay safe
             par = -1;
             for (int j = k - 1; j >= 0 && par < 0; --j) if (!found[j].is_hole) par = j;
             if (par < 0) continue;
@@ -167,14 +176,15 @@ void contours_from_binary(const uint8_t* binary, int h, int w, double tissue_are
         for (auto it = kids[k].rbegin(); it != kids[k].rend(); ++it) flat.push_back({*it, me});
     }
 
-    // ---- mask_to_contours filters (contours.py:80-114)
+    // ---- mask_to_contours filters (contours.py:80-114).  cv2.contourArea = |shoelace / 2| in float64: the sums are integers
+    // far below 2^53, so the exact integer sum converted once equals OpenCV's running double sum
     const double min_area = tissue_area_thresh * (double)((double)h * (double)w);
     const double hole_thr = (double)min_hole_area;
     std::vector<double> area(flat.size());
     std::vector<int> tissue_flat;                       // flat indices kept as tissue
     std::vector<int> hole_flat;                         // holes passing the area test, flat order
     for (size_t i = 0; i < flat.size(); ++i) {
-        area[i] = shoelace_area(found[flat[i].disc].xy);
+        area[i] = std::fabs((double)found[flat[i].disc].area2 * 0.5);
         if (flat[i].parent_flat < 0) {
             if (area[i] >= min_area) tissue_flat.push_back((int)i);
         } else if (area[i] >= hole_thr) {
@@ -188,29 +198,14 @@ void contours_from_binary(const uint8_t* binary, int h, int w, double tissue_are
         std::fill(allowed.begin(), allowed.end(), 0);
         for (int i = 0; i < max_n_holes; ++i) allowed[ranked[i]] = 1;
     }
-
-    out.polys.clear();
-    out.tissue.clear();
-    auto push_poly = [&](int flat_idx) {
-        Polygon pg;
-        pg.raw = found[flat[flat_idx].disc].xy;
-        pg.scaled.resize(pg.raw.size());
-        const float fsx = (float)sx, fsy = (float)sy;      // numpy: f32 array *= python float
-        for (size_t i = 0; i + 1 < pg.raw.size(); i += 2) {
-            volatile float vx = (float)pg.raw[i] * fsx;
-            volatile float vy = (float)pg.raw[i + 1] * fsy;
-            pg.scaled[i] = (int32_t)vx;                      // astype(int32): truncation
-            pg.scaled[i + 1] = (int32_t)vy;
-        }
-        out.polys.push_back(std::move(pg));
-        return (int)out.polys.size() - 1;
-    };
+    sel.tissue.clear();
+    sel.holes.clear();
     for (int ti : tissue_flat) {
-        Tissue t;
-        t.poly = push_poly(ti);
+        sel.tissue.push_back(flat[ti].disc);
+        std::vector<int> hs;
         for (int hf : hole_flat)
-            if (flat[hf].parent_flat == ti && allowed[hf]) t.holes.push_back(push_poly(hf));
-        out.tissue.push_back(std::move(t));
+            if (flat[hf].parent_flat == ti && allowed[hf]) hs.push_back(flat[hf].disc);
+        sel.holes.push_back(std::move(hs));
     }
 }
 

@@ -24,6 +24,7 @@
 #include <vector>
 #include "ap_common.h"
 #include "coords_internal.h"
+#include "coords_arena.h"
 
 struct ap_contours {
     ap::ContourSet set;
@@ -288,51 +289,6 @@ __global__ __launch_bounds__(256) void compact_kernel(const uint8_t* __restrict_
     }
 }
 
-// Scratch buffers of one call.  hipMalloc / hipFree per call cost more than the kernels here, and hipFree synchronises the whole
-// DEVICE: with eight coordinate workers beside the segmenter's graph replays every slide stalled every other thread's queue.
-// Each calling thread therefore keeps one grow-only arena per device (thread_local; released when the thread exits); a call
-// carves its buffers from it in order and the arena is reset when the call returns (every call ends with a stream
-// synchronisation, so nothing is in flight then).  Growth = one new, larger allocation; the old one is freed at the next reset.
-struct Arena {
-    char* base = nullptr; size_t cap = 0, used = 0; int device = -1;
-    std::vector<void*> retired;        // outgrown blocks, still referenced by the running call
-    ~Arena() { int d = 0; if (hipGetDevice(&d) == hipSuccess) release(); }      // (no runtime left at process exit: nothing to free)
-    void release() {
-        if (base) (void)hipFree(base);
-        for (void* p : retired) (void)hipFree(p);
-        base = nullptr; cap = used = 0; retired.clear();
-    }
-    void reset() {
-        used = 0;
-        for (void* p : retired) (void)hipFree(p);
-        retired.clear();
-    }
-    int take(size_t bytes, void** out) {
-        int dev = 0;
-        AP_HIP_CHECK(hipGetDevice(&dev));
-        if (dev != device) { release(); device = dev; }
-        bytes = (bytes + 255) & ~(size_t)255;
-        if (used + bytes > cap) {
-            // buffers handed out earlier in this call stay valid in the retired block; the new block starts empty
-            const size_t want = (cap * 2 > used + bytes ? cap * 2 : used + bytes) + (1u << 20);
-            void* p = nullptr;
-            AP_HIP_CHECK(hipMalloc(&p, want));
-            if (base) retired.push_back(base);
-            base = (char*)p; cap = want; used = 0;
-        }
-        *out = base + used;
-        used += bytes;
-        return AP_OK;
-    }
-};
-inline Arena& arena() { thread_local Arena a; return a; }
-struct ArenaScope { ~ArenaScope() { arena().reset(); } };
-
-template <typename T> struct DevBuf {
-    T* p = nullptr;
-    int alloc(size_t n) { return arena().take((n ? n : 1) * sizeof(T), (void**)&p); }
-};
-
 }  // namespace
 }  // namespace ap
 
@@ -352,10 +308,19 @@ int ap_contours_from_mask(const float* mask, int h, int w, double tissue_area_th
     AP_HIP_CHECK(hipMemcpyAsync(dmask.p, mask, count * sizeof(float), hipMemcpyHostToDevice, s));
     ap::threshold_kernel<<<(unsigned)((count / 4 + 256) / 256), 256, 0, s>>>(dmask.p, dbin.p, count);
     AP_HIP_CHECK(hipGetLastError());
+    ap_contours* c = new ap_contours();
+    // border following on the device (contours_device.hip: component labelling + one thread per border on an LDS bit image);
+    // AP_CONTOURS_HOST=1, or a mask too large for the LDS image, takes the host form (contours.cpp) -- same ContourSet
+    const bool host_form = getenv("AP_CONTOURS_HOST") != nullptr;          // read per call: the tests flip it in-process
+    if (!host_form && ap::contours_device_supported(h, w)) {
+        rc = ap::contours_from_binary_device(dbin.p, h, w, tissue_area_thresh, min_hole_area, max_n_holes, sx, sy, c->set, (void*)s);
+        if (rc != AP_OK) { delete c; return rc; }
+        *out = c;
+        return AP_OK;
+    }
     std::vector<uint8_t> bin(count);
     AP_HIP_CHECK(hipMemcpyAsync(bin.data(), dbin.p, count, hipMemcpyDeviceToHost, s));
     AP_HIP_CHECK(hipStreamSynchronize(s));
-    ap_contours* c = new ap_contours();
     ap::contours_from_binary(bin.data(), h, w, tissue_area_thresh, min_hole_area, max_n_holes, sx, sy, c->set);
     *out = c;
     return AP_OK;

@@ -81,3 +81,28 @@ def test_encoder_option_runs_conch_fp16_with_its_own_roofline_shape():
     assert line["roofline"]["algorithmic_flop_per_launch"] == 2.0 * 32 * 785 * 3072 * 768
     assert 0 < line["roofline"]["frac"] < 1 and line["value"] > 0
     assert line["cpu_baseline"]["rel_err_gpu_vs_cpu"] < 3e-3
+
+
+@pytest.mark.gpu
+def test_gpus_8_rehearsal_eight_ranks_on_one_device(tmp_path):
+    """The shape of BASELINE configs 4 / 5 (8 ranks, slide-per-rank, one all-gather) run as eight processes that share this
+    box's one GPU (gloo): ports, per-rank slide seeds, the gathered matrix's block order and `_pin_order`'s per-local-rank core
+    split all execute before a real 8-GPU lease does.  Small batch: 8 x (weights + workspace of 16 tiles) fits easily."""
+    common = ["--steps", "1", "--warmup", "1", "--batch", "16", "--slide", "12000", "--no-extras", "--no-cpu-baseline"]
+    line = _run(["--gpus", "8", "--dump-features", str(tmp_path / "g8.npy")] + common, timeout=1500)
+    assert line["n_gpus"] == 8 and line["config"]["ranks_in_process_group"] == 8 and line["scaling"] == "weak"
+    assert [r["rank"] for r in line["per_rank"]] == list(range(8))
+    assert [r["slide_seed"] for r in line["per_rank"]] == [1234 + r for r in range(8)]
+    assert line["all_gather"]["bytes_per_rank"] == 16 * 768 * 4 and line["value"] > 0
+    g = np.load(tmp_path / "g8.npy")
+    assert g.shape == (8 * 16, 768) and np.isfinite(g).all()
+    blocks = [g[r * 16:(r + 1) * 16] for r in range(8)]
+    assert all(np.abs(b).max() > 0 for b in blocks)
+    assert all(not np.array_equal(blocks[0], b) for b in blocks[1:])          # every rank embedded its own slide
+    one = _run(["--gpus", "1", "--slide-seed", "1239", "--dump-features", str(tmp_path / "s5.npy")] + common)
+    assert np.array_equal(np.load(tmp_path / "s5.npy"), blocks[5]) and one["n_gpus"] == 1     # rank 5's block = its single-rank run
+    from atlaspatch_amd.services.tile_ring import _pin_order
+    import torch
+    orders = [_pin_order(torch.device("cuda:0"), local_rank=r, local_world=8) for r in range(8)]
+    firsts = [o[0] for o in orders if o]
+    assert len(set(firsts)) == len(firsts)                                    # the ranks' first choices are distinct cores

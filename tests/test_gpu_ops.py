@@ -638,7 +638,8 @@ def test_clock_probe_reports_a_plausible_shader_clock():
         probe.stop()
         torch.cuda.synchronize(dev)
     info = probe.read()
-    assert info["xcds"] >= 1 and 0.3 <= info["min_GHz"] <= info["shader_clock_GHz"] <= info["max_GHz"] <= 2.6, info
-    # (the XCDs are separate clock domains: 1.44 ... 1.67 GHz were seen inside one 0.7-s bench region)
+    # (the XCDs are separate clock domains -- 1.44 ... 1.67 GHz were seen inside one 0.7-s bench region -- and an XCD with
+    # nothing to do may be clock-gated for part of a short region: only the median is held to the part's range)
+    assert info["xcds"] >= 1 and 0.3 <= info["shader_clock_GHz"] <= 2.6 and info["max_GHz"] <= 2.6, info
     s = ps.summary()
     assert s["samples"] == 0 or 20.0 <= s["package_W_mean"] <= 2000.0, s

@@ -588,6 +588,91 @@ def test_coords_and_contours_random_masks_vs_oracle(seed):
     assert np.array_equal(got, want)
 
 
+def _contours_host_form(mask, thresh):
+    """The host border following (csrc/contours.cpp) on the same mask, in a fresh process (AP_CONTOURS_HOST is read once)."""
+    import json, os, subprocess, sys, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as tmp:
+        np.save(os.path.join(tmp, "m.npy"), mask)
+        code = ("import numpy as np, json, sys; sys.path.insert(0, %r); from atlaspatch_amd.utils.contours import mask_to_contours; "
+                "t, h = mask_to_contours(np.load(%r), tissue_area_thresh=%r); "
+                "np.savez(%r, n=len(t), **{f't{i}': a.reshape(-1, 2) for i, a in enumerate(t)}, "
+                "**{f'h{i}_{j}': b.reshape(-1, 2) for i, hs in enumerate(h) for j, b in enumerate(hs)}, "
+                "nh=np.array([len(x) for x in h], dtype=np.int64))") % (root, os.path.join(tmp, "m.npy"), thresh, os.path.join(tmp, "o.npz"))
+        env = dict(os.environ, AP_CONTOURS_HOST="1")
+        subprocess.run([sys.executable, "-c", code], check=True, env=env, timeout=600)
+        z = np.load(os.path.join(tmp, "o.npz"))
+        n = int(z["n"])
+        return [z[f"t{i}"] for i in range(n)], [[z[f"h{i}_{j}"] for j in range(int(z["nh"][i]))] for i in range(n)]
+
+
+@pytest.mark.parametrize("case", ["noise_1024", "blobs_1024", "rings", "thin_walls", "nested", "full", "empty", "single", "frame_touch",
+                                  "checker", "odd_733x1024", "diag_chains"])
+def test_device_border_following_equals_the_host_form(case):
+    """contours_device.hip (component labelling + one thread per border on an LDS bit image) against contours.cpp (Suzuki-Abe
+    raster scan with marks) on masks built to break the restatement: one-pixel rings (the hole's start pixel lies on the outer
+    border too), islands in holes in islands, diagonal-only contacts, holes that only touch the frame diagonally, 4- vs
+    8-connectivity checkerboards, a CMU-1-shaped 733 x 1024 mask, pure noise at 1024 x 1024 (~10^5 borders).  Same contours,
+    same order, same points."""
+    from scipy import ndimage
+    from atlaspatch_amd.utils.contours import mask_to_contours
+    rng = np.random.default_rng(77)
+    thresh = 0.0
+    if case == "noise_1024":
+        m = rng.random((1024, 1024)) < 0.5
+    elif case == "blobs_1024":
+        f = ndimage.gaussian_filter(rng.standard_normal((1024, 1024)), 14.0)
+        m = (f > np.quantile(f, 0.55)) & (rng.random((1024, 1024)) < 0.995)
+        thresh = 0.001
+    elif case == "rings":
+        m = np.zeros((96, 130), bool)
+        for k, (y, x, r) in enumerate([(20, 20, 8), (20, 60, 3), (60, 40, 15), (60, 100, 2), (30, 110, 1)]):
+            yy, xx = np.mgrid[0:96, 0:130]
+            d = np.maximum(abs(yy - y), abs(xx - x))
+            m |= d == r                                      # one-pixel square rings
+        m[60, 40] = True                                     # island in a ring
+    elif case == "thin_walls":
+        m = np.ones((64, 64), bool)
+        m[2:62:4, 2:62] = False                              # stripes separated by one-pixel walls
+        m[:, 31] = True
+    elif case == "nested":
+        m = np.zeros((120, 120), bool)
+        for k, r in enumerate(range(55, 4, -6)):
+            m[60 - r:60 + r, 60 - r:60 + r] = k % 2 == 0     # island in hole in island ...
+    elif case == "full":
+        m = np.ones((50, 70), bool)
+    elif case == "empty":
+        m = np.zeros((50, 70), bool)
+    elif case == "single":
+        m = np.zeros((9, 9), bool); m[4, 4] = True; m[0, 0] = True; m[8, 8] = True; m[0, 8] = True
+    elif case == "frame_touch":
+        m = np.ones((40, 40), bool)
+        m[0, 5] = False; m[1, 6] = False                     # background pixel on the frame + a diagonal neighbour (a real hole)
+        m[39, 10:20] = False; m[20:30, 0] = False; m[10, 39] = False; m[11, 38] = False
+    elif case == "checker":
+        yy, xx = np.mgrid[0:65, 0:67]
+        m = (yy + xx) % 2 == 0
+    elif case == "odd_733x1024":
+        f = ndimage.gaussian_filter(rng.standard_normal((733, 1024)), 9.0)
+        m = f > np.quantile(f, 0.6)
+        thresh = 0.0005
+    else:                                                    # diagonal chains: 8-connected foreground, 4-separated background
+        m = np.zeros((80, 80), bool)
+        for k in range(70):
+            m[5 + k, 5 + k] = True; m[5 + k, 74 - k] = True
+        m[40:44, 10:70] = True
+    mask = m.astype(np.float32)
+    got_t, got_h = mask_to_contours(mask, tissue_area_thresh=thresh)
+    want_t, want_h = _contours_host_form(mask, thresh)
+    assert len(got_t) == len(want_t), (case, len(got_t), len(want_t))
+    assert [len(x) for x in got_h] == [len(x) for x in want_h], case
+    for a, b in zip(got_t, want_t):
+        assert np.array_equal(np.asarray(a).reshape(-1, 2), b), case
+    for hs, ws in zip(got_h, want_h):
+        for a, b in zip(hs, ws):
+            assert np.array_equal(np.asarray(a).reshape(-1, 2), b), case
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_coords_row_bucketed_scan_equals_the_full_scan(seed, monkeypatch):
     """The grid kernel visits, per grid row, only the polygon edges whose y-range meets the row's probe band (the host

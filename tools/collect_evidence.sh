@@ -20,5 +20,9 @@ python tools/pmc_traffic.py "$OUT/pmc_fetch" "$OUT/pmc_write" > "$OUT/traffic.js
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_mfma" -o m -- $CMD > "$OUT/pmc_mfma.log" 2>&1
 head -1 $(find "$OUT/pmc_mfma" -name "*counter_collection.csv" | head -1) > "$OUT/pmc_mfma_columns.txt" 2>/dev/null
 python tools/pmc_mfma.py "$OUT/pmc_mfma" > "$OUT/mfma_util.json"
-rm -rf "$OUT/kt" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_mfma"
+# SQ counters of the same command, two passes of eight (issue mix, waits, VALU beside MFMA): tools/pmc_sq.py
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_COEXEC_CYCLES --output-format csv -d "$OUT/pmc_sqa" -o a -- $CMD > "$OUT/pmc_sqa.log" 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY --output-format csv -d "$OUT/pmc_sqb" -o b -- $CMD > "$OUT/pmc_sqb.log" 2>&1
+python tools/pmc_sq.py "$OUT/pmc_sqa" "$OUT/pmc_sqb" > "$OUT/sq.json"
+rm -rf "$OUT/kt" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_mfma" "$OUT/pmc_sqa" "$OUT/pmc_sqb"
 head -30 "$OUT/kernel_stats.txt"

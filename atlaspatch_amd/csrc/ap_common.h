@@ -73,6 +73,13 @@ __device__ __forceinline__ f32x2_t gelu_sigmoid_poly2(f32x2_t x) {
     return x * f32x2_t{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
 }
 
+// silu(a) * b for two values, f32 (exp2 + rcp; both GEMM kernels call THIS routine so that they stay bit-identical)
+__device__ __forceinline__ f32x2_t swiglu2(f32x2_t a, f32x2_t b) {
+    const f32x2_t z = a * f32x2_t{-1.4426950408889634f, -1.4426950408889634f};
+    const f32x2_t d = f32x2_t{1.0f, 1.0f} + f32x2_t{__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])};
+    return (a * f32x2_t{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])}) * b;
+}
+
 // ---- GEMM ------------------------------------------------------------------------------
 // C[m][n] = sum_k A[m][k] * W[n][k]  (+ epilogue); A: activations [M, lda], W: weights [N, ldw],
 // both K-contiguous in the compute dtype.
@@ -95,6 +102,10 @@ enum GemmEpilogue {
     // img * (P + 1) + 1 + p as  T(pos16[1 + p][n] + T(acc + bias[n]))  together with that row's partial sums (the RESID_STATS
     // epilogue with the "residual" read from the T copy of the position embedding and remapped output rows)
     EPI_PATCH_STREAM = 7,
+    // timm SwiGLUPacked fc1 with the gate in the epilogue (uni_v2): the weight rows are INTERLEAVED in groups of 64 -- rows
+    // 64q .. 64q+31 = fc1 rows 32q .. 32q+31 (x1), rows 64q+32 .. 64q+63 = fc1 rows H+32q .. (x2) -- so that a wave's two 32-wide
+    // n blocks hold x1 and x2 of the same 32 output columns; out[m][32q + j] = T(silu(norm(x1)) * norm(x2)), out: T [M, N / 2]
+    EPI_NORM_SWIGLU = 8,
 };
 
 struct GemmArgs {
@@ -175,8 +186,9 @@ int launch_stream_to_f32(int dtype, const void* x, long stride, int rows, int di
 //   fold_ln: wout T [rows, ld] = T(w32[n][k] * gamma[k]); colsum[n] = sum_k float(wout[n][k]);
 //            bias_out[n] = bias_in[n] + sum_k w32[n][k] * beta[k]
 //   fold_ls: wout T [rows, ld] = T(w32[n][k] * ls[n]);  bias_out[n] = bias_in[n] * ls[n]   (ls may be null: plain convert)
+// swiglu_h > 0: output row r takes source row (r % 64 < 32 ? 0 : swiglu_h) + 32 * (r / 64) + r % 32 (EPI_NORM_SWIGLU's order)
 int launch_fold_ln(int dtype, const float* w32, int rows, int cols, int ld, const float* gamma, const float* beta,
-                   const float* bias_in, void* wout, float* colsum, float* bias_out, hipStream_t stream);
+                   const float* bias_in, void* wout, float* colsum, float* bias_out, hipStream_t stream, int swiglu_h = 0);
 int launch_fold_ls(int dtype, const float* w32, int rows, int cols, int ld, const float* ls, const float* bias_in,
                    void* wout, float* bias_out, hipStream_t stream);
 // prefix rows of the token stream (class token, then register tokens): prefix f32 [prefix_rows, dim] = the token values with

@@ -366,10 +366,12 @@ template <typename T>
 __global__ __launch_bounds__(256) void fold_ln_kernel(const float* __restrict__ w32, int cols, int ld,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       const float* __restrict__ bias_in, T* __restrict__ wout,
-                                                      float* __restrict__ colsum, float* __restrict__ bias_out) {
+                                                      float* __restrict__ colsum, float* __restrict__ bias_out, int swiglu_h) {
     __shared__ float red[4];
     const int n = blockIdx.x;
-    const float* src = w32 + (size_t)n * ld;
+    // EPI_NORM_SWIGLU's row order: output row n = 64 q + 32 half + j  <-  fc1 row half * H + 32 q + j
+    const int sn = swiglu_h > 0 ? ((n & 63) < 32 ? 0 : swiglu_h) + 32 * (n >> 6) + (n & 31) : n;
+    const float* src = w32 + (size_t)sn * ld;
     T* dst = wout + (size_t)n * ld;
     float cs = 0.f, bs = 0.f;
     for (int k = threadIdx.x; k < ld; k += 256) {
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(256) void fold_ln_kernel(const float* __restrict__ 
     bs = block_sum256(bs, red);
     if (threadIdx.x == 0) {
         colsum[n] = cs;
-        bias_out[n] = bias_in[n] + bs;
+        bias_out[n] = bias_in[sn] + bs;
     }
 }
 
@@ -662,9 +664,10 @@ int launch_stream_to_f32(int dtype, const void* x, long stride, int rows, int di
 }
 
 int launch_fold_ln(int dtype, const float* w32, int rows, int cols, int ld, const float* gamma, const float* beta,
-                   const float* bias_in, void* wout, float* colsum, float* bias_out, hipStream_t stream) {
-    if (dtype == AP_F16) fold_ln_kernel<f16><<<rows, 256, 0, stream>>>(w32, cols, ld, gamma, beta, bias_in, (f16*)wout, colsum, bias_out);
-    else if (dtype == AP_BF16) fold_ln_kernel<bf16><<<rows, 256, 0, stream>>>(w32, cols, ld, gamma, beta, bias_in, (bf16*)wout, colsum, bias_out);
+                   const float* bias_in, void* wout, float* colsum, float* bias_out, hipStream_t stream, int swiglu_h) {
+    AP_REQUIRE(swiglu_h == 0 || (rows == 2 * swiglu_h && swiglu_h % 32 == 0), "fold_ln: swiglu row order needs rows = 2 h, h %% 32 == 0");
+    if (dtype == AP_F16) fold_ln_kernel<f16><<<rows, 256, 0, stream>>>(w32, cols, ld, gamma, beta, bias_in, (f16*)wout, colsum, bias_out, swiglu_h);
+    else if (dtype == AP_BF16) fold_ln_kernel<bf16><<<rows, 256, 0, stream>>>(w32, cols, ld, gamma, beta, bias_in, (bf16*)wout, colsum, bias_out, swiglu_h);
     else { set_error("fold_ln: dtype %d (f16 / bf16 only)", dtype); return AP_ERR_INVALID; }
     AP_HIP_CHECK(hipGetLastError());
     return AP_OK;

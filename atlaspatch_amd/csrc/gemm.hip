@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             const f32x4 b4 = *(const f32x4*)(g.bias + n0 + wave_n * 64 + nt * 32 + g4 * 8 + hi * 4);
-            constexpr bool kNormInit = EPI == EPI_NORM_STORE || EPI == EPI_NORM_GELU;     // (these start from zero)
+            constexpr bool kNormInit = EPI == EPI_NORM_STORE || EPI == EPI_NORM_GELU || EPI == EPI_NORM_SWIGLU;     // (these start from zero)
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -229,6 +229,38 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     }
 
     // ---- epilogue: lane owns m = .. + l31 and, per (nt, g4), n = .. + 8*g4 + 4*hi + {0..3}
+    if constexpr (sizeof(T) == 2 && EPI == EPI_NORM_SWIGLU) {
+        // the wave's two n blocks are x1 and x2 of the same 32 output columns (interleaved weight rows, see ap_common.h)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int m = m0 + wave_m * 64 + mt * 32 + l31;
+            if (m >= g.M) continue;
+            const float rstd = g.rowstats[2 * (size_t)m], nmr = g.rowstats[2 * (size_t)m + 1];
+            const f32x2_t rs2 = {rstd, rstd}, nm2 = {nmr, nmr};
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                f32x4 y[2];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int n = n0 + wave_n * 64 + nt * 32 + g4 * 8 + hi * 4;
+                    const f32x4 cs = *(const f32x4*)(g.colsum + n), bb = *(const f32x4*)(g.bias + n);
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[nt][mt][g4 * 4 + e];
+                    const f32x2_t lo = __builtin_elementwise_fma(rs2, f32x2_t{v[0], v[1]},
+                        __builtin_elementwise_fma(nm2, f32x2_t{cs[0], cs[1]}, f32x2_t{bb[0], bb[1]}));
+                    const f32x2_t hi2 = __builtin_elementwise_fma(rs2, f32x2_t{v[2], v[3]},
+                        __builtin_elementwise_fma(nm2, f32x2_t{cs[2], cs[3]}, f32x2_t{bb[2], bb[3]}));
+                    y[nt] = f32x4{lo[0], lo[1], hi2[0], hi2[1]};
+                }
+                const f32x2_t a = swiglu2(f32x2_t{y[0][0], y[0][1]}, f32x2_t{y[1][0], y[1][1]});
+                const f32x2_t b = swiglu2(f32x2_t{y[0][2], y[0][3]}, f32x2_t{y[1][2], y[1][3]});
+                const int nout = ((n0 + wave_n * 64) >> 1) + g4 * 8 + hi * 4;
+                store4<T>((T*)g.out + (size_t)m * (size_t)g.ldo + nout, f32x4{a[0], a[1], b[0], b[1]});
+            }
+        }
+        return;
+    }
     if constexpr (sizeof(T) == 2 && (EPI == EPI_NORM_STORE || EPI == EPI_NORM_GELU)) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
@@ -372,6 +404,7 @@ int launch_typed(int epilogue, const GemmArgs& a, hipStream_t stream) {
         case EPI_PATCH_EMBED: gemm_kernel<T, EPI_PATCH_EMBED><<<grid, block, 0, stream>>>(a); break;
         case EPI_NORM_STORE: gemm_kernel<T, EPI_NORM_STORE><<<grid, block, 0, stream>>>(a); break;
         case EPI_NORM_GELU: gemm_kernel<T, EPI_NORM_GELU><<<grid, block, 0, stream>>>(a); break;
+        case EPI_NORM_SWIGLU: gemm_kernel<T, EPI_NORM_SWIGLU><<<grid, block, 0, stream>>>(a); break;
         case EPI_RESID_STATS: gemm_kernel<T, EPI_RESID_STATS><<<grid, block, 0, stream>>>(a); break;
         case EPI_PATCH_STREAM: gemm_kernel<T, EPI_PATCH_STREAM><<<grid, block, 0, stream>>>(a); break;
         default: set_error("gemm: unknown epilogue %d", epilogue); return AP_ERR_INVALID;
@@ -398,7 +431,7 @@ int launch_gemm_impl(int dtype, int epilogue, const GemmArgs& a, int impl, int v
         return AP_ERR_UNSUPPORTED;
 #endif
     }
-    const bool fused_epi = epilogue == EPI_NORM_STORE || epilogue == EPI_NORM_GELU || epilogue == EPI_RESID_STATS ||
+    const bool fused_epi = epilogue == EPI_NORM_STORE || epilogue == EPI_NORM_GELU || epilogue == EPI_NORM_SWIGLU || epilogue == EPI_RESID_STATS ||
                            epilogue == EPI_PATCH_STREAM;
     AP_REQUIRE(!fused_epi || dtype != AP_F32, "gemm: the fused-LayerNorm epilogues are f16 / bf16 only");
     AP_REQUIRE(!fused_epi || (epilogue == EPI_RESID_STATS ? a.partial != nullptr :

@@ -112,7 +112,8 @@ template <typename T, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) char smem[kLdsBytes];
 
-    constexpr bool kNorm = EPI == EPI_NORM_STORE || EPI == EPI_NORM_GELU;
+    constexpr bool kNorm = EPI == EPI_NORM_STORE || EPI == EPI_NORM_GELU || EPI == EPI_NORM_SWIGLU;
+    constexpr bool kSwiglu = EPI == EPI_NORM_SWIGLU;       // x1 | x2 in the wave's two n blocks -> 32 gated output columns
     constexpr bool kPatch = EPI == EPI_PATCH_STREAM;
     constexpr bool kRes = EPI == EPI_RESID_STATS || kPatch;
     const int lane = threadIdx.x & 63;
@@ -530,6 +531,32 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
                         }
                     }
                 }
+            } else if constexpr (kSwiglu) {
+                // out[m][32 q + j] = silu(norm(x1)) * norm(x2): the lane holds both in acc[0] / acc[1] (interleaved weight rows).
+                // The wave's block is 32 rows x 32 columns = 64 bytes per row: four 16-byte chunks, XOR-swizzled by row & 3
+                const f32x2_t rs2 = {rst[mb][0], rst[mb][0]}, nm2 = {rst[mb][1], rst[mb][1]};
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    f32x4 y[2];
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        const f32x2_t lo = __builtin_elementwise_fma(rs2, f32x2_t{acc[nb][mb][g4 * 4 + 0], acc[nb][mb][g4 * 4 + 1]},
+                            __builtin_elementwise_fma(nm2, f32x2_t{ncs[nb][g4][0], ncs[nb][g4][1]}, f32x2_t{nbias[nb][g4][0], nbias[nb][g4][1]}));
+                        const f32x2_t hi2 = __builtin_elementwise_fma(rs2, f32x2_t{acc[nb][mb][g4 * 4 + 2], acc[nb][mb][g4 * 4 + 3]},
+                            __builtin_elementwise_fma(nm2, f32x2_t{ncs[nb][g4][2], ncs[nb][g4][3]}, f32x2_t{nbias[nb][g4][2], nbias[nb][g4][3]}));
+                        y[nb] = f32x4{lo[0], lo[1], hi2[0], hi2[1]};
+                    }
+                    const f32x2_t a = swiglu2(f32x2_t{y[0][0], y[0][1]}, f32x2_t{y[1][0], y[1][1]});
+                    const f32x2_t b = swiglu2(f32x2_t{y[0][2], y[0][3]}, f32x2_t{y[1][2], y[1][3]});
+                    *(u32x2*)(scr + l31 * 64 + ((g4 ^ (l31 & 3)) << 4) + hi * 8) = pack4<T>(f32x4{a[0], a[1], b[0], b[1]});
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = i * 16 + (lane_e >> 2), ch = lane_e & 3;
+                    const u32x4 v = *(const u32x4*)(scr + row * 64 + ((ch ^ (row & 3)) << 4));
+                    const int m = m0 + mb * 32 + row;
+                    if (m < g.M) *(u32x4*)((T*)g.out + (size_t)m * g.ldo + (n0 >> 1) + ch * 8) = v;
+                }
             } else {
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb)
@@ -614,6 +641,7 @@ int launch_typed(int epilogue, const GemmArgs& a, int num_cu, int variant, hipSt
         case EPI_BIAS_RESID: return launch_epi<T, EPI_BIAS_RESID>(a, num_cu, variant, stream);
         case EPI_NORM_STORE: return launch_epi<T, EPI_NORM_STORE>(a, num_cu, variant, stream);
         case EPI_NORM_GELU: return launch_epi<T, EPI_NORM_GELU>(a, num_cu, variant, stream);
+        case EPI_NORM_SWIGLU: return launch_epi<T, EPI_NORM_SWIGLU>(a, num_cu, variant, stream);
         case EPI_RESID_STATS: return launch_epi<T, EPI_RESID_STATS>(a, num_cu, variant, stream);
         case EPI_PATCH_STREAM: return launch_epi<T, EPI_PATCH_STREAM>(a, num_cu, variant, stream);
     }
@@ -635,10 +663,11 @@ extern int g_gemm_trace_tiles;
 bool AP_G256_FN(gemm256_supports)(int dtype, int epilogue, const GemmArgs& a) {
     if (dtype != AP_F16 && dtype != AP_BF16) return false;
     if (epilogue != EPI_BIAS_STORE && epilogue != EPI_BIAS_GELU && epilogue != EPI_BIAS_RESID &&
-        epilogue != EPI_NORM_STORE && epilogue != EPI_NORM_GELU && epilogue != EPI_RESID_STATS && epilogue != EPI_PATCH_STREAM)
+        epilogue != EPI_NORM_STORE && epilogue != EPI_NORM_GELU && epilogue != EPI_NORM_SWIGLU && epilogue != EPI_RESID_STATS &&
+        epilogue != EPI_PATCH_STREAM)
         return false;
     if (epilogue == EPI_PATCH_STREAM && (!a.partial || !a.pos16 || a.P <= 0 || a.R <= 0 || a.M >= (1 << 24))) return false;
-    if ((epilogue == EPI_NORM_STORE || epilogue == EPI_NORM_GELU) && (!a.colsum || !a.rowstats)) return false;
+    if ((epilogue == EPI_NORM_STORE || epilogue == EPI_NORM_GELU || epilogue == EPI_NORM_SWIGLU) && (!a.colsum || !a.rowstats)) return false;
     if (epilogue == EPI_RESID_STATS && !a.partial) return false;
     if (a.N % kBN != 0 || a.K % 128 != 0 || a.K < 128) return false;
     if (((size_t)a.lda * 2) % 16 != 0 || ((size_t)a.ldw * 2) % 16 != 0) return false;

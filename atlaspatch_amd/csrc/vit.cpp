@@ -423,12 +423,11 @@ int blocks_fused(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipStream
             ap::GemmArgs g{};
             g.A = w.x16; g.lda = D; g.W = fb.fc1_w; g.ldw = bp.fc1->ld;
             g.M = M; g.N = F1; g.K = D; g.bias = fb.fc1_b; g.colsum = fb.fc1_cs; g.rowstats = w.rowstats;
-            g.out = w.hid; g.ldo = F1;
+            // SwiGLU: the folded fc1 weights are row-interleaved (x1 | x2 of the same 32 output columns in one wave's tile), so
+            // the gate runs in the epilogue on the f32 values: out = hid2 [M, H] directly, one rounding
+            g.out = swiglu ? w.hid2 : w.hid; g.ldo = swiglu ? H : F1;
             ScopedTimer t(m, AP_PROF_GEMM_FC1, stream);
-            if ((rc = ap::launch_gemm(dt, swiglu ? ap::EPI_NORM_STORE : ap::EPI_NORM_GELU, g, stream)) != AP_OK) return rc;
-            // SwiGLU: the gate needs columns j and mlp + j of one row, which live in different tiles of the GEMM: a streaming
-            // pass (HBM-bound, 6 B read + 2 B written per gated value) instead of an epilogue
-            if (swiglu && (rc = ap::launch_swiglu(dt, w.hid, M, H, w.hid2, stream)) != AP_OK) return rc;
+            if ((rc = ap::launch_gemm(dt, swiglu ? ap::EPI_NORM_SWIGLU : ap::EPI_NORM_GELU, g, stream)) != AP_OK) return rc;
         }
         {
             ap::GemmArgs g{};
@@ -793,7 +792,8 @@ int ap_vit_finalize(ap_vit* m) {
             fb.fc2_w = dalloc((size_t)D * bp.fc2->ld * es); fb.fc2_b = (float*)dalloc(D * 4);
             if (rc != AP_OK) break;
             if ((rc = ap::launch_fold_ln(dt, bp.qkv->dev32, 3 * DA, D, bp.qkv->ld, bp.ln1_w, bp.ln1_b, bp.qkv_b, fb.qkv_w, fb.qkv_cs, fb.qkv_b, nullptr)) != AP_OK) break;
-            if ((rc = ap::launch_fold_ln(dt, bp.fc1->dev32, F1, D, bp.fc1->ld, bp.ln2_w, bp.ln2_b, bp.fc1_b, fb.fc1_w, fb.fc1_cs, fb.fc1_b, nullptr)) != AP_OK) break;
+            if ((rc = ap::launch_fold_ln(dt, bp.fc1->dev32, F1, D, bp.fc1->ld, bp.ln2_w, bp.ln2_b, bp.fc1_b, fb.fc1_w, fb.fc1_cs, fb.fc1_b, nullptr,
+                                         m->cfg.mlp_type == AP_MLP_SWIGLU ? H : 0)) != AP_OK) break;
             if ((rc = ap::launch_fold_ls(dt, bp.proj->dev32, D, DA, bp.proj->ld, bp.ls1, bp.proj_b, fb.proj_w, fb.proj_b, nullptr)) != AP_OK) break;
             if ((rc = ap::launch_fold_ls(dt, bp.fc2->dev32, D, H, bp.fc2->ld, bp.ls2, bp.fc2_b, fb.fc2_w, fb.fc2_b, nullptr)) != AP_OK) break;
         }

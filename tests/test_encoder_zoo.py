@@ -124,9 +124,10 @@ MEASURED = {
     ("vit_b_32 L12", "float32"): (2.30e-6, 2.79e-5, 2.20e-5),
     ("vit_l_32 L24", "float16"): (1.768e-3, 1.946e-2, 1.625e-2),
     ("vit_l_32 L24, f32_stream", "float16"): (1.111e-3, 1.357e-2, 1.134e-2),
-    # uni_v2: the SwiGLU gate runs as a streaming pass on the ROUNDED fc1 output (two roundings and a product, like the
-    # reference's own half-precision modules; the GELU encoders round once, after the activation) -> ~1.8 x the error of uni_v1
-    ("uni_v2 L24", "float16"): (2.944e-3, 4.323e-2, 3.087e-2),
+    # uni_v2: SwiGLU gate in the fc1 epilogue on the f32 values (round 4: 2.94e-3 with the gate as a separate pass on the
+    # rounded fc1 output).  The product of two branches and dim 1536 give ~1.8 x uni_v1's error in every mode (float32: 6e-6)
+    ("uni_v2 L24", "float16"): (2.825e-3, 3.710e-2, 3.180e-2),
+    ("uni_v2 L24, f32_stream", "float16"): (2.526e-3, 3.558e-2, 2.909e-2),
     ("uni_v2 L24", "float32"): (6.00e-6, 1.117e-4, 7.00e-5),
     ("vit_h_14 L32", "float16"): (1.662e-3, 2.921e-2, 2.235e-2),
     ("vit_h_14 L32, f32_stream", "float16"): (9.04e-4, 2.090e-2, 1.378e-2),

@@ -177,6 +177,7 @@ int ap_gemm_fused(int dtype, int epilogue, const void* A, int lda, const void* W
     int epi;
     if (epilogue == AP_EPI_NORM) epi = ap::EPI_NORM_STORE;
     else if (epilogue == AP_EPI_NORM_GELU) epi = ap::EPI_NORM_GELU;
+    else if (epilogue == AP_EPI_NORM_SWIGLU) epi = ap::EPI_NORM_SWIGLU;
     else if (epilogue == AP_EPI_RESID_STATS) epi = ap::EPI_RESID_STATS;
     else { ap::set_error("ap_gemm_fused: unknown epilogue %d", epilogue); return AP_ERR_INVALID; }
     AP_REQUIRE(epi == ap::EPI_RESID_STATS ? partial != nullptr : (colsum && rowstats), "ap_gemm_fused: missing operand for epilogue %d", epilogue);

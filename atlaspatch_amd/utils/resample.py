@@ -184,7 +184,7 @@ class DeviceResampler:
                                                   None if box is None else (box[0], box[2]))
         by, ky, self.ksy = pillow_resample_tables(self.in_hw[0], self.out_hw[0], filter_name,
                                                   None if box is None else (box[1], box[3]))
-        to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+        to = lambda a: torch.from_numpy(np.array(a, order="C")).to(self.device)      # a writable copy (tables may be cached views)
         self.bx, self.kx, self.by, self.ky = to(bx), to(kx), to(by), to(ky)
         self._tmp = None
 

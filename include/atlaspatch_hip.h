@@ -306,6 +306,9 @@ int ap_gemm(int dtype, int epilogue, const void* A, int lda, const void* W, int 
  * bias' = b + W beta and rowstats[m] = (rstd, -mean * rstd) of row m of x.
  *   AP_EPI_NORM         out T [M, ldo] = rstd * acc + (-mean rstd) * colsum[n] + bias[n]
  *   AP_EPI_NORM_GELU    out = gelu(that)
+ *   AP_EPI_NORM_SWIGLU  timm SwiGLUPacked (models/patch/uni.py:91-93, uni_v2) with the gate in the epilogue: W / colsum / bias rows
+ *                       INTERLEAVED in groups of 64 -- rows 64q .. 64q+31 = fc1 rows 32q .. (x1), rows 64q+32 .. 64q+63 = fc1 rows
+ *                       N/2 + 32q .. (x2) -- and out T [M, N / 2]: out[m][32q + j] = silu(norm x1) * norm x2, one rounding
  *   AP_EPI_RESID_STATS  out T [M, ldo] (in place) = T(out + T(acc + bias[n]))  -- the residual add -- and
  *                       partial f32 [M, N / 64, 2] = per row and 64-column group (sum, sum of squares) of the NEW row;
  *                       ap_rowstats_finalize turns them into the next rowstats (deterministic, fixed order, double).
@@ -315,6 +318,7 @@ int ap_gemm(int dtype, int epilogue, const void* A, int lda, const void* W, int 
 #define AP_EPI_NORM 4
 #define AP_EPI_NORM_GELU 5
 #define AP_EPI_RESID_STATS 6
+#define AP_EPI_NORM_SWIGLU 8
 int ap_gemm_fused(int dtype, int epilogue, const void* A, int lda, const void* W, int ldw, int M, int N, int K,
                   const float* bias, const float* colsum, const float* rowstats, float* partial,
                   void* out, int ldo, int impl, ap_stream_t stream);

@@ -97,6 +97,42 @@ def _fused(env, dt, epi, A, W, bias, colsum, rowstats, partial, out, impl=256):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("dt,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
+@pytest.mark.parametrize("shape", [(1, 512, 256), (265, 8192, 1536), (3000, 2048, 384), (256 * 9 + 5, 1024, 768)])
+def test_gemm_norm_swiglu_epilogue(env, dt, tol, shape):
+    """AP_EPI_NORM_SWIGLU (uni_v2's SwiGLUPacked fc1): LayerNorm algebra + silu(x1) * x2 in the epilogue on row-interleaved
+    weights, against torch on the same rounded operands; the 128 x 128 and the persistent kernel give the same bits."""
+    _lib, lib, dev, stream = env
+    M, N, K = shape                                    # N = 2 H packed rows
+    H = N // 2
+    g = torch.Generator(device=dev).manual_seed(M + N)
+    x = (torch.randn((M, K), device=dev, generator=g) * 1.5 + 0.2).to(dt)
+    W = (torch.randn((N, K), device=dev, generator=g) * (1.5 / K ** 0.5)).to(dt)         # the LayerNorm gain is folded already
+    bias = torch.randn(N, device=dev, generator=g) * 0.2
+    xf = x.float()
+    mean, var = xf.mean(1, keepdim=True), xf.var(1, unbiased=False, keepdim=True)
+    rstd = torch.rsqrt(var + 1e-6)
+    rowstats = torch.cat([rstd, -mean * rstd], 1).contiguous()
+    colsum = W.float().sum(1)
+    # interleave: row 64 q + 32 half + j  <-  packed row half * H + 32 q + j
+    r = torch.arange(N, device=dev)
+    src = torch.where((r % 64) < 32, torch.zeros_like(r), torch.full_like(r, H)) + 32 * (r // 64) + r % 32
+    Wi, bi, ci = W[src].contiguous(), bias[src].contiguous(), colsum[src].contiguous()
+    outs = {}
+    for impl in (256, 128):
+        if impl == 256 and (N % 256 or K % 128):
+            continue
+        out = torch.full((M, H), float("nan"), device=dev, dtype=dt)
+        _fused(env, dt, 8, x, Wi, bi, ci, rowstats, None, out, impl=impl)
+        outs[impl] = out
+    y = ((xf - mean) * rstd) @ W.float().t() + bias
+    want = torch.nn.functional.silu(y[:, :H]) * y[:, H:]
+    got = next(iter(outs.values()))
+    assert (got.float() - want).abs().max().item() <= tol * max(1.0, want.abs().max().item())
+    if len(outs) == 2:
+        assert torch.equal(outs[256], outs[128])
+
+
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(1, 768, 768), (197, 768, 768), (1000, 768, 3072), (256 * 40 + 77, 1024, 1024),
                                    (348 * 197, 768, 768)])

@@ -326,7 +326,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
         for (int kk = 0; kk < 4; ++kk) {
             fb0[kk] = *(const Frag*)(buf + U_Y0 * kUnitBytes + pb[kk]);
             fa[0][kk] = *(const Frag*)(buf + U_X0 * kUnitBytes + pa[kk]);
+#ifdef AP_ABL_HALF_A
+            fa[1][kk] = fa[0][kk];       // timing probe only (wrong results): the LDS fragment volume of a 128 x 128-per-wave layout
+#else
             fa[1][kk] = *(const Frag*)(buf + U_X0 * kUnitBytes + 32 * kRowBytes + pa[kk]);
+#endif
         }
         AP_PHASE_SYNC();
         AP_MMA(acc[0][0], fb0[0], fa[0][0]); AP_MMA(acc[0][1], fb0[0], fa[1][0]);
@@ -350,7 +354,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             fa[0][kk] = *(const Frag*)(buf + U_X1 * kUnitBytes + pa[kk]);
+#ifdef AP_ABL_HALF_A
+            fa[1][kk] = fa[0][kk];
+#else
             fa[1][kk] = *(const Frag*)(buf + U_X1 * kUnitBytes + 32 * kRowBytes + pa[kk]);
+#endif
         }
         AP_PHASE_SYNC();
         AP_MMA(acc[1][2], fb1[0], fa[0][0]); AP_MMA(acc[1][3], fb1[0], fa[1][0]);

@@ -47,6 +47,14 @@ TRANSFORM_RESIZE = {
     "uni_v1": (224, "bicubic"),
     "uni_v2": (224, "bicubic"),
     "conch_v1": (448, "bicubic"),
+    # transformers image processors (dinov2.py:20-25, phikon.py:16-21: AutoImageProcessor(use_fast=True), configs from the public
+    # model cards, unverifiable offline): facebook/dinov2-* = BitImageProcessor(shortest_edge 256, bicubic, crop 224);
+    # owkin/phikon = ViTImageProcessor(224 x 224, bilinear, no crop); owkin/phikon-v2 = BitImageProcessor(224, bicubic, crop 224).
+    # Deviation, stated: the fast processors resample with torchvision's tensor kernels (antialias on), this path with the
+    # Pillow-exact device resize; on the default 256-px tiles the dinov2 resize is a no-op.
+    "dinov2_small": (256, "bicubic"), "dinov2_base": (256, "bicubic"), "dinov2_large": (256, "bicubic"),
+    "dinov2_giant": (256, "bicubic"),
+    "phikon_v1": (224, "bilinear"), "phikon_v2": (224, "bicubic"),
 }
 
 ARCHS = {
@@ -76,6 +84,26 @@ ARCHS = {
     # normalize=False) returns that 512-vector.
     "conch_v1": dict(image_size=448, patch_size=16, dim=768, depth=12, heads=12, mlp_dim=3072,
                      ln_eps=1e-6, layer_scale=False, pool="attn", pool_dim=512, pool_heads=8, pool_ln_eps=1e-5),
+    # transformers Dinov2Model (models/patch/dinov2.py:12-17,46-60: AutoModel.from_pretrained(facebook/dinov2-*),
+    # last_hidden_state[:, 0]): patch 14 at the processor's 224-px crop = 256 + 1 tokens, LayerScale, LayerNorm 1e-6; the
+    # checkpoints hold a 37 x 37 position grid (518 px) that the model resamples to the input's 16 x 16 with torch's bicubic
+    # interpolate in every forward (Dinov2Embeddings.interpolate_pos_encoding) -- done once at load here, with the same call.
+    # Canonical form: no_embed_class with the class position row folded into the class token (the hf_dinov2 adapter).
+    # giant: SwiGLUFFN, hidden = (int(1536 * 4 * 2 / 3) + 7) // 8 * 8 = 4096, silu(x1) * x2 on the two halves of weights_in
+    "dinov2_small": dict(image_size=224, patch_size=14, dim=384, depth=12, heads=6, mlp_dim=1536, ln_eps=1e-6,
+                         layer_scale=True, no_embed_class=True),
+    "dinov2_base": dict(image_size=224, patch_size=14, dim=768, depth=12, heads=12, mlp_dim=3072, ln_eps=1e-6,
+                        layer_scale=True, no_embed_class=True),
+    "dinov2_large": dict(image_size=224, patch_size=14, dim=1024, depth=24, heads=16, mlp_dim=4096, ln_eps=1e-6,
+                         layer_scale=True, no_embed_class=True),
+    "dinov2_giant": dict(image_size=224, patch_size=14, dim=1536, depth=40, heads=24, mlp_dim=4096, ln_eps=1e-6,
+                         layer_scale=True, no_embed_class=True, mlp="swiglu"),
+    # models/patch/phikon.py: phikon_v1 = transformers ViTModel(owkin/phikon, add_pooling_layer=False) = ViT-B/16, LayerNorm
+    # 1e-12 (ViTConfig default), last_hidden_state[:, 0] (after the final LayerNorm); phikon_v2 = AutoModel(owkin/phikon-v2) =
+    # Dinov2Model ViT-L/16 at 224 px (197 tokens)
+    "phikon_v1": dict(image_size=224, patch_size=16, dim=768, depth=12, heads=12, mlp_dim=3072, ln_eps=1e-12, layer_scale=False),
+    "phikon_v2": dict(image_size=224, patch_size=16, dim=1024, depth=24, heads=16, mlp_dim=4096, ln_eps=1e-6,
+                      layer_scale=True, no_embed_class=True),
 }
 
 
@@ -95,8 +123,23 @@ def _detect_source(sd: dict) -> str:
     raise ValueError("unrecognised ViT state dict (expected torchvision, timm, HF ViTModel or canonical keys)")
 
 
-def canonical_state_dict(sd: dict, *, depth: int, layer_scale: bool, source: str = "auto") -> dict:
-    """Return ``{canonical name: float32 CPU tensor}`` for ``ap_vit_set_param``."""
+def resample_position_grid(pos: torch.Tensor, grid: int) -> torch.Tensor:
+    """Patch position rows [g0 * g0, D] -> [grid * grid, D] exactly as transformers' ``interpolate_pos_encoding`` does it
+    (Dinov2Embeddings: float32, ``F.interpolate(mode="bicubic", align_corners=False)`` on the [1, D, g0, g0] view)."""
+    g0 = int(round(pos.shape[0] ** 0.5))
+    if g0 * g0 != pos.shape[0]:
+        raise ValueError(f"position embedding with {pos.shape[0]} patch rows is not a square grid")
+    if g0 == grid:
+        return pos
+    x = pos.detach().to(torch.float32).reshape(1, g0, g0, -1).permute(0, 3, 1, 2)
+    y = torch.nn.functional.interpolate(x, size=(grid, grid), mode="bicubic", align_corners=False)
+    return y.permute(0, 2, 3, 1).reshape(grid * grid, -1).contiguous()
+
+
+def canonical_state_dict(sd: dict, *, depth: int, layer_scale: bool, source: str = "auto", grid: Optional[int] = None) -> dict:
+    """Return ``{canonical name: float32 CPU tensor}`` for ``ap_vit_set_param``.  ``grid``: patches per side of the input the
+    encoder will see; an HF DINOv2 checkpoint trained on another grid has its position rows resampled to it (as the model
+    itself does in every forward)."""
     sd = {k: v for k, v in sd.items()}
     if source == "auto":
         source = _detect_source(sd)
@@ -173,7 +216,7 @@ def canonical_state_dict(sd: dict, *, depth: int, layer_scale: bool, source: str
         put("cls_token", (sd["embeddings.cls_token"].reshape(-1).float() + pos[0].float()))
         if "embeddings.register_tokens" in sd:
             put("reg_tokens", sd["embeddings.register_tokens"][0])
-        put("pos_embed", pos[1:])
+        put("pos_embed", pos[1:] if grid is None else resample_position_grid(pos[1:], int(grid)))
         put("norm.weight", sd["layernorm.weight"]); put("norm.bias", sd["layernorm.bias"])
         for i in range(depth):
             p, b = f"encoder.layer.{i}.", f"blocks.{i}."
@@ -474,7 +517,7 @@ def build_hip_vit_extractor(*, name: str, arch, device, dtype, state_dict: Optio
             pool_state = {k: v for k, v in state_dict.items() if k.startswith("attn_pool.")}
             state_dict = {k: v for k, v in state_dict.items() if not k.startswith("attn_pool.")}
     state = canonical_state_dict(state_dict, depth=spec["depth"], layer_scale=bool(spec.get("layer_scale")),
-                                 source=source)
+                                 source=source, grid=spec["image_size"] // spec["patch_size"])
     if pool_state:
         state.update({k: v.detach().to(torch.float32).cpu().contiguous() for k, v in pool_state.items()})
     vit = HipViT(spec, state, device=torch.device(device), dtype=dtype)
@@ -527,3 +570,23 @@ def register_uni(registry, *, device, dtype=torch.float32, num_workers: int = 0)
     registry.register("uni_v2", lambda: build_hip_vit_extractor(
         name="uni_v2", arch="uni_v2", device=device, dtype=dtype, random_init_seed=_env_seed(),
         resize=TRANSFORM_RESIZE["uni_v2"], expect_size=None, max_batch=1024))
+
+
+def register_dinov2(registry, *, device, dtype=torch.float32, num_workers: int = 0) -> None:
+    """dinov2_small / base / large / giant (models/patch/dinov2.py:12-17): the reference runs transformers' Dinov2Model on the
+    processor's output and returns the class token of ``last_hidden_state``.  Same device kernels as the other encoders (LayerScale
+    folded, giant: SwiGLU gate in the fc1 epilogue); checkpoints: the HF state dict (model.safetensors of facebook/dinov2-*) as
+    ``$ATLASPATCH_WEIGHTS_DIR/<name>.safetensors``."""
+    for name, cap in (("dinov2_small", 4096), ("dinov2_base", 2048), ("dinov2_large", 2048), ("dinov2_giant", 512)):
+        registry.register(name, lambda n=name, c=cap: build_hip_vit_extractor(
+            name=n, arch=n, device=device, dtype=dtype, random_init_seed=_env_seed(), resize=TRANSFORM_RESIZE[n],
+            expect_size=None, max_batch=c))
+
+
+def register_phikon(registry, *, device, dtype=torch.float32, num_workers: int = 0) -> None:
+    """phikon_v1 (transformers ViTModel, ViT-B/16, LayerNorm eps 1e-12) and phikon_v2 (Dinov2Model ViT-L/16), models/patch/phikon.py:
+    class token of ``last_hidden_state``.  HF state dicts in ATLASPATCH_WEIGHTS_DIR."""
+    for name in ("phikon_v1", "phikon_v2"):
+        registry.register(name, lambda n=name: build_hip_vit_extractor(
+            name=n, arch=n, device=device, dtype=dtype, random_init_seed=_env_seed(), resize=TRANSFORM_RESIZE[n],
+            expect_size=None, max_batch=2048))

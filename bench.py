@@ -43,6 +43,13 @@ ENCODERS = {
                           "bicubic) on the device)", "batch": 128},
     "uni_v2": {"label": "UNI2-h (ViT-H/14 at 224 px, 8 register tokens, SwiGLU, LayerScale; Resize(224, bicubic) on the device)",
                "batch": 1024},
+    # the transformers-backed encoder files (models/patch/dinov2.py, phikon.py)
+    "dinov2_small": {"label": "DINOv2 ViT-S/14 (257 tokens, LayerScale)", "batch": 4096},
+    "dinov2_base": {"label": "DINOv2 ViT-B/14 (257 tokens, LayerScale)", "batch": 2048},
+    "dinov2_large": {"label": "DINOv2 ViT-L/14 (257 tokens, LayerScale)", "batch": 1024},
+    "dinov2_giant": {"label": "DINOv2 ViT-g/14 (257 tokens, 40 blocks, SwiGLU, LayerScale)", "batch": 512},
+    "phikon_v1": {"label": "Phikon (HF ViT-B/16, LayerNorm 1e-12; Resize(224, bilinear) on the device)", "batch": 2048},
+    "phikon_v2": {"label": "Phikon-v2 (HF DINOv2 ViT-L/16; Resize(224, bicubic) on the device)", "batch": 2048},
 }
 
 
@@ -83,7 +90,8 @@ def parse_args():
                          "100000 = config 4 for N > 1)")
     ap.add_argument("--encoder", default="vit_b_16", choices=sorted(ENCODERS),
                     help="registered encoder of the forward (vit_b_16 = configs 2 / 4, uni_v1 = config 3, conch_v1 = config 5; "
-                         "vit_b_32 / vit_l_32 / vit_h_14 / uni_v2 = the rest of the reference's encoder files)")
+                         "vit_b_32 / vit_l_32 / vit_h_14 / uni_v2 = the rest of those encoder files; dinov2_* / phikon_* = the "
+                         "transformers-backed files)")
     ap.add_argument("--slide-seed", type=int, default=1234, help="rank r embeds the synthetic slide of seed SLIDE_SEED + r")
     ap.add_argument("--dump-features", default=None,
                     help="rank 0 saves the float32 feature matrix of the timed steps (the gathered [N*K*B, D] matrix for N > 1) "

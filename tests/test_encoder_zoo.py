@@ -82,6 +82,47 @@ def test_oracle_matches_hf_dinov2_with_registers(swiglu):
     assert _rel(got[:, 0].numpy(), out.pooler_output.numpy()) <= 2e-6                       # class token = what uni_v2 returns
 
 
+@pytest.mark.parametrize("swiglu,grid_ckpt,grid_in", [(False, 5, 4), (True, 5, 4), (False, 4, 4)])
+def test_oracle_matches_hf_dinov2_with_resampled_positions(swiglu, grid_ckpt, grid_in):
+    """models/patch/dinov2.py / phikon.py (phikon_v2): transformers' Dinov2Model -- the module the reference itself calls --
+    on an input whose patch grid differs from the checkpoint's (facebook/dinov2-*: 37 x 37 stored, 16 x 16 at the processor's
+    224-px crop): the model resamples its position rows in every forward; the adapter does it once (``resample_position_grid``)."""
+    from transformers import Dinov2Config, Dinov2Model
+    from atlaspatch_amd.encoders.vit import canonical_state_dict
+    from oracle import vit_oracle
+    torch.manual_seed(0)
+    cfg = Dinov2Config(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, mlp_ratio=4, use_swiglu_ffn=swiglu,
+                       patch_size=14, image_size=14 * grid_ckpt, layerscale_value=1.0, layer_norm_eps=1e-6)
+    model = _seed_params(Dinov2Model(cfg).eval())
+    x = torch.randn(3, 3, 14 * grid_in, 14 * grid_in, generator=torch.Generator().manual_seed(4))
+    with torch.inference_mode():
+        out = model(pixel_values=x)
+    sd = canonical_state_dict(dict(model.state_dict()), depth=2, layer_scale=True, grid=grid_in)      # auto-detected: hf_dinov2
+    assert "reg_tokens" not in sd and sd["pos_embed"].shape == (grid_in * grid_in, 128)
+    got = vit_oracle.vit_tokens_canonical(sd, x, heads=2, depth=2)
+    assert got.shape == out.last_hidden_state.shape == (3, 1 + grid_in * grid_in, 128)
+    assert _rel(got.numpy(), out.last_hidden_state.numpy()) <= 2e-6
+    # what the reference returns: last_hidden_state[:, 0] (dinov2.py:58-60)
+    assert _rel(got[:, 0].numpy(), out.last_hidden_state[:, 0].numpy()) <= 2e-6
+
+
+def test_oracle_matches_hf_vit_with_the_phikon_layer_norm_eps():
+    """phikon_v1 (phikon.py:36-56) = transformers ViTModel(add_pooling_layer=False) with ViTConfig's default LayerNorm eps 1e-12."""
+    from transformers import ViTConfig, ViTModel
+    from atlaspatch_amd.encoders.vit import ARCHS, canonical_state_dict
+    from oracle import vit_oracle
+    torch.manual_seed(0)
+    cfg = ViTConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=512, image_size=64, patch_size=16)
+    assert cfg.layer_norm_eps == ARCHS["phikon_v1"]["ln_eps"] == 1e-12
+    model = _seed_params(ViTModel(cfg, add_pooling_layer=False).eval())
+    x = torch.randn(3, 3, 64, 64, generator=torch.Generator().manual_seed(2))
+    with torch.inference_mode():
+        want = model(pixel_values=x).last_hidden_state
+    sd = canonical_state_dict(dict(model.state_dict()), depth=2, layer_scale=False, source="hf")
+    got = vit_oracle.vit_tokens_canonical(sd, x, heads=2, depth=2, eps=1e-12)
+    assert _rel(got.numpy(), want.numpy()) <= 2e-6
+
+
 def test_head_padding_leaves_the_function_unchanged():
     """pad_heads: 80-wide heads stored 128 wide (zero rows in q / k / v, zero columns in proj) with the softmax scale kept at
     1 / sqrt(80) -- checked with an explicit attention on the padded tensors."""
@@ -108,8 +149,11 @@ def test_registry_has_the_reference_names_of_the_three_encoder_files():
     from atlaspatch_amd.encoders import build_default_registry
     from atlaspatch_amd.encoders.vit import ARCHS, TRANSFORM_RESIZE
     names = build_default_registry(device="cpu").available()
-    for n in ("vit_b_16", "vit_b_32", "vit_l_16", "vit_l_32", "vit_h_14", "uni_v1", "uni_v2", "conch_v1"):
+    for n in ("vit_b_16", "vit_b_32", "vit_l_16", "vit_l_32", "vit_h_14", "uni_v1", "uni_v2", "conch_v1",
+              "dinov2_small", "dinov2_base", "dinov2_large", "dinov2_giant", "phikon_v1", "phikon_v2"):       # dinov2.py:12-17, phikon.py
         assert n in names and n in ARCHS and n in TRANSFORM_RESIZE
+    g = ARCHS["dinov2_giant"]
+    assert (g["dim"], g["depth"], g["heads"], g["mlp_dim"]) == (1536, 40, 24, (int(1536 * 4 * 2 / 3) + 7) // 8 * 8)
     assert ARCHS["vit_h_14"]["image_size"] == 518 and TRANSFORM_RESIZE["vit_h_14"] == (518, "bicubic")
     a = ARCHS["uni_v2"]
     assert (a["dim"], a["depth"], a["heads"], a["mlp_dim"], a["reg_tokens"], a["patch_size"]) == (1536, 24, 24, 4096, 8, 14)
@@ -132,6 +176,24 @@ MEASURED = {
     ("vit_h_14 L32", "float16"): (1.662e-3, 2.921e-2, 2.235e-2),
     ("vit_h_14 L32, f32_stream", "float16"): (9.04e-4, 2.090e-2, 1.378e-2),
 }
+MEASURED.update({                     # the transformers-backed encoders (dinov2.py, phikon.py)
+    ("dinov2_small L12", "float16"): (1.234e-3, 1.442e-2, 1.326e-2),
+    ("dinov2_small L12, f32_stream", "float16"): (8.13e-4, 1.153e-2, 9.96e-3),
+    ("dinov2_small L12", "float32"): (1.571e-6, 2.843e-5, 1.952e-5),
+    ("dinov2_base L12", "float16"): (1.348e-3, 1.727e-2, 1.301e-2),
+    ("dinov2_base L12, f32_stream", "float16"): (9.98e-4, 1.655e-2, 1.123e-2),
+    ("dinov2_large L24", "float16"): (1.687e-3, 2.067e-2, 1.504e-2),
+    ("dinov2_large L24, f32_stream", "float16"): (9.90e-4, 1.461e-2, 9.70e-3),
+    # 40 SwiGLU blocks at dim 1536 with LayerScale drawn in [0.2, 0.7] (the test's, not the checkpoints' 1e-5 .. 1): uni_v2's
+    # per-block error (2.8e-3 over 24 blocks) over 40
+    ("dinov2_giant L40", "float16"): (4.264e-3, 6.629e-2, 3.659e-2),
+    ("dinov2_giant L40, f32_stream", "float16"): (3.315e-3, 4.796e-2, 3.527e-2),
+    ("phikon_v1 L12", "float16"): (1.256e-3, 1.599e-2, 1.356e-2),
+    ("phikon_v1 L12, f32_stream", "float16"): (9.14e-4, 1.484e-2, 1.025e-2),
+    ("phikon_v1 L12", "float32"): (1.949e-6, 2.594e-5, 2.134e-5),
+    ("phikon_v2 L24", "float16"): (1.589e-3, 2.143e-2, 1.685e-2),
+    ("phikon_v2 L24, f32_stream", "float16"): (9.86e-4, 1.527e-2, 1.200e-2),
+})
 HEADROOM = (1.2, 1.5, 1.25)
 FALLBACK = {"float32": (3.0e-6, 6e-5, 4e-5), "float16": (3.6e-3, 5.2e-2, 3.8e-2)}
 
@@ -169,7 +231,11 @@ def _with_layer_scale(sd, arch, seed):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,dtype,n", [("vit_b_32", torch.float16, 8), ("vit_b_32", torch.float32, 8), ("vit_l_32", torch.float16, 8),
-                                          ("uni_v2", torch.float16, 6), ("uni_v2", torch.float32, 4), ("vit_h_14", torch.float16, 3)])
+                                          ("uni_v2", torch.float16, 6), ("uni_v2", torch.float32, 4), ("vit_h_14", torch.float16, 3),
+                                          ("dinov2_small", torch.float16, 8), ("dinov2_small", torch.float32, 8),
+                                          ("dinov2_base", torch.float16, 8), ("dinov2_large", torch.float16, 6),
+                                          ("dinov2_giant", torch.float16, 4), ("phikon_v1", torch.float16, 8),
+                                          ("phikon_v1", torch.float32, 8), ("phikon_v2", torch.float16, 6)])
 def test_encoder_at_real_size_vs_fp32_oracle(name, dtype, n):
     from atlaspatch_amd.encoders.vit import ARCHS, TRANSFORM_RESIZE, build_hip_vit_extractor, random_canonical_state_dict
     from oracle import vit_oracle
@@ -190,7 +256,7 @@ def test_encoder_at_real_size_vs_fp32_oracle(name, dtype, n):
         assert _rel(got_full, got) <= 2e-3                          # the CLS-only tail and the full last block agree
     ex.cleanup()
     want = vit_oracle.canonical_extract(sd, tiles, heads=arch["heads"], depth=arch["depth"], image_size=arch["image_size"],
-                                        resize=TRANSFORM_RESIZE[name], batch=2)
+                                        resize=TRANSFORM_RESIZE[name], batch=2, eps=arch["ln_eps"])
     assert got.shape == want.shape == (n, arch["dim"]) and got.dtype == np.float32
     _check(got, want, dtype, f"{name} L{arch['depth']}")
     if got_f32s is not None:
@@ -220,5 +286,32 @@ def test_dinov2_with_registers_checkpoint_layout_on_the_device_vs_the_hf_model(d
     x = vit_oracle.transform_resize_crop(tiles, resize=(224, "bicubic"), crop=224)
     with torch.inference_mode():
         want = model(pixel_values=x).pooler_output.numpy()
+    assert got.shape == want.shape == (5, 384)
+    assert _rel(got, want) <= tol, _rel(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float16, 4e-3)])
+def test_dinov2_checkpoint_with_a_518px_position_grid_on_the_device_vs_the_hf_model(dtype, tol):
+    """The registered ``dinov2_small`` shape fed an HF Dinov2Model state dict whose position embedding is the checkpoints' 37 x 37
+    grid: the adapter resamples it to 16 x 16, the device result is compared with the HF model ITSELF at 224 px (which resamples
+    in its forward) -- the module the reference calls (dinov2.py:46-60), 4 blocks."""
+    from transformers import Dinov2Config, Dinov2Model
+    from atlaspatch_amd.encoders.vit import ARCHS, TRANSFORM_RESIZE, build_hip_vit_extractor
+    from oracle import vit_oracle
+    torch.manual_seed(0)
+    cfg = Dinov2Config(hidden_size=384, num_hidden_layers=4, num_attention_heads=6, mlp_ratio=4, patch_size=14, image_size=518,
+                       layerscale_value=1.0, layer_norm_eps=1e-6)
+    model = _seed_params(Dinov2Model(cfg).eval())
+    assert model.state_dict()["embeddings.position_embeddings"].shape == (1, 1 + 37 * 37, 384)
+    arch = dict(ARCHS["dinov2_small"], depth=4)
+    ex = build_hip_vit_extractor(name="dinov2_small", arch=arch, state_dict=dict(model.state_dict()), device=torch.device("cuda:0"),
+                                 dtype=dtype, resize=TRANSFORM_RESIZE["dinov2_small"], expect_size=None, max_batch=64)
+    tiles = _tiles(5, 53)
+    got = ex.extract_batch(tiles, batch_size=32)
+    ex.cleanup()
+    x = vit_oracle.transform_resize_crop(tiles, resize=TRANSFORM_RESIZE["dinov2_small"], crop=224)
+    with torch.inference_mode():
+        want = model(pixel_values=x).last_hidden_state[:, 0].numpy()
     assert got.shape == want.shape == (5, 384)
     assert _rel(got, want) <= tol, _rel(got, want)

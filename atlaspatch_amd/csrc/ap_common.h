@@ -182,6 +182,8 @@ int launch_rowstats_finalize(const float* partial, int rows, int groups, int dim
                              hipStream_t stream);
 // x T rows (row stride `stride` elements) -> dst f32 [rows, dim] dense
 int launch_stream_to_f32(int dtype, const void* x, long stride, int rows, int dim, float* dst, hipStream_t stream);
+// AP_POOL_CLS_MEAN: y f32 [n * tokens, dim] (final LayerNorm of every token) -> out f32 [n, 2 * dim] = [row 0 | mean of rows prefix ..]
+int launch_cls_mean_pool(const float* y, int n, int tokens, int prefix, int dim, float* out, hipStream_t stream);
 // Weight folding (ap_vit_finalize).  w32: f32 [rows, ld] (zero padded beyond cols).
 //   fold_ln: wout T [rows, ld] = T(w32[n][k] * gamma[k]); colsum[n] = sum_k float(wout[n][k]);
 //            bias_out[n] = bias_in[n] + sum_k w32[n][k] * beta[k]

@@ -577,6 +577,20 @@ __global__ void chw_to_patchrows_any_kernel(const TI* __restrict__ x, int n, int
     dst[((size_t)(img * g + py) * g + px) * ld + (c * ps + ky) * ps + kx] = from_f32<TO>((float)x[i]);
 }
 
+// AP_POOL_CLS_MEAN (midnight.py:58-61, virchow.py:58-61): one thread per (image, channel); the patch rows are summed in row
+// order in double (deterministic, coalesced across the channel threads) and divided once
+__global__ __launch_bounds__(256) void cls_mean_pool_kernel(const float* __restrict__ y, int tokens, int prefix, int dim,
+                                                            float* __restrict__ out) {
+    const int d = blockIdx.x * 256 + threadIdx.x, img = blockIdx.y;
+    if (d >= dim) return;
+    const float* base = y + (size_t)img * tokens * dim + d;
+    double acc = 0.0;
+    for (int t = prefix; t < tokens; ++t) acc += (double)base[(size_t)t * dim];
+    float* o = out + (size_t)img * 2 * dim;
+    o[d] = base[0];
+    o[dim + d] = (float)(acc / (double)(tokens - prefix));
+}
+
 }  // namespace
 
 int launch_add2_layernorm(int delta_dtype, int out_dtype, float* x, long stride, const void* delta0, long dstride0,
@@ -647,6 +661,15 @@ int launch_rowstats_finalize(const float* partial, int rows, int groups, int dim
     if (rows <= 0) return AP_OK;
     AP_REQUIRE(groups > 0 && groups % 2 == 0, "rowstats_finalize: groups %d must be even", groups);
     rowstats_finalize_kernel<<<(rows + 31) / 32, 256, 0, stream>>>(partial, rows, groups, dim, eps, rowstats);
+    AP_HIP_CHECK(hipGetLastError());
+    return AP_OK;
+}
+
+int launch_cls_mean_pool(const float* y, int n, int tokens, int prefix, int dim, float* out, hipStream_t stream) {
+    AP_REQUIRE(n >= 0 && tokens > prefix && prefix >= 1 && dim > 0, "cls_mean_pool: %d tokens, prefix %d", tokens, prefix);
+    if (n == 0) return AP_OK;
+    dim3 grid((unsigned)((dim + 255) / 256), (unsigned)n);
+    cls_mean_pool_kernel<<<grid, 256, 0, stream>>>(y, tokens, prefix, dim, out);
     AP_HIP_CHECK(hipGetLastError());
     return AP_OK;
 }

@@ -461,6 +461,14 @@ int run_blocks(ap_vit* m, int n, const Workspace& w, float* out, hipStream_t str
                                         n, D, m->norm_w,
                                         m->norm_b, c.ln_eps, out, stream);
 
+    if (c.pool == AP_POOL_CLS_MEAN) {
+        // final LN on ALL tokens (f32 [M, D], reuses qkv), then [class token | mean of the patch tokens] -> out f32 [n, 2 D]
+        float* y = (float*)w.qkv;
+        if ((rc = ap::launch_add_layernorm(dt, AP_F32, w.tok, D, pending, D, pending_ls, M, D, m->norm_w, m->norm_b, c.ln_eps, y,
+                                           stream)) != AP_OK) return rc;
+        return ap::launch_cls_mean_pool(y, n, m->tokens, m->prefix, D, out, stream);
+    }
+
     // ---- AP_POOL_ATTN (CONCH visual tower): final LN on ALL tokens, then the one-query attentional pooler.
     // Buffers: y f32 [M, D] reuses qkv, xk T [M, D] = xn, kv T [M, 2P] reuses hid, pooled T [n, P] = att,
     // o32 f32 [n, P] reuses delta.
@@ -529,7 +537,7 @@ int ap_vit_create(const ap_vit_config* cfg, ap_vit** out) {
     AP_REQUIRE(c.depth > 0, "vit_create: depth %d", c.depth);
     AP_REQUIRE(c.compute_dtype == AP_F16 || c.compute_dtype == AP_BF16 || c.compute_dtype == AP_F32,
                "vit_create: compute dtype %d", c.compute_dtype);
-    AP_REQUIRE(c.pool == AP_POOL_CLS || c.pool == AP_POOL_ATTN, "vit_create: pool %d", c.pool);
+    AP_REQUIRE(c.pool == AP_POOL_CLS || c.pool == AP_POOL_ATTN || c.pool == AP_POOL_CLS_MEAN, "vit_create: pool %d", c.pool);
     if (c.pool == AP_POOL_ATTN) {
         AP_REQUIRE(c.compute_dtype != AP_F32, "vit_create: the attentional pooler runs in float16 / bfloat16 only");
         AP_REQUIRE(c.pool_heads > 0 && c.pool_dim == c.pool_heads * 64 && c.pool_dim % 128 == 0 &&
@@ -828,7 +836,10 @@ size_t ap_vit_workspace_bytes(const ap_vit* m, int n) {
     return whole > halves ? whole : halves;
 }
 
-int ap_vit_embed_dim(const ap_vit* m) { return !m ? 0 : (m->cfg.pool == AP_POOL_ATTN ? m->cfg.pool_dim : m->cfg.dim); }
+int ap_vit_embed_dim(const ap_vit* m) {
+    if (!m) return 0;
+    return m->cfg.pool == AP_POOL_ATTN ? m->cfg.pool_dim : (m->cfg.pool == AP_POOL_CLS_MEAN ? 2 * m->cfg.dim : m->cfg.dim);
+}
 
 int ap_vit_profile_enable(ap_vit* m, int on) {
     AP_REQUIRE(m, "vit_profile_enable: null handle");

@@ -55,6 +55,24 @@ TRANSFORM_RESIZE = {
     "dinov2_small": (256, "bicubic"), "dinov2_base": (256, "bicubic"), "dinov2_large": (256, "bicubic"),
     "dinov2_giant": (256, "bicubic"),
     "phikon_v1": (224, "bilinear"), "phikon_v2": (224, "bicubic"),
+    # torchvision transforms written out in the loader files (PIL input -> Pillow filters):
+    #   midnight.py:14-24 Resize(224) + CenterCrop(224), Normalize(0.5, 0.5); hoptimus.py:15-30 Resize((224, 224)) + its own
+    #   mean / std; gigapath.py:15-26 Resize(256, BICUBIC) + CenterCrop(224); pathorchestra.py:52-58 Resize(224)
+    "midnight": (224, "bilinear"), "h_optimus_0": (224, "bilinear"), "h_optimus_1": (224, "bilinear"),
+    "prov_gigapath": (256, "bicubic"), "pathorchestra": (224, "bilinear"),
+    # lunit.py:58-59: timm create_transform of the hub data config (expected: Resize(256, bicubic) + CenterCrop(224), the
+    # checkpoints' own mean / std; unverifiable offline)
+    "lunit_vit_small_patch16_dino": (256, "bicubic"), "lunit_vit_small_patch8_dino": (256, "bicubic"),
+}
+
+# Normalize() constants per registered name (default: ImageNet)
+TRANSFORM_NORM = {
+    "conch_v1": (OPENAI_CLIP_MEAN, OPENAI_CLIP_STD),
+    "midnight": ((0.5, 0.5, 0.5), (0.5, 0.5, 0.5)),                                                   # midnight.py:22
+    "h_optimus_0": ((0.707223, 0.578729, 0.703617), (0.211883, 0.230117, 0.177517)),                  # hoptimus.py:24-27
+    "h_optimus_1": ((0.707223, 0.578729, 0.703617), (0.211883, 0.230117, 0.177517)),
+    "lunit_vit_small_patch16_dino": ((0.70322989, 0.53606487, 0.66096631), (0.21716536, 0.26081574, 0.20723464)),
+    "lunit_vit_small_patch8_dino": ((0.70322989, 0.53606487, 0.66096631), (0.21716536, 0.26081574, 0.20723464)),
 }
 
 ARCHS = {
@@ -104,6 +122,27 @@ ARCHS = {
     "phikon_v1": dict(image_size=224, patch_size=16, dim=768, depth=12, heads=12, mlp_dim=3072, ln_eps=1e-12, layer_scale=False),
     "phikon_v2": dict(image_size=224, patch_size=16, dim=1024, depth=24, heads=16, mlp_dim=4096, ln_eps=1e-6,
                       layer_scale=True, no_embed_class=True),
+    # models/patch/midnight.py: transformers AutoModel(kaiko-ai/midnight) = Dinov2Model ViT-g/14 (the loader's emb_dim 3072 = 2 x
+    # 1536), features = cat(last_hidden_state[:, 0], last_hidden_state[:, 1:].mean(1))
+    "midnight": dict(image_size=224, patch_size=14, dim=1536, depth=40, heads=24, mlp_dim=4096, ln_eps=1e-6,
+                     layer_scale=True, no_embed_class=True, mlp="swiglu", pool="cls_mean"),
+    # timm hub models; the architecture comes from the hub's config.json, not from the reference's text (public model cards,
+    # unverifiable offline -- same standing as uni_v1 / uni_v2).  hoptimus.py:53-58 (init_values 1e-5): H-optimus-0 / -1 =
+    # vit_giant_patch14_reg4_dinov2 at 224 px (1536 / 40 / 24, SwiGLUPacked 4096, 4 register tokens, no_embed_class);
+    # gigapath.py:46: vit_giant_patch14_dinov2 with patch 16 (1536 / 40 / 24, SwiGLUPacked 4096, class position row);
+    # lunit.py:10-16: timm vit_small patch 16 / 8 (384 / 12 / 6); pathorchestra.py:38-43: ViT-L/16 with LayerScale
+    "h_optimus_0": dict(image_size=224, patch_size=14, dim=1536, depth=40, heads=24, mlp_dim=4096, ln_eps=1e-6,
+                        layer_scale=True, reg_tokens=4, no_embed_class=True, mlp="swiglu"),
+    "h_optimus_1": dict(image_size=224, patch_size=14, dim=1536, depth=40, heads=24, mlp_dim=4096, ln_eps=1e-6,
+                        layer_scale=True, reg_tokens=4, no_embed_class=True, mlp="swiglu"),
+    "prov_gigapath": dict(image_size=224, patch_size=16, dim=1536, depth=40, heads=24, mlp_dim=4096, ln_eps=1e-6,
+                          layer_scale=True, mlp="swiglu"),
+    "lunit_vit_small_patch16_dino": dict(image_size=224, patch_size=16, dim=384, depth=12, heads=6, mlp_dim=1536, ln_eps=1e-6,
+                                         layer_scale=False),
+    "lunit_vit_small_patch8_dino": dict(image_size=224, patch_size=8, dim=384, depth=12, heads=6, mlp_dim=1536, ln_eps=1e-6,
+                                        layer_scale=False),
+    "pathorchestra": dict(image_size=224, patch_size=16, dim=1024, depth=24, heads=16, mlp_dim=4096, ln_eps=1e-6,
+                          layer_scale=True),
 }
 
 
@@ -359,13 +398,14 @@ class HipViT:
         self.dtype = dtype
         self.arch = dict(arch)
         attn_pool = arch.get("pool") == "attn"
-        self.embed_dim = int(arch["pool_dim"] if attn_pool else arch["dim"])
+        cls_mean = arch.get("pool") == "cls_mean"          # [class token | mean of the patch tokens] (midnight.py:58-61)
+        self.embed_dim = int(arch["pool_dim"] if attn_pool else (2 * arch["dim"] if cls_mean else arch["dim"]))
         hd_true = arch["dim"] // arch["heads"]
         hd_stored = stored_head_dim(arch["dim"], arch["heads"])
         cfg = _lib.VitConfig(arch["image_size"], arch["patch_size"], arch["dim"], arch["depth"],
                              arch["heads"], arch["mlp_dim"], float(arch["ln_eps"]),
                              1 if arch.get("layer_scale") else 0, _lib.torch_dtype_code(dtype),
-                             1 if attn_pool else 0, int(arch.get("pool_dim", 0)), int(arch.get("pool_heads", 0)),
+                             1 if attn_pool else (2 if cls_mean else 0), int(arch.get("pool_dim", 0)), int(arch.get("pool_heads", 0)),
                              float(arch.get("pool_ln_eps", 1e-5)),
                              int(arch.get("reg_tokens", 0)), 1 if arch.get("no_embed_class") else 0,
                              1 if arch.get("mlp") == "swiglu" else 0, hd_stored,
@@ -590,3 +630,16 @@ def register_phikon(registry, *, device, dtype=torch.float32, num_workers: int =
         registry.register(name, lambda n=name: build_hip_vit_extractor(
             name=n, arch=n, device=device, dtype=dtype, random_init_seed=_env_seed(), resize=TRANSFORM_RESIZE[n],
             expect_size=None, max_batch=2048))
+
+
+def register_more_vits(registry, *, device, dtype=torch.float32, num_workers: int = 0) -> None:
+    """The other loader files whose model is a plain ViT this engine runs: midnight (models/patch/midnight.py, transformers
+    Dinov2Model giant, class token + mean patch token), h_optimus_0 / h_optimus_1 (hoptimus.py), prov_gigapath (gigapath.py),
+    the two Lunit ViT-S (lunit.py) and pathorchestra (pathorchestra.py).  Checkpoints: HF (midnight) or timm key names in
+    ATLASPATCH_WEIGHTS_DIR; each with the transform its loader file writes out (``TRANSFORM_RESIZE`` / ``TRANSFORM_NORM``)."""
+    for name, cap in (("midnight", 512), ("h_optimus_0", 512), ("h_optimus_1", 512), ("prov_gigapath", 512),
+                      ("lunit_vit_small_patch16_dino", 4096), ("lunit_vit_small_patch8_dino", 512), ("pathorchestra", 2048)):
+        mean, std = TRANSFORM_NORM.get(name, (IMAGENET_MEAN, IMAGENET_STD))
+        registry.register(name, lambda n=name, c=cap, mu=mean, sd=std: build_hip_vit_extractor(
+            name=n, arch=n, device=device, dtype=dtype, random_init_seed=_env_seed(), resize=TRANSFORM_RESIZE[n],
+            expect_size=None, max_batch=c, mean=mu, std=sd))

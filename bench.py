@@ -50,6 +50,15 @@ ENCODERS = {
     "dinov2_giant": {"label": "DINOv2 ViT-g/14 (257 tokens, 40 blocks, SwiGLU, LayerScale)", "batch": 512},
     "phikon_v1": {"label": "Phikon (HF ViT-B/16, LayerNorm 1e-12; Resize(224, bilinear) on the device)", "batch": 2048},
     "phikon_v2": {"label": "Phikon-v2 (HF DINOv2 ViT-L/16; Resize(224, bicubic) on the device)", "batch": 2048},
+    # midnight.py (HF DINOv2 ViT-g/14, class token | mean patch token) and the timm-hub ViTs
+    "midnight": {"label": "Midnight (HF DINOv2 ViT-g/14, class token + mean patch token = 3072-d)", "batch": 512,
+                 "mean": (0.5, 0.5, 0.5), "std": (0.5, 0.5, 0.5)},
+    "h_optimus_0": {"label": "H-optimus-0 (ViT-g/14, 4 register tokens, SwiGLU)", "batch": 512,
+                    "mean": (0.707223, 0.578729, 0.703617), "std": (0.211883, 0.230117, 0.177517)},
+    "prov_gigapath": {"label": "Prov-GigaPath tile encoder (ViT-g/16, SwiGLU)", "batch": 512},
+    "lunit_vit_small_patch16_dino": {"label": "Lunit ViT-S/16 DINO", "batch": 4096},
+    "lunit_vit_small_patch8_dino": {"label": "Lunit ViT-S/8 DINO (785 tokens)", "batch": 512},
+    "pathorchestra": {"label": "PathOrchestra (ViT-L/16 + LayerScale)", "batch": 2048},
 }
 
 
@@ -69,6 +78,8 @@ def encoder_geometry(arch):
         P = arch["pool_dim"]
         model += 2.0 * T * D * 2 * P + 4.0 * T * P + 2.0 * P * P
         executed = model
+    elif arch.get("pool") == "cls_mean":
+        executed = model                 # class token | mean patch token: every block runs for every token
     else:
         executed = model - block + 2.0 * T * D * 2 * D + 2.0 * (2 * D * D + mlp_w) + 4.0 * T * D
     return {"tokens": T, "model": model, "executed": executed}

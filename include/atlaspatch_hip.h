@@ -184,7 +184,10 @@ typedef struct ap_vit_config {
                             AP_POOL_ATTN: final LN on all tokens, then the attentional pooler of
                             CONCH's visual tower with ONE query (models/patch/conch.py:52,
                             encode_image(proj_contrast=False, normalize=False)): LN_k, k/v
-                            projection to pool_dim, softmax pooling per head, out_proj, LN */
+                            projection to pool_dim, softmax pooling per head, out_proj, LN.
+                            AP_POOL_CLS_MEAN: final LN on all tokens, out = [class token | mean of the PATCH tokens]
+                            (2 * dim floats; register tokens excluded): torch.cat([cls, patch_tokens.mean(1)], -1) of
+                            models/patch/midnight.py:58-61, virchow.py:58-61,111-114, hoptimus.py:158-161 */
     int pool_dim;        /* 512 (conch_v1); heads of 64 */
     int pool_heads;      /* 8 */
     float pool_ln_eps;   /* 1e-5 (open_clip LayerNorm) */
@@ -205,6 +208,7 @@ typedef struct ap_vit_config {
 #define AP_MLP_SWIGLU 1
 #define AP_POOL_CLS 0
 #define AP_POOL_ATTN 1
+#define AP_POOL_CLS_MEAN 2
 
 int ap_vit_create(const ap_vit_config* cfg, ap_vit** out);
 void ap_vit_destroy(ap_vit* m);
@@ -245,7 +249,7 @@ int ap_vit_finalize(ap_vit* m);
 int ap_vit_set_option(ap_vit* m, int option, int value);
 
 size_t ap_vit_workspace_bytes(const ap_vit* m, int n);
-int ap_vit_embed_dim(const ap_vit* m);   /* dim (AP_POOL_CLS) or pool_dim (AP_POOL_ATTN) */
+int ap_vit_embed_dim(const ap_vit* m);   /* dim (AP_POOL_CLS), pool_dim (AP_POOL_ATTN) or 2 * dim (AP_POOL_CLS_MEAN) */
 
 /* Optional per-launch timing with HIP events recorded on the forward's own stream (what
  * bench.py's roofline block reads).  Off by default; when on, every kernel launch of a forward

@@ -221,12 +221,16 @@ def transform_resize_crop(patches_u8, *, resize, crop: int, mean=IMAGENET_MEAN, 
 
 @torch.inference_mode()
 def canonical_extract(sd: dict, patches_u8, *, heads: int, depth: int, image_size: int, resize=None, eps: float = 1e-6,
-                      batch: int = 8) -> np.ndarray:
-    """extract_batch of a class-token-pooled encoder from canonical parameters: transform -> tokens -> LN -> token 0."""
+                      batch: int = 8, pool: str = "cls", mean=IMAGENET_MEAN, std=IMAGENET_STD) -> np.ndarray:
+    """extract_batch of an encoder from canonical parameters: transform -> tokens -> LN -> token 0 (``pool="cls"``) or
+    torch.cat([token 0, patch tokens.mean(1)], -1) (``pool="cls_mean"``: models/patch/midnight.py:58-61, virchow.py:58-61;
+    register tokens are not patch tokens, virchow.py:111-114)."""
     outs = []
+    prefix = 1 + (sd["reg_tokens"].shape[0] if "reg_tokens" in sd else 0)
     for s in range(0, len(patches_u8), batch):
-        x = transform_resize_crop(patches_u8[s:s + batch], resize=resize, crop=image_size)
-        outs.append(vit_tokens_canonical(sd, x, heads=heads, depth=depth, eps=eps)[:, 0])
+        x = transform_resize_crop(patches_u8[s:s + batch], resize=resize, crop=image_size, mean=mean, std=std)
+        tok = vit_tokens_canonical(sd, x, heads=heads, depth=depth, eps=eps)
+        outs.append(tok[:, 0] if pool == "cls" else torch.cat([tok[:, 0], tok[:, prefix:].mean(1)], dim=-1))
     return torch.cat(outs, 0).to(torch.float32).numpy()
 
 

@@ -102,8 +102,11 @@ def test_oracle_matches_hf_dinov2_with_resampled_positions(swiglu, grid_ckpt, gr
     got = vit_oracle.vit_tokens_canonical(sd, x, heads=2, depth=2)
     assert got.shape == out.last_hidden_state.shape == (3, 1 + grid_in * grid_in, 128)
     assert _rel(got.numpy(), out.last_hidden_state.numpy()) <= 2e-6
-    # what the reference returns: last_hidden_state[:, 0] (dinov2.py:58-60)
+    # what the reference returns: last_hidden_state[:, 0] (dinov2.py:58-60); midnight.py:58-61: class token | mean patch token
     assert _rel(got[:, 0].numpy(), out.last_hidden_state[:, 0].numpy()) <= 2e-6
+    lhs = out.last_hidden_state
+    want = torch.cat([lhs[:, 0, :], lhs[:, 1:, :].mean(1)], dim=-1).numpy()
+    assert _rel(torch.cat([got[:, 0], got[:, 1:].mean(1)], -1).numpy(), want) <= 2e-6
 
 
 def test_oracle_matches_hf_vit_with_the_phikon_layer_norm_eps():
@@ -150,7 +153,9 @@ def test_registry_has_the_reference_names_of_the_three_encoder_files():
     from atlaspatch_amd.encoders.vit import ARCHS, TRANSFORM_RESIZE
     names = build_default_registry(device="cpu").available()
     for n in ("vit_b_16", "vit_b_32", "vit_l_16", "vit_l_32", "vit_h_14", "uni_v1", "uni_v2", "conch_v1",
-              "dinov2_small", "dinov2_base", "dinov2_large", "dinov2_giant", "phikon_v1", "phikon_v2"):       # dinov2.py:12-17, phikon.py
+              "dinov2_small", "dinov2_base", "dinov2_large", "dinov2_giant", "phikon_v1", "phikon_v2",        # dinov2.py:12-17, phikon.py
+              "midnight", "h_optimus_0", "h_optimus_1", "prov_gigapath", "lunit_vit_small_patch16_dino",
+              "lunit_vit_small_patch8_dino", "pathorchestra"):
         assert n in names and n in ARCHS and n in TRANSFORM_RESIZE
     g = ARCHS["dinov2_giant"]
     assert (g["dim"], g["depth"], g["heads"], g["mlp_dim"]) == (1536, 40, 24, (int(1536 * 4 * 2 / 3) + 7) // 8 * 8)
@@ -193,6 +198,19 @@ MEASURED.update({                     # the transformers-backed encoders (dinov2
     ("phikon_v1 L12", "float32"): (1.949e-6, 2.594e-5, 2.134e-5),
     ("phikon_v2 L24", "float16"): (1.589e-3, 2.143e-2, 1.685e-2),
     ("phikon_v2 L24, f32_stream", "float16"): (9.86e-4, 1.527e-2, 1.200e-2),
+    # midnight.py (class token | mean patch token: the mean averages the patch rows' errors), the timm-hub ViTs
+    ("midnight L40", "float16"): (3.017e-3, 4.090e-2, 3.155e-2),
+    ("midnight L40, f32_stream", "float16"): (2.408e-3, 3.742e-2, 2.504e-2),
+    ("h_optimus_0 L40", "float16"): (2.081e-3, 2.721e-2, 1.881e-2),
+    ("h_optimus_0 L40, f32_stream", "float16"): (1.214e-3, 1.546e-2, 1.353e-2),
+    ("prov_gigapath L40", "float16"): (4.525e-3, 7.961e-2, 5.496e-2),
+    ("prov_gigapath L40, f32_stream", "float16"): (3.821e-3, 4.545e-2, 3.699e-2),
+    ("lunit_vit_small_patch16_dino L12", "float16"): (1.231e-3, 1.642e-2, 1.196e-2),
+    ("lunit_vit_small_patch16_dino L12, f32_stream", "float16"): (8.39e-4, 1.278e-2, 1.089e-2),
+    ("lunit_vit_small_patch8_dino L12", "float16"): (1.204e-3, 1.495e-2, 1.269e-2),
+    ("lunit_vit_small_patch8_dino L12, f32_stream", "float16"): (8.37e-4, 1.174e-2, 1.005e-2),
+    ("pathorchestra L24", "float16"): (1.706e-3, 1.989e-2, 1.422e-2),
+    ("pathorchestra L24, f32_stream", "float16"): (1.008e-3, 1.532e-2, 1.154e-2),
 })
 HEADROOM = (1.2, 1.5, 1.25)
 FALLBACK = {"float32": (3.0e-6, 6e-5, 4e-5), "float16": (3.6e-3, 5.2e-2, 3.8e-2)}
@@ -235,15 +253,21 @@ def _with_layer_scale(sd, arch, seed):
                                           ("dinov2_small", torch.float16, 8), ("dinov2_small", torch.float32, 8),
                                           ("dinov2_base", torch.float16, 8), ("dinov2_large", torch.float16, 6),
                                           ("dinov2_giant", torch.float16, 4), ("phikon_v1", torch.float16, 8),
-                                          ("phikon_v1", torch.float32, 8), ("phikon_v2", torch.float16, 6)])
+                                          ("phikon_v1", torch.float32, 8), ("phikon_v2", torch.float16, 6),
+                                          ("midnight", torch.float16, 4), ("h_optimus_0", torch.float16, 4),
+                                          ("prov_gigapath", torch.float16, 4), ("lunit_vit_small_patch16_dino", torch.float16, 8),
+                                          ("lunit_vit_small_patch8_dino", torch.float16, 4), ("pathorchestra", torch.float16, 6)])
 def test_encoder_at_real_size_vs_fp32_oracle(name, dtype, n):
-    from atlaspatch_amd.encoders.vit import ARCHS, TRANSFORM_RESIZE, build_hip_vit_extractor, random_canonical_state_dict
+    from atlaspatch_amd.encoders.vit import (ARCHS, IMAGENET_MEAN, IMAGENET_STD, TRANSFORM_NORM, TRANSFORM_RESIZE, build_hip_vit_extractor,
+                                             random_canonical_state_dict)
     from oracle import vit_oracle
     torch.set_num_threads(min(32, torch.get_num_threads()))
     arch = dict(ARCHS[name])
+    mean, std = TRANSFORM_NORM.get(name, (IMAGENET_MEAN, IMAGENET_STD))
+    pool = arch.get("pool", "cls")
     sd = _with_layer_scale(random_canonical_state_dict(arch, seed=41), arch, 42)
     ex = build_hip_vit_extractor(name=name, arch=arch, state_dict=sd, source="canonical", device=torch.device("cuda:0"), dtype=dtype,
-                                 resize=TRANSFORM_RESIZE[name], expect_size=None, max_batch=64)
+                                 resize=TRANSFORM_RESIZE[name], expect_size=None, max_batch=64, mean=mean, std=std)
     tiles = _tiles(n, 43)
     got = ex.extract_batch(tiles, batch_size=32)
     got_f32s = None
@@ -254,10 +278,12 @@ def test_encoder_at_real_size_vs_fp32_oracle(name, dtype, n):
         ex.vit.set_option("full_last_block", True)
         got_full = ex.extract_batch(tiles, batch_size=32)
         assert _rel(got_full, got) <= 2e-3                          # the CLS-only tail and the full last block agree
+        if pool == "cls_mean":
+            assert np.array_equal(got_full, got)                    # (this pooling always runs the full last block)
     ex.cleanup()
     want = vit_oracle.canonical_extract(sd, tiles, heads=arch["heads"], depth=arch["depth"], image_size=arch["image_size"],
-                                        resize=TRANSFORM_RESIZE[name], batch=2, eps=arch["ln_eps"])
-    assert got.shape == want.shape == (n, arch["dim"]) and got.dtype == np.float32
+                                        resize=TRANSFORM_RESIZE[name], batch=2, eps=arch["ln_eps"], pool=pool, mean=mean, std=std)
+    assert got.shape == want.shape == (n, arch["dim"] * (2 if pool == "cls_mean" else 1)) and got.dtype == np.float32
     _check(got, want, dtype, f"{name} L{arch['depth']}")
     if got_f32s is not None:
         _check(got_f32s, want, dtype, f"{name} L{arch['depth']}, f32_stream")
@@ -314,4 +340,32 @@ def test_dinov2_checkpoint_with_a_518px_position_grid_on_the_device_vs_the_hf_mo
     with torch.inference_mode():
         want = model(pixel_values=x).last_hidden_state[:, 0].numpy()
     assert got.shape == want.shape == (5, 384)
+    assert _rel(got, want) <= tol, _rel(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float16, 4e-3)])
+def test_class_token_plus_mean_patch_token_on_the_device_vs_the_hf_model(dtype, tol):
+    """midnight.py:56-61 on an HF Dinov2Model (SwiGLU, LayerScale, 37 x 37 position grid), 4 blocks of dim 384: the device's
+    AP_POOL_CLS_MEAN output against torch.cat([cls, patch_tokens.mean(1)], -1) of the HF model itself."""
+    from transformers import Dinov2Config, Dinov2Model
+    from atlaspatch_amd.encoders.vit import build_hip_vit_extractor
+    from oracle import vit_oracle
+    torch.manual_seed(0)
+    cfg = Dinov2Config(hidden_size=384, num_hidden_layers=4, num_attention_heads=6, mlp_ratio=4, use_swiglu_ffn=True, patch_size=14,
+                       image_size=518, layerscale_value=1.0, layer_norm_eps=1e-6)
+    model = _seed_params(Dinov2Model(cfg).eval())
+    arch = dict(image_size=224, patch_size=14, dim=384, depth=4, heads=6, mlp_dim=1024, ln_eps=1e-6, layer_scale=True,
+                no_embed_class=True, mlp="swiglu", pool="cls_mean")
+    ex = build_hip_vit_extractor(name="midnight", arch=arch, state_dict=dict(model.state_dict()), device=torch.device("cuda:0"),
+                                 dtype=dtype, resize=(224, "bilinear"), expect_size=None, max_batch=64, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5))
+    assert ex.embedding_dim == 768
+    tiles = _tiles(5, 59)
+    got = ex.extract_batch(tiles, batch_size=32)
+    ex.cleanup()
+    x = vit_oracle.transform_resize_crop(tiles, resize=(224, "bilinear"), crop=224, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5))
+    with torch.inference_mode():
+        lhs = model(x).last_hidden_state
+        want = torch.cat([lhs[:, 0, :], lhs[:, 1:, :].mean(1)], dim=-1).numpy()
+    assert got.shape == want.shape == (5, 768)
     assert _rel(got, want) <= tol, _rel(got, want)

@@ -92,22 +92,22 @@ namespace ap {
 namespace {
 __global__ __launch_bounds__(64) void clock_probe_kernel(long long* __restrict__ out) {
     if (threadIdx.x != 0) return;
-    const unsigned xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 15u;      // HW_REG_XCC_ID[3:0]
-    const long long t = (long long)__builtin_amdgcn_s_memtime();
-    const long long r = (long long)__builtin_amdgcn_s_memrealtime();
-    if (xcc < 8) {
-        out[xcc * 4 + 0] = t;
-        out[xcc * 4 + 1] = r;
-        out[xcc * 4 + 2] = (long long)xcc;
-        out[xcc * 4 + 3] = (long long)blockIdx.x;
-    }
+    const unsigned xcc = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) & 7u;       // HW_REG_XCC_ID[3:0]
+    const unsigned hw = __builtin_amdgcn_s_getreg(((16 - 1) << 11) | (0 << 6) | 4);             // HW_REG_HW_ID[15:0]
+    const unsigned cu = (hw >> 8) & 15u, sh = (hw >> 12) & 1u, se = (hw >> 13) & 7u;
+    const unsigned slot = (xcc << 8) | (se << 5) | (sh << 4) | cu;
+    typedef long long ll2 __attribute__((ext_vector_type(2)));
+    ll2 v;
+    v[0] = (long long)__builtin_amdgcn_s_memtime();
+    v[1] = (long long)__builtin_amdgcn_s_memrealtime();
+    *(ll2*)(out + 2 * slot) = v;                                                                 // one 16-byte store per stamp
 }
 }  // namespace
 }  // namespace ap
 
-extern "C" int ap_clock_probe(long long* out32, ap_stream_t stream) {
-    AP_REQUIRE(out32, "ap_clock_probe: null pointer");
-    ap::clock_probe_kernel<<<32, 64, 0, (hipStream_t)stream>>>(out32);
+extern "C" int ap_clock_probe(long long* out, ap_stream_t stream) {
+    AP_REQUIRE(out, "ap_clock_probe: null pointer");
+    ap::clock_probe_kernel<<<1024, 64, 0, (hipStream_t)stream>>>(out);
     AP_HIP_CHECK(hipGetLastError());
     return AP_OK;
 }

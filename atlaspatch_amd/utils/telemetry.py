@@ -23,11 +23,13 @@ from .. import _lib
 
 
 class ClockProbe:
+    SLOTS = 2048            # AP_CLOCK_PROBE_SLOTS: xcc << 8 | se << 5 | sh << 4 | cu
+
     def __init__(self, device) -> None:
         self.device = torch.device(device)
         self.lib = _lib.load()
-        self.a = torch.zeros(32, dtype=torch.int64, device=self.device)
-        self.b = torch.zeros(32, dtype=torch.int64, device=self.device)
+        self.a = torch.zeros(2 * self.SLOTS, dtype=torch.int64, device=self.device)
+        self.b = torch.zeros(2 * self.SLOTS, dtype=torch.int64, device=self.device)
 
     def _stamp(self, buf) -> None:
         with torch.cuda.device(self.device):
@@ -41,21 +43,30 @@ class ClockProbe:
         self._stamp(self.b)
 
     def read(self) -> dict:
-        """Call after a synchronize.  Per XCD that both probes touched: GHz = 0.1 * d(memtime) / d(memrealtime)."""
-        a = self.a.cpu().numpy().reshape(8, 4); b = self.b.cpu().numpy().reshape(8, 4)
+        """Call after a synchronize.  Per compute unit that both probes reached: GHz = 0.1 * d(memtime) / d(memrealtime) (the
+        s_memtime counters of different compute units are not aligned, so only same-unit stamps are differenced); per XCD the
+        median over its units, overall the median over the XCDs."""
+        import numpy as np
+        a = self.a.cpu().numpy().reshape(self.SLOTS, 2); b = self.b.cpu().numpy().reshape(self.SLOTS, 2)
+        ok = (a[:, 1] > 0) & (b[:, 1] > a[:, 1]) & (b[:, 0] > a[:, 0])
+        if not ok.any():
+            return {"shader_clock_GHz": None, "xcds": 0}
+        ghz = np.where(ok, 0.1 * (b[:, 0] - a[:, 0]) / np.maximum(b[:, 1] - a[:, 1], 1), np.nan)
         per = {}
         for x in range(8):
-            dt, dr = int(b[x, 0] - a[x, 0]), int(b[x, 1] - a[x, 1])
-            if a[x, 1] > 0 and b[x, 1] > 0 and dr > 0 and dt > 0:
-                per[x] = 0.1 * dt / dr
-        if not per:
-            return {"shader_clock_GHz": None, "xcds": 0}
+            v = ghz[x * 256:(x + 1) * 256]
+            v = v[~np.isnan(v)]
+            if v.size:
+                per[x] = float(np.median(v))
         vals = sorted(per.values())
+        allv = ghz[~np.isnan(ghz)]
         return {"shader_clock_GHz": round(vals[len(vals) // 2], 4), "min_GHz": round(vals[0], 4), "max_GHz": round(vals[-1], 4),
                 "mean_GHz": round(sum(vals) / len(vals), 4), "per_xcd_GHz": [round(per[x], 4) if x in per else None for x in range(8)],
-                "xcds": len(vals), "region_ms": round(max(int(b[x, 1] - a[x, 1]) for x in per) / 1e5, 3),
-                "method": "s_memtime / s_memrealtime stamps per XCD (ap_clock_probe) on the launch stream before the first and "
-                          "after the last timed step; median over XCDs"}
+                "xcds": len(vals), "compute_units": int(ok.sum()),
+                "cu_spread_GHz": [round(float(np.percentile(allv, 5)), 4), round(float(np.percentile(allv, 95)), 4)],
+                "region_ms": round(float((b[ok, 1] - a[ok, 1]).max()) / 1e5, 3),
+                "method": "s_memtime / s_memrealtime stamps per compute unit (ap_clock_probe) on the launch stream before the first "
+                          "and after the last timed step; per XCD the median over its compute units, then the median over XCDs"}
 
 
 def _device_bdf(device):

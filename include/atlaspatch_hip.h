@@ -442,11 +442,15 @@ int ap_synth_region(int64_t x, int64_t y, int w, int h, int level_ds, int level,
                     int64_t width, int64_t height, uint32_t seed,
                     const int64_t* ellipses, int k, uint8_t* dst, ap_stream_t stream);
 
-/* Measurement aid (bench.py): one launch writes, per XCD x (HW_REG_XCC_ID), out32[4x + 0] = s_memtime (shader-clock ticks),
- * out32[4x + 1] = s_memrealtime (100 MHz ticks), out32[4x + 2] = x, out32[4x + 3] = the workgroup that wrote the slot.
- * out32: 32 int64 in device memory, zeroed by the caller.  Two probes on one stream around a region give the average
- * shader clock there: GHz = 0.1 * d(memtime) / d(memrealtime).  No reference counterpart. */
-int ap_clock_probe(long long* out32, ap_stream_t stream);
+/* Measurement aid (bench.py): one launch of 1024 single-wave workgroups; each writes, into the slot of the compute unit it ran on
+ * -- slot = XCC_ID (3 bits) << 8 | SE_ID (3) << 5 | SH_ID (1) << 4 | CU_ID (4), from HW_REG_XCC_ID / HW_REG_HW_ID -- the pair
+ * out[2 slot + 0] = s_memtime (shader-clock ticks), out[2 slot + 1] = s_memrealtime (100 MHz ticks) as one 16-byte store.
+ * s_memtime counters of different compute units are NOT aligned with each other (offsets of 1e7 ticks and more inside one XCD),
+ * so only stamps of the SAME compute unit may be differenced.  out: AP_CLOCK_PROBE_SLOTS * 2 int64 in device memory, zeroed by
+ * the caller.  Two probes on one stream around a region give the average shader clock there per compute unit that both reached:
+ * GHz = 0.1 * d(memtime) / d(memrealtime).  No reference counterpart.  (ABI v18: v17 keyed the slots by XCD only.) */
+#define AP_CLOCK_PROBE_SLOTS 2048
+int ap_clock_probe(long long* out, ap_stream_t stream);
 
 #ifdef __cplusplus
 }

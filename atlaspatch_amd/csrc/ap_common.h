@@ -73,6 +73,14 @@ __device__ __forceinline__ f32x2_t gelu_sigmoid_poly2(f32x2_t x) {
     return x * f32x2_t{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
 }
 
+// CLIP's QuickGELU (models/patch/clip.py: the OpenAI weights; transformers "quick_gelu"): x * sigmoid(1.702 x), two values, f32
+// (exp2 + rcp; both GEMM kernels call THIS routine)
+__device__ __forceinline__ f32x2_t quick_gelu2(f32x2_t x) {
+    const f32x2_t z = x * f32x2_t{-1.702f * 1.4426950408889634f, -1.702f * 1.4426950408889634f};
+    const f32x2_t d = f32x2_t{1.0f, 1.0f} + f32x2_t{__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])};
+    return x * f32x2_t{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+}
+
 // silu(a) * b for two values, f32 (exp2 + rcp; both GEMM kernels call THIS routine so that they stay bit-identical)
 __device__ __forceinline__ f32x2_t swiglu2(f32x2_t a, f32x2_t b) {
     const f32x2_t z = a * f32x2_t{-1.4426950408889634f, -1.4426950408889634f};
@@ -106,6 +114,8 @@ enum GemmEpilogue {
     // 64q .. 64q+31 = fc1 rows 32q .. 32q+31 (x1), rows 64q+32 .. 64q+63 = fc1 rows H+32q .. (x2) -- so that a wave's two 32-wide
     // n blocks hold x1 and x2 of the same 32 output columns; out[m][32q + j] = T(silu(norm(x1)) * norm(x2)), out: T [M, N / 2]
     EPI_NORM_SWIGLU = 8,
+    EPI_NORM_QGELU = 9,    // EPI_NORM_GELU with CLIP's QuickGELU x * sigmoid(1.702 x)
+    EPI_BIAS_QGELU = 10,   // EPI_BIAS_GELU likewise
 };
 
 struct GemmArgs {

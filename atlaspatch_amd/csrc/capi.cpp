@@ -160,7 +160,7 @@ int ap_gemm(int dtype, int epilogue, const void* A, int lda, const void* W, int 
             int K, const float* bias, const float* gamma, void* out, int ldo, int impl, int variant,
             ap_stream_t stream) {
     AP_REQUIRE(A && W && bias && out, "ap_gemm: null pointer");
-    AP_REQUIRE(epilogue == AP_EPI_BIAS || epilogue == AP_EPI_BIAS_GELU || epilogue == AP_EPI_BIAS_RESID,
+    AP_REQUIRE(epilogue == AP_EPI_BIAS || epilogue == AP_EPI_BIAS_GELU || epilogue == AP_EPI_BIAS_RESID || epilogue == AP_EPI_BIAS_QUICK_GELU,
                "ap_gemm: unknown epilogue %d", epilogue);
     AP_REQUIRE(dtype == AP_F16 || dtype == AP_BF16 || dtype == AP_F32, "ap_gemm: unknown dtype %d", dtype);
     ap::GemmArgs g{};
@@ -178,6 +178,7 @@ int ap_gemm_fused(int dtype, int epilogue, const void* A, int lda, const void* W
     if (epilogue == AP_EPI_NORM) epi = ap::EPI_NORM_STORE;
     else if (epilogue == AP_EPI_NORM_GELU) epi = ap::EPI_NORM_GELU;
     else if (epilogue == AP_EPI_NORM_SWIGLU) epi = ap::EPI_NORM_SWIGLU;
+    else if (epilogue == AP_EPI_NORM_QUICK_GELU) epi = ap::EPI_NORM_QGELU;
     else if (epilogue == AP_EPI_RESID_STATS) epi = ap::EPI_RESID_STATS;
     else { ap::set_error("ap_gemm_fused: unknown epilogue %d", epilogue); return AP_ERR_INVALID; }
     AP_REQUIRE(epi == ap::EPI_RESID_STATS ? partial != nullptr : (colsum && rowstats), "ap_gemm_fused: missing operand for epilogue %d", epilogue);

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             const f32x4 b4 = *(const f32x4*)(g.bias + n0 + wave_n * 64 + nt * 32 + g4 * 8 + hi * 4);
-            constexpr bool kNormInit = EPI == EPI_NORM_STORE || EPI == EPI_NORM_GELU || EPI == EPI_NORM_SWIGLU;     // (these start from zero)
+            constexpr bool kNormInit = EPI == EPI_NORM_STORE || EPI == EPI_NORM_GELU || EPI == EPI_NORM_SWIGLU || EPI == EPI_NORM_QGELU;   // (these start from zero)
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
         }
         return;
     }
-    if constexpr (sizeof(T) == 2 && (EPI == EPI_NORM_STORE || EPI == EPI_NORM_GELU)) {
+    if constexpr (sizeof(T) == 2 && (EPI == EPI_NORM_STORE || EPI == EPI_NORM_GELU || EPI == EPI_NORM_QGELU)) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const int m = m0 + wave_m * 64 + mt * 32 + l31;
@@ -284,6 +284,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
                     v = f32x4{lo[0], lo[1], hi2[0], hi2[1]};
                     if constexpr (EPI == EPI_NORM_GELU) {
                         const f32x2_t a = gelu_sigmoid_poly2(f32x2_t{v[0], v[1]}), b = gelu_sigmoid_poly2(f32x2_t{v[2], v[3]});
+                        v = f32x4{a[0], a[1], b[0], b[1]};
+                    }
+                    if constexpr (EPI == EPI_NORM_QGELU) {
+                        const f32x2_t a = quick_gelu2(f32x2_t{v[0], v[1]}), b = quick_gelu2(f32x2_t{v[2], v[3]});
                         v = f32x4{a[0], a[1], b[0], b[1]};
                     }
                     store4<T>((T*)g.out + (size_t)m * (size_t)g.ldo + n, v);
@@ -371,6 +375,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
                         v = f32x4{lo[0], lo[1], hi2[0], hi2[1]};
                     }
                     store4<T>((T*)g.out + orow + n, v);
+                } else if constexpr (EPI == EPI_BIAS_QGELU) {
+                    if constexpr (sizeof(T) == 2) {      // the packed routine of gemm256 (bit-identical); float32: libm expf
+                        const f32x2_t lo = quick_gelu2(f32x2_t{v[0], v[1]}), hi2 = quick_gelu2(f32x2_t{v[2], v[3]});
+                        v = f32x4{lo[0], lo[1], hi2[0], hi2[1]};
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.0f + expf(-1.702f * v[e]));
+                    }
+                    store4<T>((T*)g.out + orow + n, v);
                 } else if constexpr (EPI == EPI_BIAS_RESID) {
                     float* dst = (float*)g.out + orow + n;
                     f32x4 r = *(const f32x4*)dst;
@@ -405,6 +418,8 @@ int launch_typed(int epilogue, const GemmArgs& a, hipStream_t stream) {
         case EPI_NORM_STORE: gemm_kernel<T, EPI_NORM_STORE><<<grid, block, 0, stream>>>(a); break;
         case EPI_NORM_GELU: gemm_kernel<T, EPI_NORM_GELU><<<grid, block, 0, stream>>>(a); break;
         case EPI_NORM_SWIGLU: gemm_kernel<T, EPI_NORM_SWIGLU><<<grid, block, 0, stream>>>(a); break;
+        case EPI_NORM_QGELU: gemm_kernel<T, EPI_NORM_QGELU><<<grid, block, 0, stream>>>(a); break;
+        case EPI_BIAS_QGELU: gemm_kernel<T, EPI_BIAS_QGELU><<<grid, block, 0, stream>>>(a); break;
         case EPI_RESID_STATS: gemm_kernel<T, EPI_RESID_STATS><<<grid, block, 0, stream>>>(a); break;
         case EPI_PATCH_STREAM: gemm_kernel<T, EPI_PATCH_STREAM><<<grid, block, 0, stream>>>(a); break;
         default: set_error("gemm: unknown epilogue %d", epilogue); return AP_ERR_INVALID;
@@ -431,7 +446,8 @@ int launch_gemm_impl(int dtype, int epilogue, const GemmArgs& a, int impl, int v
         return AP_ERR_UNSUPPORTED;
 #endif
     }
-    const bool fused_epi = epilogue == EPI_NORM_STORE || epilogue == EPI_NORM_GELU || epilogue == EPI_NORM_SWIGLU || epilogue == EPI_RESID_STATS ||
+    const bool fused_epi = epilogue == EPI_NORM_STORE || epilogue == EPI_NORM_GELU || epilogue == EPI_NORM_SWIGLU || epilogue == EPI_NORM_QGELU ||
+                           epilogue == EPI_RESID_STATS ||
                            epilogue == EPI_PATCH_STREAM;
     AP_REQUIRE(!fused_epi || dtype != AP_F32, "gemm: the fused-LayerNorm epilogues are f16 / bf16 only");
     AP_REQUIRE(!fused_epi || (epilogue == EPI_RESID_STATS ? a.partial != nullptr :

@@ -112,7 +112,7 @@ template <typename T, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) char smem[kLdsBytes];
 
-    constexpr bool kNorm = EPI == EPI_NORM_STORE || EPI == EPI_NORM_GELU || EPI == EPI_NORM_SWIGLU;
+    constexpr bool kNorm = EPI == EPI_NORM_STORE || EPI == EPI_NORM_GELU || EPI == EPI_NORM_SWIGLU || EPI == EPI_NORM_QGELU;
     constexpr bool kSwiglu = EPI == EPI_NORM_SWIGLU;       // x1 | x2 in the wave's two n blocks -> 32 gated output columns
     constexpr bool kPatch = EPI == EPI_PATCH_STREAM;
     constexpr bool kRes = EPI == EPI_RESID_STATS || kPatch;
@@ -586,6 +586,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
                             const f32x2_t lo = gelu_sigmoid_poly2(f32x2_t{v[0], v[1]}), hi2 = gelu_sigmoid_poly2(f32x2_t{v[2], v[3]});
                             v = f32x4{lo[0], lo[1], hi2[0], hi2[1]};
                         }
+                        if constexpr (EPI == EPI_BIAS_QGELU || EPI == EPI_NORM_QGELU) {
+                            const f32x2_t lo = quick_gelu2(f32x2_t{v[0], v[1]}), hi2 = quick_gelu2(f32x2_t{v[2], v[3]});
+                            v = f32x4{lo[0], lo[1], hi2[0], hi2[1]};
+                        }
                         if (has_gamma) {
                             const f32x4 ga = *(const f32x4*)(gp + nb * 32 + g4 * 8);
 #pragma unroll
@@ -650,6 +654,8 @@ int launch_typed(int epilogue, const GemmArgs& a, int num_cu, int variant, hipSt
         case EPI_NORM_STORE: return launch_epi<T, EPI_NORM_STORE>(a, num_cu, variant, stream);
         case EPI_NORM_GELU: return launch_epi<T, EPI_NORM_GELU>(a, num_cu, variant, stream);
         case EPI_NORM_SWIGLU: return launch_epi<T, EPI_NORM_SWIGLU>(a, num_cu, variant, stream);
+        case EPI_NORM_QGELU: return launch_epi<T, EPI_NORM_QGELU>(a, num_cu, variant, stream);
+        case EPI_BIAS_QGELU: return launch_epi<T, EPI_BIAS_QGELU>(a, num_cu, variant, stream);
         case EPI_RESID_STATS: return launch_epi<T, EPI_RESID_STATS>(a, num_cu, variant, stream);
         case EPI_PATCH_STREAM: return launch_epi<T, EPI_PATCH_STREAM>(a, num_cu, variant, stream);
     }
@@ -672,10 +678,12 @@ bool AP_G256_FN(gemm256_supports)(int dtype, int epilogue, const GemmArgs& a) {
     if (dtype != AP_F16 && dtype != AP_BF16) return false;
     if (epilogue != EPI_BIAS_STORE && epilogue != EPI_BIAS_GELU && epilogue != EPI_BIAS_RESID &&
         epilogue != EPI_NORM_STORE && epilogue != EPI_NORM_GELU && epilogue != EPI_NORM_SWIGLU && epilogue != EPI_RESID_STATS &&
+        epilogue != EPI_NORM_QGELU && epilogue != EPI_BIAS_QGELU &&
         epilogue != EPI_PATCH_STREAM)
         return false;
     if (epilogue == EPI_PATCH_STREAM && (!a.partial || !a.pos16 || a.P <= 0 || a.R <= 0 || a.M >= (1 << 24))) return false;
-    if ((epilogue == EPI_NORM_STORE || epilogue == EPI_NORM_GELU || epilogue == EPI_NORM_SWIGLU) && (!a.colsum || !a.rowstats)) return false;
+    if ((epilogue == EPI_NORM_STORE || epilogue == EPI_NORM_GELU || epilogue == EPI_NORM_SWIGLU || epilogue == EPI_NORM_QGELU) &&
+        (!a.colsum || !a.rowstats)) return false;
     if (epilogue == EPI_RESID_STATS && !a.partial) return false;
     if (a.N % kBN != 0 || a.K % 128 != 0 || a.K < 128) return false;
     if (((size_t)a.lda * 2) % 16 != 0 || ((size_t)a.ldw * 2) % 16 != 0) return false;

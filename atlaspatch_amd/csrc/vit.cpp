@@ -65,6 +65,9 @@ struct ap_vit {
     ap::PoolParams pool{};
     const ap::Param* pe_w = nullptr;
     const float *pe_b = nullptr, *cls = nullptr, *pos = nullptr, *norm_w = nullptr, *norm_b = nullptr;
+    const float *pre_w = nullptr, *pre_b = nullptr;        // CLIP ln_pre
+    const ap::Param* head_proj = nullptr;                       // CLIP visual projection [P, dim]
+    float* zero_bias = nullptr;                             // f32 [proj_dim] zeros (the projection has no bias)
     // options (ap_vit_set_option; the defaults come from the environment once, at creation)
     bool full_last_block = false, two_half_overlap = false, f32_stream = false;
     std::vector<ap::FusedBlock> fused;      // filled by ap_vit_finalize for f16 / bf16
@@ -270,7 +273,7 @@ int blocks_f32_stream(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipS
                 ap::GemmArgs g{};
                 g.A = w.xn; g.lda = D; g.W = bp.fc1->dev; g.ldw = bp.fc1->ld;
                 g.M = n; g.N = F1; g.K = D; g.bias = bp.fc1_b; g.out = w.hid; g.ldo = F1;
-                if ((rc = ap::launch_gemm_impl(dt, swiglu ? ap::EPI_BIAS_STORE : ap::EPI_BIAS_GELU, g, 128, 0, stream)) != AP_OK) return rc;
+                if ((rc = ap::launch_gemm_impl(dt, swiglu ? ap::EPI_BIAS_STORE : (c.act == AP_ACT_QUICK_GELU ? ap::EPI_BIAS_QGELU : ap::EPI_BIAS_GELU), g, 128, 0, stream)) != AP_OK) return rc;
                 if (swiglu && (rc = ap::launch_swiglu(dt, w.hid, n, H, w.hid2, stream)) != AP_OK) return rc;
             }
             {
@@ -311,7 +314,7 @@ int blocks_f32_stream(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipS
             g.A = w.xn; g.lda = D; g.W = bp.fc1->dev; g.ldw = bp.fc1->ld;
             g.M = M; g.N = F1; g.K = D; g.bias = bp.fc1_b; g.out = w.hid; g.ldo = F1;
             ScopedTimer t(m, AP_PROF_GEMM_FC1, stream);
-            if ((rc = ap::launch_gemm(dt, swiglu ? ap::EPI_BIAS_STORE : ap::EPI_BIAS_GELU, g, stream)) != AP_OK) return rc;
+            if ((rc = ap::launch_gemm(dt, swiglu ? ap::EPI_BIAS_STORE : (c.act == AP_ACT_QUICK_GELU ? ap::EPI_BIAS_QGELU : ap::EPI_BIAS_GELU), g, stream)) != AP_OK) return rc;
             if (swiglu && (rc = ap::launch_swiglu(dt, w.hid, M, H, w.hid2, stream)) != AP_OK) return rc;
         }
         {
@@ -389,7 +392,7 @@ int blocks_fused(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipStream
                 ap::GemmArgs g{};
                 g.A = w.xn; g.lda = D; g.W = bp.fc1->dev; g.ldw = bp.fc1->ld;
                 g.M = n; g.N = F1; g.K = D; g.bias = bp.fc1_b; g.out = w.hid; g.ldo = F1;
-                if ((rc = ap::launch_gemm_impl(dt, swiglu ? ap::EPI_BIAS_STORE : ap::EPI_BIAS_GELU, g, 128, 0, stream)) != AP_OK) return rc;
+                if ((rc = ap::launch_gemm_impl(dt, swiglu ? ap::EPI_BIAS_STORE : (c.act == AP_ACT_QUICK_GELU ? ap::EPI_BIAS_QGELU : ap::EPI_BIAS_GELU), g, 128, 0, stream)) != AP_OK) return rc;
                 if (swiglu && (rc = ap::launch_swiglu(dt, w.hid, n, H, w.hid2, stream)) != AP_OK) return rc;
             }
             {
@@ -427,7 +430,7 @@ int blocks_fused(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipStream
             // the gate runs in the epilogue on the f32 values: out = hid2 [M, H] directly, one rounding
             g.out = swiglu ? w.hid2 : w.hid; g.ldo = swiglu ? H : F1;
             ScopedTimer t(m, AP_PROF_GEMM_FC1, stream);
-            if ((rc = ap::launch_gemm(dt, swiglu ? ap::EPI_NORM_SWIGLU : ap::EPI_NORM_GELU, g, stream)) != AP_OK) return rc;
+            if ((rc = ap::launch_gemm(dt, swiglu ? ap::EPI_NORM_SWIGLU : (c.act == AP_ACT_QUICK_GELU ? ap::EPI_NORM_QGELU : ap::EPI_NORM_GELU), g, stream)) != AP_OK) return rc;
         }
         {
             ap::GemmArgs g{};
@@ -450,11 +453,31 @@ int run_blocks(ap_vit* m, int n, const Workspace& w, float* out, hipStream_t str
     int rc;
     const bool fused = dt != AP_F32 && !m->f32_stream;
     // K of the patch-embed GEMM is kpe (3 ps^2 padded to 64): the persistent kernel wants K % 128 == 0, the 128 x 128 one K % 64
-    if ((rc = fused ? patch_embed_stream(m, n, w, stream) : patch_embed(m, n, w, stream)) != AP_OK) return rc;
+    if (c.pre_norm) {
+        // CLIP ln_pre: the embedded tokens are normalised before the first block.  The f32 token matrix is built as in the
+        // f32-stream dataflow, normalised in place (row-wise kernel: a row is read whole before it is written), and -- fused
+        // dataflow -- rounded into the T stream together with its first row statistics (launch_stream_init)
+        if ((rc = patch_embed(m, n, w, stream)) != AP_OK) return rc;
+        { ScopedTimer t(m, AP_PROF_LAYERNORM, stream);
+          if ((rc = ap::launch_layernorm(AP_F32, w.tok, D, M, D, m->pre_w, m->pre_b, c.ln_eps, w.tok, stream)) != AP_OK) return rc;
+          if (fused && (rc = ap::launch_stream_init(dt, w.tok, M, D, c.ln_eps, w.x16, w.rowstats, stream)) != AP_OK) return rc; }
+    } else if ((rc = fused ? patch_embed_stream(m, n, w, stream) : patch_embed(m, n, w, stream)) != AP_OK) return rc;
     StreamTail st;
     if ((rc = fused ? blocks_fused(m, n, w, st, stream) : blocks_f32_stream(m, n, w, st, stream)) != AP_OK) return rc;
     const void* pending = st.pending;
     const float* pending_ls = st.pending_ls;
+    if (c.pool == AP_POOL_CLS && c.proj_dim > 0) {
+        // CLIP: final LayerNorm on the class rows in the compute type (xn, T [n, D]), the bias-free visual projection on the
+        // 128 x 128 kernel (att, T [n, P]), widened to f32.  (The reference's half-precision model does the same roundings.)
+        const int P = c.proj_dim;
+        if ((rc = ap::launch_add_layernorm(dt, dt, w.tok, st.tok_stride, pending, st.pending_stride, pending_ls, n, D, m->norm_w,
+                                           m->norm_b, c.ln_eps, w.xn, stream)) != AP_OK) return rc;
+        ap::GemmArgs g{};
+        g.A = w.xn; g.lda = D; g.W = m->head_proj->dev; g.ldw = m->head_proj->ld; g.M = n; g.N = P; g.K = D;
+        g.bias = m->zero_bias; g.out = dt == AP_F32 ? (void*)out : w.att; g.ldo = P;
+        if ((rc = ap::launch_gemm_impl(dt, ap::EPI_BIAS_STORE, g, 128, 0, stream)) != AP_OK) return rc;
+        return dt == AP_F32 ? AP_OK : ap::launch_stream_to_f32(dt, w.att, P, n, P, out, stream);
+    }
     if (c.pool == AP_POOL_CLS)
         // final LayerNorm on the CLS row of every image (last fc2 output folded in first) -> out f32 [n, D]
         return ap::launch_add_layernorm(dt, AP_F32, w.tok, st.tok_stride, pending, st.pending_stride, pending_ls,
@@ -544,6 +567,9 @@ int ap_vit_create(const ap_vit_config* cfg, ap_vit** out) {
                    2 * c.pool_dim <= c.mlp_dim && 2 * c.pool_dim <= 3 * c.dim,
                    "vit_create: pool_dim %d / pool_heads %d (heads of 64, multiple of 128)", c.pool_dim, c.pool_heads);
     }
+    AP_REQUIRE(c.act == AP_ACT_GELU || (c.act == AP_ACT_QUICK_GELU && c.mlp_type == AP_MLP_GELU), "vit_create: act %d", c.act);
+    AP_REQUIRE(c.proj_dim == 0 || (c.pool == AP_POOL_CLS && c.proj_dim % 128 == 0 && c.proj_dim <= c.dim),
+               "vit_create: proj_dim %d (class-token pooling, a multiple of 128, at most dim)", c.proj_dim);
     const int g = c.image_size / c.patch_size;
     const int prefix = 1 + c.reg_tokens;
     AP_REQUIRE(c.compute_dtype != AP_F32 || (prefix + g * g <= 288 && hd == 64),
@@ -574,6 +600,15 @@ int ap_vit_create(const ap_vit_config* cfg, ap_vit** out) {
     add("pos_embed", m->pos_rows, D, false);
     add("norm.weight", 1, D, false);
     add("norm.bias", 1, D, false);
+    if (c.pre_norm) { add("pre_norm.weight", 1, D, false); add("pre_norm.bias", 1, D, false); }
+    if (c.proj_dim > 0) {
+        add("head_proj.weight", c.proj_dim, D, true);
+        if (rc == AP_OK && (hipMalloc((void**)&m->zero_bias, (size_t)c.proj_dim * sizeof(float)) != hipSuccess ||
+                            hipMemset(m->zero_bias, 0, (size_t)c.proj_dim * sizeof(float)) != hipSuccess)) {
+            ap::set_error("vit_create: hipMalloc of the projection's zero bias failed");
+            rc = AP_ERR_HIP;
+        }
+    }
     for (int i = 0; i < c.depth; ++i) {
         const std::string b = "blocks." + std::to_string(i) + ".";
         add(b + "ln1.weight", 1, D, false); add(b + "ln1.bias", 1, D, false);
@@ -605,6 +640,7 @@ void ap_vit_destroy(ap_vit* m) {
     }
     for (void* p : m->fused_allocs) (void)hipFree(p);
     if (m->prefix_dev) (void)hipFree(m->prefix_dev);
+    if (m->zero_bias) (void)hipFree(m->zero_bias);
     for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->ev_join) (void)hipEventDestroy(m->ev_join);
@@ -742,6 +778,8 @@ int ap_vit_finalize(ap_vit* m) {
     m->pe_w = find(m, "patch_embed.weight");
     m->pe_b = vec("patch_embed.bias"); m->cls = vec("cls_token"); m->pos = vec("pos_embed");
     m->norm_w = vec("norm.weight"); m->norm_b = vec("norm.bias");
+    m->pre_w = vec("pre_norm.weight"); m->pre_b = vec("pre_norm.bias");
+    m->head_proj = m->cfg.proj_dim > 0 ? find(m, "head_proj.weight") : nullptr;
     {   // class / register token rows with their position rows folded in (f32; rebuilt on every finalize: it is tiny)
         if (!m->prefix_dev) AP_HIP_CHECK(hipMalloc((void**)&m->prefix_dev, (size_t)m->prefix * m->cfg.dim * sizeof(float)));
         int prc = ap::launch_prefix_build(m->cls, vec("reg_tokens"), m->cfg.reg_tokens, m->cfg.no_embed_class ? nullptr : m->pos,
@@ -838,6 +876,7 @@ size_t ap_vit_workspace_bytes(const ap_vit* m, int n) {
 
 int ap_vit_embed_dim(const ap_vit* m) {
     if (!m) return 0;
+    if (m->cfg.proj_dim > 0) return m->cfg.proj_dim;
     return m->cfg.pool == AP_POOL_ATTN ? m->cfg.pool_dim : (m->cfg.pool == AP_POOL_CLS_MEAN ? 2 * m->cfg.dim : m->cfg.dim);
 }
 

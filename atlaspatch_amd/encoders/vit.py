@@ -63,11 +63,19 @@ TRANSFORM_RESIZE = {
     # lunit.py:58-59: timm create_transform of the hub data config (expected: Resize(256, bicubic) + CenterCrop(224), the
     # checkpoints' own mean / std; unverifiable offline)
     "lunit_vit_small_patch16_dino": (256, "bicubic"), "lunit_vit_small_patch8_dino": (256, "bicubic"),
+    # open_clip image transform (clip.py:38-40) / transformers CLIPProcessor (plip.py:35, quilt.py): Resize(S, bicubic) +
+    # CenterCrop(S), OpenAI CLIP mean / std
+    "clip_vit_b_32": (224, "bicubic"), "clip_vit_b_16": (224, "bicubic"), "clip_vit_l_14": (224, "bicubic"),
+    "clip_vit_l_14_336": (336, "bicubic"), "plip": (224, "bicubic"), "quilt_b_32": (224, "bicubic"), "quilt_b_16": (224, "bicubic"),
 }
 
 # Normalize() constants per registered name (default: ImageNet)
 TRANSFORM_NORM = {
     "conch_v1": (OPENAI_CLIP_MEAN, OPENAI_CLIP_STD),
+    "clip_vit_b_32": (OPENAI_CLIP_MEAN, OPENAI_CLIP_STD), "clip_vit_b_16": (OPENAI_CLIP_MEAN, OPENAI_CLIP_STD),
+    "clip_vit_l_14": (OPENAI_CLIP_MEAN, OPENAI_CLIP_STD), "clip_vit_l_14_336": (OPENAI_CLIP_MEAN, OPENAI_CLIP_STD),
+    "plip": (OPENAI_CLIP_MEAN, OPENAI_CLIP_STD), "quilt_b_32": (OPENAI_CLIP_MEAN, OPENAI_CLIP_STD),
+    "quilt_b_16": (OPENAI_CLIP_MEAN, OPENAI_CLIP_STD),
     "midnight": ((0.5, 0.5, 0.5), (0.5, 0.5, 0.5)),                                                   # midnight.py:22
     "h_optimus_0": ((0.707223, 0.578729, 0.703617), (0.211883, 0.230117, 0.177517)),                  # hoptimus.py:24-27
     "h_optimus_1": ((0.707223, 0.578729, 0.703617), (0.211883, 0.230117, 0.177517)),
@@ -143,6 +151,24 @@ ARCHS = {
                                         layer_scale=False),
     "pathorchestra": dict(image_size=224, patch_size=16, dim=1024, depth=24, heads=16, mlp_dim=4096, ln_eps=1e-6,
                           layer_scale=True),
+    # CLIP vision towers: models/patch/clip.py:16-19 (open_clip ViT-B-32 / ViT-B-16 / ViT-L-14 / ViT-L-14-336, "openai"),
+    # plip.py (transformers CLIPModel vinid/plip = ViT-B/32), quilt.py (CLIPModel wisdomik/QuiltNet-B-32 / B-16).  No
+    # patch-embedding bias, LayerNorm on the embedded tokens before the blocks (ln_pre), QuickGELU, LayerNorm 1e-5, final
+    # LayerNorm of the class token times the bias-free visual projection = encode_image / get_image_features
+    "clip_vit_b_32": dict(image_size=224, patch_size=32, dim=768, depth=12, heads=12, mlp_dim=3072, ln_eps=1e-5, layer_scale=False,
+                          pre_norm=True, act="quick_gelu", proj_dim=512),
+    "clip_vit_b_16": dict(image_size=224, patch_size=16, dim=768, depth=12, heads=12, mlp_dim=3072, ln_eps=1e-5, layer_scale=False,
+                          pre_norm=True, act="quick_gelu", proj_dim=512),
+    "clip_vit_l_14": dict(image_size=224, patch_size=14, dim=1024, depth=24, heads=16, mlp_dim=4096, ln_eps=1e-5, layer_scale=False,
+                          pre_norm=True, act="quick_gelu", proj_dim=768),
+    "clip_vit_l_14_336": dict(image_size=336, patch_size=14, dim=1024, depth=24, heads=16, mlp_dim=4096, ln_eps=1e-5,
+                              layer_scale=False, pre_norm=True, act="quick_gelu", proj_dim=768),
+    "plip": dict(image_size=224, patch_size=32, dim=768, depth=12, heads=12, mlp_dim=3072, ln_eps=1e-5, layer_scale=False,
+                 pre_norm=True, act="quick_gelu", proj_dim=512),
+    "quilt_b_32": dict(image_size=224, patch_size=32, dim=768, depth=12, heads=12, mlp_dim=3072, ln_eps=1e-5, layer_scale=False,
+                       pre_norm=True, act="quick_gelu", proj_dim=512),
+    "quilt_b_16": dict(image_size=224, patch_size=16, dim=768, depth=12, heads=12, mlp_dim=3072, ln_eps=1e-5, layer_scale=False,
+                       pre_norm=True, act="quick_gelu", proj_dim=512),
 }
 
 
@@ -153,6 +179,10 @@ def _detect_source(sd: dict) -> str:
         return "torchvision"
     if "patch_embed.proj.weight" in keys:
         return "timm"
+    if "vision_model.pre_layrnorm.weight" in keys or "pre_layrnorm.weight" in keys:
+        return "hf_clip"
+    if "visual.ln_pre.weight" in keys or "ln_pre.weight" in keys:
+        return "open_clip"
     if "embeddings.register_tokens" in keys or any(".layer_scale1.lambda1" in k for k in keys):
         return "hf_dinov2"
     if any(k.startswith("embeddings.patch_embeddings") for k in keys):
@@ -245,6 +275,48 @@ def canonical_state_dict(sd: dict, *, depth: int, layer_scale: bool, source: str
             put(b + "ln2.weight", sd[p + "layernorm_after.weight"]); put(b + "ln2.bias", sd[p + "layernorm_after.bias"])
             put(b + "fc1.weight", sd[f1 + ".weight"]); put(b + "fc1.bias", sd[f1 + ".bias"])
             put(b + "fc2.weight", sd[f2 + ".weight"]); put(b + "fc2.bias", sd[f2 + ".bias"])
+    elif source == "hf_clip":
+        # transformers CLIPModel / CLIPVisionModelWithProjection (plip.py:34, quilt.py: CLIPModel.from_pretrained): the vision
+        # tower + visual_projection.  No patch-embedding bias; class_embedding + position_embedding rows; pre_layrnorm (sic)
+        v = "vision_model." if "vision_model.pre_layrnorm.weight" in sd else ""
+        d = sd[v + "embeddings.class_embedding"].shape[0]
+        put("patch_embed.weight", sd[v + "embeddings.patch_embedding.weight"]); put("patch_embed.bias", torch.zeros(d))
+        put("cls_token", sd[v + "embeddings.class_embedding"].reshape(-1))
+        put("pos_embed", sd[v + "embeddings.position_embedding.weight"])
+        put("pre_norm.weight", sd[v + "pre_layrnorm.weight"]); put("pre_norm.bias", sd[v + "pre_layrnorm.bias"])
+        put("norm.weight", sd[v + "post_layernorm.weight"]); put("norm.bias", sd[v + "post_layernorm.bias"])
+        if "visual_projection.weight" in sd:
+            put("head_proj.weight", sd["visual_projection.weight"])
+        for i in range(depth):
+            p, b = f"{v}encoder.layers.{i}.", f"blocks.{i}."
+            a = p + "self_attn."
+            put(b + "ln1.weight", sd[p + "layer_norm1.weight"]); put(b + "ln1.bias", sd[p + "layer_norm1.bias"])
+            put(b + "qkv.weight", torch.cat([sd[a + "q_proj.weight"], sd[a + "k_proj.weight"], sd[a + "v_proj.weight"]], 0))
+            put(b + "qkv.bias", torch.cat([sd[a + "q_proj.bias"], sd[a + "k_proj.bias"], sd[a + "v_proj.bias"]], 0))
+            put(b + "proj.weight", sd[a + "out_proj.weight"]); put(b + "proj.bias", sd[a + "out_proj.bias"])
+            put(b + "ln2.weight", sd[p + "layer_norm2.weight"]); put(b + "ln2.bias", sd[p + "layer_norm2.bias"])
+            put(b + "fc1.weight", sd[p + "mlp.fc1.weight"]); put(b + "fc1.bias", sd[p + "mlp.fc1.bias"])
+            put(b + "fc2.weight", sd[p + "mlp.fc2.weight"]); put(b + "fc2.bias", sd[p + "mlp.fc2.bias"])
+    elif source == "open_clip":
+        # open_clip VisionTransformer (clip.py:38-40, the OpenAI checkpoints; key names of the public package [3P], unverified
+        # offline): visual.conv1 (no bias), class_embedding, positional_embedding, ln_pre, transformer.resblocks.<i>.{ln_1,
+        # attn.in_proj_weight | in_proj_bias | out_proj, ln_2, mlp.c_fc, mlp.c_proj}, ln_post, proj [width, output_dim]
+        v = "visual." if "visual.ln_pre.weight" in sd else ""
+        d = sd[v + "class_embedding"].shape[0]
+        put("patch_embed.weight", sd[v + "conv1.weight"]); put("patch_embed.bias", torch.zeros(d))
+        put("cls_token", sd[v + "class_embedding"].reshape(-1)); put("pos_embed", sd[v + "positional_embedding"])
+        put("pre_norm.weight", sd[v + "ln_pre.weight"]); put("pre_norm.bias", sd[v + "ln_pre.bias"])
+        put("norm.weight", sd[v + "ln_post.weight"]); put("norm.bias", sd[v + "ln_post.bias"])
+        if v + "proj" in sd:
+            put("head_proj.weight", sd[v + "proj"].t())
+        for i in range(depth):
+            p, b = f"{v}transformer.resblocks.{i}.", f"blocks.{i}."
+            put(b + "ln1.weight", sd[p + "ln_1.weight"]); put(b + "ln1.bias", sd[p + "ln_1.bias"])
+            put(b + "qkv.weight", sd[p + "attn.in_proj_weight"]); put(b + "qkv.bias", sd[p + "attn.in_proj_bias"])
+            put(b + "proj.weight", sd[p + "attn.out_proj.weight"]); put(b + "proj.bias", sd[p + "attn.out_proj.bias"])
+            put(b + "ln2.weight", sd[p + "ln_2.weight"]); put(b + "ln2.bias", sd[p + "ln_2.bias"])
+            put(b + "fc1.weight", sd[p + "mlp.c_fc.weight"]); put(b + "fc1.bias", sd[p + "mlp.c_fc.bias"])
+            put(b + "fc2.weight", sd[p + "mlp.c_proj.weight"]); put(b + "fc2.bias", sd[p + "mlp.c_proj.bias"])
     elif source == "hf_dinov2":
         # transformers Dinov2Model / Dinov2WithRegistersModel: the position embedding has a class row and patch rows but none
         # for the register tokens, which are inserted AFTER it is added -> canonical no_embed_class form with the class row
@@ -382,6 +454,10 @@ def random_canonical_state_dict(arch: dict, seed: int = 0) -> dict:
             sd[b + "ls2"] = torch.full((d,), 1e-5) + w(d, s=1e-6)
     if arch.get("pool") == "attn":
         sd.update(attn_pool_canonical(random_attn_pool(arch, seed), pool_eps=arch.get("pool_ln_eps", 1e-5)))
+    if arch.get("pre_norm"):
+        sd["pre_norm.weight"] = 1.0 + w(d, s=0.1); sd["pre_norm.bias"] = w(d)
+    if arch.get("proj_dim"):
+        sd["head_proj.weight"] = w(arch["proj_dim"], d, s=d ** -0.5)
     return sd
 
 
@@ -400,6 +476,8 @@ class HipViT:
         attn_pool = arch.get("pool") == "attn"
         cls_mean = arch.get("pool") == "cls_mean"          # [class token | mean of the patch tokens] (midnight.py:58-61)
         self.embed_dim = int(arch["pool_dim"] if attn_pool else (2 * arch["dim"] if cls_mean else arch["dim"]))
+        if arch.get("proj_dim"):                           # CLIP visual projection
+            self.embed_dim = int(arch["proj_dim"])
         hd_true = arch["dim"] // arch["heads"]
         hd_stored = stored_head_dim(arch["dim"], arch["heads"])
         cfg = _lib.VitConfig(arch["image_size"], arch["patch_size"], arch["dim"], arch["depth"],
@@ -409,7 +487,9 @@ class HipViT:
                              float(arch.get("pool_ln_eps", 1e-5)),
                              int(arch.get("reg_tokens", 0)), 1 if arch.get("no_embed_class") else 0,
                              1 if arch.get("mlp") == "swiglu" else 0, hd_stored,
-                             0.0 if hd_stored == hd_true else float(1.0 / np.sqrt(np.float32(hd_true))))
+                             0.0 if hd_stored == hd_true else float(1.0 / np.sqrt(np.float32(hd_true))),
+                             1 if arch.get("pre_norm") else 0, 1 if arch.get("act") == "quick_gelu" else 0,
+                             int(arch.get("proj_dim", 0)))
         state = pad_heads(state, dim=arch["dim"], heads=arch["heads"], depth=arch["depth"])
         handle = C.c_void_p()
         # hipMalloc / hipMemcpy on the legacy stream must not fall into another thread's stream capture (the SAM2 hipGraph):
@@ -640,6 +720,19 @@ def register_more_vits(registry, *, device, dtype=torch.float32, num_workers: in
     for name, cap in (("midnight", 512), ("h_optimus_0", 512), ("h_optimus_1", 512), ("prov_gigapath", 512),
                       ("lunit_vit_small_patch16_dino", 4096), ("lunit_vit_small_patch8_dino", 512), ("pathorchestra", 2048)):
         mean, std = TRANSFORM_NORM.get(name, (IMAGENET_MEAN, IMAGENET_STD))
+        registry.register(name, lambda n=name, c=cap, mu=mean, sd=std: build_hip_vit_extractor(
+            name=n, arch=n, device=device, dtype=dtype, random_init_seed=_env_seed(), resize=TRANSFORM_RESIZE[n],
+            expect_size=None, max_batch=c, mean=mu, std=sd))
+
+
+def register_clip(registry, *, device, dtype=torch.float32, num_workers: int = 0) -> None:
+    """The CLIP vision towers with a plain ViT: clip_vit_b_32 / b_16 / l_14 / l_14_336 (models/patch/clip.py, open_clip, OpenAI
+    weights), plip (plip.py) and quilt_b_32 / quilt_b_16 (quilt.py), both transformers CLIPModel; features = encode_image /
+    get_image_features (projected, not normalised).  Checkpoints: open_clip or HF CLIP state dicts in ATLASPATCH_WEIGHTS_DIR.
+    (The ResNet CLIPs, quilt_b_16_pmb and omiclip are other architectures.)"""
+    for name, cap in (("clip_vit_b_32", 4096), ("clip_vit_b_16", 2048), ("clip_vit_l_14", 1024), ("clip_vit_l_14_336", 256),
+                      ("plip", 4096), ("quilt_b_32", 4096), ("quilt_b_16", 2048)):
+        mean, std = TRANSFORM_NORM[name]
         registry.register(name, lambda n=name, c=cap, mu=mean, sd=std: build_hip_vit_extractor(
             name=n, arch=n, device=device, dtype=dtype, random_init_seed=_env_seed(), resize=TRANSFORM_RESIZE[n],
             expect_size=None, max_batch=c, mean=mu, std=sd))

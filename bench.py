@@ -59,6 +59,12 @@ ENCODERS = {
     "lunit_vit_small_patch16_dino": {"label": "Lunit ViT-S/16 DINO", "batch": 4096},
     "lunit_vit_small_patch8_dino": {"label": "Lunit ViT-S/8 DINO (785 tokens)", "batch": 512},
     "pathorchestra": {"label": "PathOrchestra (ViT-L/16 + LayerScale)", "batch": 2048},
+    # CLIP vision towers (clip.py, plip.py, quilt.py): ln_pre, QuickGELU, projection
+    "clip_vit_b_32": {"label": "CLIP ViT-B/32 image tower (encode_image, 512-d)", "batch": 4096, "mean": OPENAI_CLIP_MEAN, "std": OPENAI_CLIP_STD},
+    "clip_vit_b_16": {"label": "CLIP ViT-B/16 image tower (encode_image, 512-d)", "batch": 2048, "mean": OPENAI_CLIP_MEAN, "std": OPENAI_CLIP_STD},
+    "clip_vit_l_14": {"label": "CLIP ViT-L/14 image tower (encode_image, 768-d)", "batch": 1024, "mean": OPENAI_CLIP_MEAN, "std": OPENAI_CLIP_STD},
+    "clip_vit_l_14_336": {"label": "CLIP ViT-L/14 at 336 px (577 tokens)", "batch": 256, "mean": OPENAI_CLIP_MEAN, "std": OPENAI_CLIP_STD},
+    "plip": {"label": "PLIP (HF CLIP ViT-B/32, get_image_features)", "batch": 4096, "mean": OPENAI_CLIP_MEAN, "std": OPENAI_CLIP_STD},
 }
 
 

@@ -203,7 +203,17 @@ typedef struct ap_vit_config {
                             3 * heads * head_dim rows, proj.weight heads * head_dim columns (64 or 128).  A model whose true
                             head width is not 64 / 128 (vit_h_14: 80) is uploaded zero-padded to 128 with attn_scale set */
     float attn_scale;    /* 0 = 1 / sqrt(head_dim); else the softmax scale (vit_h_14: 1 / sqrt(80)) */
+    /* ---- ABI v18: CLIP vision towers (models/patch/clip.py, plip.py, quilt.py: open_clip VisionTransformer / transformers
+     *      CLIPVisionModel).  All zero = the v17 behaviour. */
+    int pre_norm;        /* 1: LayerNorm on the embedded tokens (class + position added) before the first block (CLIP ln_pre /
+                            pre_layrnorm); parameters pre_norm.weight | bias [dim] */
+    int act;             /* AP_ACT_GELU (erf) or AP_ACT_QUICK_GELU (x * sigmoid(1.702 x), the OpenAI CLIP weights); AP_MLP_GELU only */
+    int proj_dim;        /* 0, or P: the pooled vector (AP_POOL_CLS: final LN of the class token) is multiplied by
+                            head_proj.weight [P, dim] without bias (CLIP visual projection: encode_image / get_image_features);
+                            multiple of 128; ap_vit_embed_dim = P */
 } ap_vit_config;
+#define AP_ACT_GELU 0
+#define AP_ACT_QUICK_GELU 1
 #define AP_MLP_GELU 0
 #define AP_MLP_SWIGLU 1
 #define AP_POOL_CLS 0
@@ -290,6 +300,7 @@ int ap_vit_forward_chw(ap_vit* m, const void* x, int x_dtype, int n,
  *   AP_EPI_BIAS        out T   [M, ldo] = C                       (nn.Linear)
  *   AP_EPI_BIAS_GELU   out T   [M, ldo] = gelu_erf(C)             (Linear + nn.GELU())
  *   AP_EPI_BIAS_RESID  out f32 [M, ldo] += C * (gamma ? gamma[n] : 1)   (residual add, LayerScale)
+ *   AP_EPI_BIAS_QUICK_GELU  out T [M, ldo] = C * sigmoid(1.702 C)   (CLIP's QuickGELU: models/patch/clip.py, plip.py)
  * A: T [M, lda], W: T [N, ldw] (both K-contiguous, the checkpoint's [out, in] layout), bias /
  * gamma: f32 [N].  N % 128 == 0 and K % (128 / sizeof(T)) == 0.  impl: 0 = pick, 128 = the
  * 128x128-tile kernel, 256 = the persistent 256x256-tile kernel (f16 / bf16, N % 256 == 0,
@@ -297,6 +308,7 @@ int ap_vit_forward_chw(ap_vit* m, const void* x, int x_dtype, int n,
 #define AP_EPI_BIAS 0
 #define AP_EPI_BIAS_GELU 1
 #define AP_EPI_BIAS_RESID 2
+#define AP_EPI_BIAS_QUICK_GELU 10
 int ap_gemm(int dtype, int epilogue, const void* A, int lda, const void* W, int ldw,
             int M, int N, int K, const float* bias, const float* gamma, void* out, int ldo,
             int impl, int variant, ap_stream_t stream);
@@ -310,6 +322,7 @@ int ap_gemm(int dtype, int epilogue, const void* A, int lda, const void* W, int 
  * bias' = b + W beta and rowstats[m] = (rstd, -mean * rstd) of row m of x.
  *   AP_EPI_NORM         out T [M, ldo] = rstd * acc + (-mean rstd) * colsum[n] + bias[n]
  *   AP_EPI_NORM_GELU    out = gelu(that)
+ *   AP_EPI_NORM_QUICK_GELU  out = that * sigmoid(1.702 * that)
  *   AP_EPI_NORM_SWIGLU  timm SwiGLUPacked (models/patch/uni.py:91-93, uni_v2) with the gate in the epilogue: W / colsum / bias rows
  *                       INTERLEAVED in groups of 64 -- rows 64q .. 64q+31 = fc1 rows 32q .. (x1), rows 64q+32 .. 64q+63 = fc1 rows
  *                       N/2 + 32q .. (x2) -- and out T [M, N / 2]: out[m][32q + j] = silu(norm x1) * norm x2, one rounding
@@ -323,6 +336,7 @@ int ap_gemm(int dtype, int epilogue, const void* A, int lda, const void* W, int 
 #define AP_EPI_NORM_GELU 5
 #define AP_EPI_RESID_STATS 6
 #define AP_EPI_NORM_SWIGLU 8
+#define AP_EPI_NORM_QUICK_GELU 9
 int ap_gemm_fused(int dtype, int epilogue, const void* A, int lda, const void* W, int ldw, int M, int N, int K,
                   const float* bias, const float* colsum, const float* rowstats, float* partial,
                   void* out, int ldo, int impl, ap_stream_t stream);

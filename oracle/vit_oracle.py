@@ -149,7 +149,7 @@ OPENAI_CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
 
 
 @torch.inference_mode()
-def vit_tokens_canonical(sd: dict, x: torch.Tensor, *, heads: int, depth: int, eps: float = 1e-6) -> torch.Tensor:
+def vit_tokens_canonical(sd: dict, x: torch.Tensor, *, heads: int, depth: int, eps: float = 1e-6, act: str = "gelu") -> torch.Tensor:
     """timm ``VisionTransformer.forward_features`` from canonical parameter names: [n,3,S,S] -> [n, prefix+P, D].
 
     Covers what the reference's encoder files instantiate (models/patch/vit.py:9-15, uni.py:13-125):
@@ -159,7 +159,10 @@ def vit_tokens_canonical(sd: dict, x: torch.Tensor, *, heads: int, depth: int, e
         to every token after the concatenation (torchvision, timm default);
       * ``fc1.weight`` with twice as many rows as ``fc2.weight`` has columns: timm ``SwiGLUPacked`` (GluMlp with
         gate_last=False): x1, x2 = fc1(x).chunk(2, -1); fc2(silu(x1) * x2); otherwise fc2(gelu_erf(fc1(x)));
-      * ``ls1`` / ``ls2``: LayerScale.
+      * ``ls1`` / ``ls2``: LayerScale;
+      * ``pre_norm.weight`` present: CLIP's ln_pre -- LayerNorm on the embedded tokens before the first block (open_clip
+        VisionTransformer.forward, transformers CLIPVisionTransformer.pre_layrnorm); ``act="quick_gelu"``: x * sigmoid(1.702 x)
+        (the OpenAI CLIP weights; models/patch/clip.py, plip.py, quilt.py).
     Pinned against transformers' ViTModel (patch 16 / 32 / 14, 80-wide heads) and Dinov2WithRegistersModel (register tokens,
     SwiGLU, LayerScale) by tests/test_encoder_zoo.py."""
     w, b = sd["patch_embed.weight"], sd["patch_embed.bias"]
@@ -175,6 +178,8 @@ def vit_tokens_canonical(sd: dict, x: torch.Tensor, *, heads: int, depth: int, e
     else:
         tok = torch.cat(prefix + [pe], dim=1) + pos[None]
     dh = d // heads
+    if "pre_norm.weight" in sd:
+        tok = F.layer_norm(tok, (d,), sd["pre_norm.weight"], sd["pre_norm.bias"], eps)
     for i in range(depth):
         p = f"blocks.{i}."
         h = F.layer_norm(tok, (d,), sd[p + "ln1.weight"], sd[p + "ln1.bias"], eps)
@@ -192,6 +197,8 @@ def vit_tokens_canonical(sd: dict, x: torch.Tensor, *, heads: int, depth: int, e
         if sd[p + "fc1.weight"].shape[0] == 2 * sd[p + "fc2.weight"].shape[1]:
             x1, x2 = m.chunk(2, dim=-1)
             m = F.silu(x1) * x2
+        elif act == "quick_gelu":
+            m = m * torch.sigmoid(1.702 * m)
         else:
             m = F.gelu(m)
         m = m @ sd[p + "fc2.weight"].T + sd[p + "fc2.bias"]
@@ -221,7 +228,7 @@ def transform_resize_crop(patches_u8, *, resize, crop: int, mean=IMAGENET_MEAN, 
 
 @torch.inference_mode()
 def canonical_extract(sd: dict, patches_u8, *, heads: int, depth: int, image_size: int, resize=None, eps: float = 1e-6,
-                      batch: int = 8, pool: str = "cls", mean=IMAGENET_MEAN, std=IMAGENET_STD) -> np.ndarray:
+                      batch: int = 8, pool: str = "cls", mean=IMAGENET_MEAN, std=IMAGENET_STD, act: str = "gelu") -> np.ndarray:
     """extract_batch of an encoder from canonical parameters: transform -> tokens -> LN -> token 0 (``pool="cls"``) or
     torch.cat([token 0, patch tokens.mean(1)], -1) (``pool="cls_mean"``: models/patch/midnight.py:58-61, virchow.py:58-61;
     register tokens are not patch tokens, virchow.py:111-114)."""
@@ -229,8 +236,11 @@ def canonical_extract(sd: dict, patches_u8, *, heads: int, depth: int, image_siz
     prefix = 1 + (sd["reg_tokens"].shape[0] if "reg_tokens" in sd else 0)
     for s in range(0, len(patches_u8), batch):
         x = transform_resize_crop(patches_u8[s:s + batch], resize=resize, crop=image_size, mean=mean, std=std)
-        tok = vit_tokens_canonical(sd, x, heads=heads, depth=depth, eps=eps)
-        outs.append(tok[:, 0] if pool == "cls" else torch.cat([tok[:, 0], tok[:, prefix:].mean(1)], dim=-1))
+        tok = vit_tokens_canonical(sd, x, heads=heads, depth=depth, eps=eps, act=act)
+        feat = tok[:, 0] if pool == "cls" else torch.cat([tok[:, 0], tok[:, prefix:].mean(1)], dim=-1)
+        if "head_proj.weight" in sd:                     # CLIP: pooled @ visual projection (no bias)
+            feat = feat @ sd["head_proj.weight"].T
+        outs.append(feat)
     return torch.cat(outs, 0).to(torch.float32).numpy()
 
 

@@ -126,6 +126,51 @@ def test_oracle_matches_hf_vit_with_the_phikon_layer_norm_eps():
     assert _rel(got.numpy(), want.numpy()) <= 2e-6
 
 
+def _hf_clip(hidden=128, layers=2, heads=2, image=64, patch=32, proj=128):
+    from transformers import CLIPConfig, CLIPModel
+    torch.manual_seed(0)
+    vc = dict(hidden_size=hidden, intermediate_size=4 * hidden, num_hidden_layers=layers, num_attention_heads=heads, image_size=image,
+              patch_size=patch, projection_dim=proj, hidden_act="quick_gelu", layer_norm_eps=1e-5)
+    tc = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=1, num_attention_heads=2, vocab_size=100,
+              max_position_embeddings=16, bos_token_id=1, eos_token_id=2, pad_token_id=0)
+    return _seed_params(CLIPModel(CLIPConfig(text_config=tc, vision_config=vc, projection_dim=proj)).eval())
+
+
+def _clip_image_features(model, x):
+    with torch.inference_mode():
+        f = model.get_image_features(pixel_values=x)
+    return (f if torch.is_tensor(f) else f.pooler_output).numpy()
+
+
+@pytest.mark.parametrize("patch,image", [(32, 64), (16, 64), (14, 56)])
+def test_oracle_matches_hf_clip_get_image_features(patch, image):
+    """plip.py:56 / quilt.py:59-60 call transformers' CLIPModel.get_image_features -- importable here: no patch-embedding bias,
+    pre_layrnorm, QuickGELU, LayerNorm 1e-5, post_layernorm of the class token, bias-free visual projection.  The oracle through
+    the product's hf_clip adapter reproduces it (the same towers serve clip.py's open_clip ViT-B-32 / B-16 / L-14)."""
+    from atlaspatch_amd.encoders.vit import canonical_state_dict
+    from oracle import vit_oracle
+    model = _hf_clip(patch=patch, image=image)
+    x = torch.randn(3, 3, image, image, generator=torch.Generator().manual_seed(5))
+    want = _clip_image_features(model, x)
+    sd = canonical_state_dict(dict(model.state_dict()), depth=2, layer_scale=False)            # auto-detected: hf_clip
+    assert "pre_norm.weight" in sd and sd["head_proj.weight"].shape == (128, 128) and float(sd["patch_embed.bias"].abs().max()) == 0.0
+    tok = vit_oracle.vit_tokens_canonical(sd, x, heads=2, depth=2, eps=1e-5, act="quick_gelu")
+    got = (tok[:, 0] @ sd["head_proj.weight"].T).numpy()
+    assert _rel(got, want) <= 2e-6
+    # the open_clip layout of the same tower (clip.py) maps to the same canonical tensors
+    oc = {"visual.conv1.weight": sd["patch_embed.weight"], "visual.class_embedding": sd["cls_token"],
+          "visual.positional_embedding": sd["pos_embed"], "visual.ln_pre.weight": sd["pre_norm.weight"],
+          "visual.ln_pre.bias": sd["pre_norm.bias"], "visual.ln_post.weight": sd["norm.weight"], "visual.ln_post.bias": sd["norm.bias"],
+          "visual.proj": sd["head_proj.weight"].t().contiguous()}
+    for i in range(2):
+        b, p = f"blocks.{i}.", f"visual.transformer.resblocks.{i}."
+        for src, dst in (("ln1", "ln_1"), ("ln2", "ln_2"), ("proj", "attn.out_proj"), ("fc1", "mlp.c_fc"), ("fc2", "mlp.c_proj")):
+            oc[p + dst + ".weight"] = sd[b + src + ".weight"]; oc[p + dst + ".bias"] = sd[b + src + ".bias"]
+        oc[p + "attn.in_proj_weight"] = sd[b + "qkv.weight"]; oc[p + "attn.in_proj_bias"] = sd[b + "qkv.bias"]
+    back = canonical_state_dict(oc, depth=2, layer_scale=False)                                # auto-detected: open_clip
+    assert set(back) == set(sd) and all(torch.equal(back[k], sd[k]) for k in sd)
+
+
 def test_head_padding_leaves_the_function_unchanged():
     """pad_heads: 80-wide heads stored 128 wide (zero rows in q / k / v, zero columns in proj) with the softmax scale kept at
     1 / sqrt(80) -- checked with an explicit attention on the padded tensors."""
@@ -155,7 +200,8 @@ def test_registry_has_the_reference_names_of_the_three_encoder_files():
     for n in ("vit_b_16", "vit_b_32", "vit_l_16", "vit_l_32", "vit_h_14", "uni_v1", "uni_v2", "conch_v1",
               "dinov2_small", "dinov2_base", "dinov2_large", "dinov2_giant", "phikon_v1", "phikon_v2",        # dinov2.py:12-17, phikon.py
               "midnight", "h_optimus_0", "h_optimus_1", "prov_gigapath", "lunit_vit_small_patch16_dino",
-              "lunit_vit_small_patch8_dino", "pathorchestra"):
+              "lunit_vit_small_patch8_dino", "pathorchestra",
+              "clip_vit_b_32", "clip_vit_b_16", "clip_vit_l_14", "clip_vit_l_14_336", "plip", "quilt_b_32", "quilt_b_16"):     # clip.py:16-19
         assert n in names and n in ARCHS and n in TRANSFORM_RESIZE
     g = ARCHS["dinov2_giant"]
     assert (g["dim"], g["depth"], g["heads"], g["mlp_dim"]) == (1536, 40, 24, (int(1536 * 4 * 2 / 3) + 7) // 8 * 8)
@@ -211,6 +257,18 @@ MEASURED.update({                     # the transformers-backed encoders (dinov2
     ("lunit_vit_small_patch8_dino L12, f32_stream", "float16"): (8.37e-4, 1.174e-2, 1.005e-2),
     ("pathorchestra L24", "float16"): (1.706e-3, 1.989e-2, 1.422e-2),
     ("pathorchestra L24, f32_stream", "float16"): (1.008e-3, 1.532e-2, 1.154e-2),
+    # CLIP towers (ln_pre, QuickGELU epilogue, projection in the compute type)
+    ("clip_vit_b_32 L12", "float16"): (1.149e-3, 1.942e-2, 1.568e-2),
+    ("clip_vit_b_32 L12, f32_stream", "float16"): (5.95e-4, 1.043e-2, 7.54e-3),
+    ("clip_vit_b_32 L12", "float32"): (1.300e-6, 1.883e-5, 1.475e-5),
+    ("clip_vit_b_16 L12", "float16"): (1.154e-3, 1.846e-2, 1.338e-2),
+    ("clip_vit_b_16 L12, f32_stream", "float16"): (6.05e-4, 1.331e-2, 6.91e-3),
+    ("clip_vit_l_14 L24", "float16"): (1.491e-3, 2.587e-2, 1.814e-2),
+    ("clip_vit_l_14 L24, f32_stream", "float16"): (6.93e-4, 1.356e-2, 9.09e-3),
+    ("clip_vit_l_14_336 L24", "float16"): (1.509e-3, 2.051e-2, 1.759e-2),
+    ("clip_vit_l_14_336 L24, f32_stream", "float16"): (7.64e-4, 9.78e-3, 8.78e-3),
+    ("plip L12", "float16"): (1.149e-3, 1.942e-2, 1.568e-2),
+    ("plip L12, f32_stream", "float16"): (5.95e-4, 1.043e-2, 7.54e-3),
 })
 HEADROOM = (1.2, 1.5, 1.25)
 FALLBACK = {"float32": (3.0e-6, 6e-5, 4e-5), "float16": (3.6e-3, 5.2e-2, 3.8e-2)}
@@ -256,7 +314,10 @@ def _with_layer_scale(sd, arch, seed):
                                           ("phikon_v1", torch.float32, 8), ("phikon_v2", torch.float16, 6),
                                           ("midnight", torch.float16, 4), ("h_optimus_0", torch.float16, 4),
                                           ("prov_gigapath", torch.float16, 4), ("lunit_vit_small_patch16_dino", torch.float16, 8),
-                                          ("lunit_vit_small_patch8_dino", torch.float16, 4), ("pathorchestra", torch.float16, 6)])
+                                          ("lunit_vit_small_patch8_dino", torch.float16, 4), ("pathorchestra", torch.float16, 6),
+                                          ("clip_vit_b_32", torch.float16, 8), ("clip_vit_b_32", torch.float32, 8),
+                                          ("clip_vit_b_16", torch.float16, 8), ("clip_vit_l_14", torch.float16, 6),
+                                          ("clip_vit_l_14_336", torch.float16, 4), ("plip", torch.float16, 8)])
 def test_encoder_at_real_size_vs_fp32_oracle(name, dtype, n):
     from atlaspatch_amd.encoders.vit import (ARCHS, IMAGENET_MEAN, IMAGENET_STD, TRANSFORM_NORM, TRANSFORM_RESIZE, build_hip_vit_extractor,
                                              random_canonical_state_dict)
@@ -264,7 +325,7 @@ def test_encoder_at_real_size_vs_fp32_oracle(name, dtype, n):
     torch.set_num_threads(min(32, torch.get_num_threads()))
     arch = dict(ARCHS[name])
     mean, std = TRANSFORM_NORM.get(name, (IMAGENET_MEAN, IMAGENET_STD))
-    pool = arch.get("pool", "cls")
+    pool, act = arch.get("pool", "cls"), arch.get("act", "gelu")
     sd = _with_layer_scale(random_canonical_state_dict(arch, seed=41), arch, 42)
     ex = build_hip_vit_extractor(name=name, arch=arch, state_dict=sd, source="canonical", device=torch.device("cuda:0"), dtype=dtype,
                                  resize=TRANSFORM_RESIZE[name], expect_size=None, max_batch=64, mean=mean, std=std)
@@ -282,8 +343,8 @@ def test_encoder_at_real_size_vs_fp32_oracle(name, dtype, n):
             assert np.array_equal(got_full, got)                    # (this pooling always runs the full last block)
     ex.cleanup()
     want = vit_oracle.canonical_extract(sd, tiles, heads=arch["heads"], depth=arch["depth"], image_size=arch["image_size"],
-                                        resize=TRANSFORM_RESIZE[name], batch=2, eps=arch["ln_eps"], pool=pool, mean=mean, std=std)
-    assert got.shape == want.shape == (n, arch["dim"] * (2 if pool == "cls_mean" else 1)) and got.dtype == np.float32
+                                        resize=TRANSFORM_RESIZE[name], batch=2, eps=arch["ln_eps"], pool=pool, mean=mean, std=std, act=act)
+    assert got.shape == want.shape == (n, arch.get("proj_dim") or arch["dim"] * (2 if pool == "cls_mean" else 1)) and got.dtype == np.float32
     _check(got, want, dtype, f"{name} L{arch['depth']}")
     if got_f32s is not None:
         _check(got_f32s, want, dtype, f"{name} L{arch['depth']}, f32_stream")
@@ -369,3 +430,30 @@ def test_class_token_plus_mean_patch_token_on_the_device_vs_the_hf_model(dtype, 
         want = torch.cat([lhs[:, 0, :], lhs[:, 1:, :].mean(1)], dim=-1).numpy()
     assert got.shape == want.shape == (5, 768)
     assert _rel(got, want) <= tol, _rel(got, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float16, 4e-3)])
+def test_clip_tower_on_the_device_vs_hf_get_image_features(dtype, tol):
+    """plip.py:56 on the device: an HF CLIPModel state dict (ViT-B/32 shape at dim 384, 4 blocks) through the hf_clip adapter,
+    ln_pre + QuickGELU epilogue + projection, against CLIPModel.get_image_features itself."""
+    from atlaspatch_amd.encoders.vit import OPENAI_CLIP_MEAN, OPENAI_CLIP_STD, build_hip_vit_extractor
+    from oracle import vit_oracle
+    model = _hf_clip(hidden=384, layers=4, heads=6, image=224, patch=32, proj=256)
+    arch = dict(image_size=224, patch_size=32, dim=384, depth=4, heads=6, mlp_dim=1536, ln_eps=1e-5, layer_scale=False,
+                pre_norm=True, act="quick_gelu", proj_dim=256)
+    ex = build_hip_vit_extractor(name="plip", arch=arch, state_dict=dict(model.state_dict()), device=torch.device("cuda:0"), dtype=dtype,
+                                 resize=(224, "bicubic"), expect_size=None, max_batch=64, mean=OPENAI_CLIP_MEAN, std=OPENAI_CLIP_STD)
+    assert ex.embedding_dim == 256
+    tiles = _tiles(6, 61)
+    got = ex.extract_batch(tiles, batch_size=32)
+    if dtype != torch.float32:
+        ex.vit.set_option("f32_stream", True)
+        got2 = ex.extract_batch(tiles, batch_size=32)
+    ex.cleanup()
+    x = vit_oracle.transform_resize_crop(tiles, resize=(224, "bicubic"), crop=224, mean=OPENAI_CLIP_MEAN, std=OPENAI_CLIP_STD)
+    want = _clip_image_features(model, x)
+    assert got.shape == want.shape == (6, 256)
+    assert _rel(got, want) <= tol, _rel(got, want)
+    if dtype != torch.float32:
+        assert _rel(got2, want) <= tol, _rel(got2, want)

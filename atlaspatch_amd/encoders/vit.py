@@ -59,6 +59,9 @@ TRANSFORM_RESIZE = {
     #   midnight.py:14-24 Resize(224) + CenterCrop(224), Normalize(0.5, 0.5); hoptimus.py:15-30 Resize((224, 224)) + its own
     #   mean / std; gigapath.py:15-26 Resize(256, BICUBIC) + CenterCrop(224); pathorchestra.py:52-58 Resize(224)
     "midnight": (224, "bilinear"), "h_optimus_0": (224, "bilinear"), "h_optimus_1": (224, "bilinear"),
+    # virchow.py:14-19: timm create_transform of the hub config (expected: Resize(224, bicubic) + CenterCrop(224), ImageNet
+    # mean / std; unverifiable offline)
+    "virchow_v1": (224, "bicubic"), "virchow_v2": (224, "bicubic"),
     "prov_gigapath": (256, "bicubic"), "pathorchestra": (224, "bilinear"),
     # lunit.py:58-59: timm create_transform of the hub data config (expected: Resize(256, bicubic) + CenterCrop(224), the
     # checkpoints' own mean / std; unverifiable offline)
@@ -67,6 +70,7 @@ TRANSFORM_RESIZE = {
     # CenterCrop(S), OpenAI CLIP mean / std
     "clip_vit_b_32": (224, "bicubic"), "clip_vit_b_16": (224, "bicubic"), "clip_vit_l_14": (224, "bicubic"),
     "clip_vit_l_14_336": (336, "bicubic"), "plip": (224, "bicubic"), "quilt_b_32": (224, "bicubic"), "quilt_b_16": (224, "bicubic"),
+    "biomedclip": (224, "bicubic"),
 }
 
 # Normalize() constants per registered name (default: ImageNet)
@@ -75,7 +79,7 @@ TRANSFORM_NORM = {
     "clip_vit_b_32": (OPENAI_CLIP_MEAN, OPENAI_CLIP_STD), "clip_vit_b_16": (OPENAI_CLIP_MEAN, OPENAI_CLIP_STD),
     "clip_vit_l_14": (OPENAI_CLIP_MEAN, OPENAI_CLIP_STD), "clip_vit_l_14_336": (OPENAI_CLIP_MEAN, OPENAI_CLIP_STD),
     "plip": (OPENAI_CLIP_MEAN, OPENAI_CLIP_STD), "quilt_b_32": (OPENAI_CLIP_MEAN, OPENAI_CLIP_STD),
-    "quilt_b_16": (OPENAI_CLIP_MEAN, OPENAI_CLIP_STD),
+    "quilt_b_16": (OPENAI_CLIP_MEAN, OPENAI_CLIP_STD), "biomedclip": (OPENAI_CLIP_MEAN, OPENAI_CLIP_STD),
     "midnight": ((0.5, 0.5, 0.5), (0.5, 0.5, 0.5)),                                                   # midnight.py:22
     "h_optimus_0": ((0.707223, 0.578729, 0.703617), (0.211883, 0.230117, 0.177517)),                  # hoptimus.py:24-27
     "h_optimus_1": ((0.707223, 0.578729, 0.703617), (0.211883, 0.230117, 0.177517)),
@@ -145,6 +149,13 @@ ARCHS = {
                         layer_scale=True, reg_tokens=4, no_embed_class=True, mlp="swiglu"),
     "prov_gigapath": dict(image_size=224, patch_size=16, dim=1536, depth=40, heads=24, mlp_dim=4096, ln_eps=1e-6,
                           layer_scale=True, mlp="swiglu"),
+    # virchow.py:41-46,94-99 (mlp_layer=SwiGLUPacked, act_layer=SiLU; hub config: ViT-H/14, 1280 / 32 / 16 -> 80-wide heads,
+    # mlp_ratio 5.3375 -> packed 6832 = 2 x 3416, init_values 1e-5; Virchow2: 4 register tokens).  Features: class token |
+    # mean of the patch tokens (virchow.py:58-61; Virchow2 skips its registers, :111-114) = 2560-d
+    "virchow_v1": dict(image_size=224, patch_size=14, dim=1280, depth=32, heads=16, mlp_dim=3416, ln_eps=1e-6, layer_scale=True,
+                       mlp="swiglu", pool="cls_mean"),
+    "virchow_v2": dict(image_size=224, patch_size=14, dim=1280, depth=32, heads=16, mlp_dim=3416, ln_eps=1e-6, layer_scale=True,
+                       mlp="swiglu", pool="cls_mean", reg_tokens=4),
     "lunit_vit_small_patch16_dino": dict(image_size=224, patch_size=16, dim=384, depth=12, heads=6, mlp_dim=1536, ln_eps=1e-6,
                                          layer_scale=False),
     "lunit_vit_small_patch8_dino": dict(image_size=224, patch_size=8, dim=384, depth=12, heads=6, mlp_dim=1536, ln_eps=1e-6,
@@ -169,6 +180,10 @@ ARCHS = {
                        pre_norm=True, act="quick_gelu", proj_dim=512),
     "quilt_b_16": dict(image_size=224, patch_size=16, dim=768, depth=12, heads=12, mlp_dim=3072, ln_eps=1e-5, layer_scale=False,
                        pre_norm=True, act="quick_gelu", proj_dim=512),
+    # biomedclip.py: open_clip TimmModel = timm vit_base_patch16_224 (erf GELU, LayerNorm 1e-6, class token) + linear projection
+    # 768 -> 512 without bias; encode_image (not normalised)
+    "biomedclip": dict(image_size=224, patch_size=16, dim=768, depth=12, heads=12, mlp_dim=3072, ln_eps=1e-6, layer_scale=False,
+                       proj_dim=512),
 }
 
 
@@ -177,6 +192,8 @@ def _detect_source(sd: dict) -> str:
     keys = sd.keys()
     if "conv_proj.weight" in keys:
         return "torchvision"
+    if "visual.trunk.patch_embed.proj.weight" in keys and "visual.head.proj.weight" in keys:
+        return "open_clip_timm"
     if "patch_embed.proj.weight" in keys:
         return "timm"
     if "vision_model.pre_layrnorm.weight" in keys or "pre_layrnorm.weight" in keys:
@@ -236,6 +253,12 @@ def canonical_state_dict(sd: dict, *, depth: int, layer_scale: bool, source: str
             f2 = "mlp.3" if p + "mlp.3.weight" in sd else "mlp.linear_2"
             put(b + "fc1.weight", sd[p + f1 + ".weight"]); put(b + "fc1.bias", sd[p + f1 + ".bias"])
             put(b + "fc2.weight", sd[p + f2 + ".weight"]); put(b + "fc2.bias", sd[p + f2 + ".bias"])
+    elif source == "open_clip_timm":
+        # open_clip TimmModel (biomedclip.py:40: hf-hub:microsoft/BiomedCLIP-...-vit_base_patch16_224): visual.trunk = a timm ViT
+        # (class-token pooling), visual.head.proj = the bias-free linear projection [embed_dim, width] [3P, unverified offline]
+        trunk = {k[len("visual.trunk."):]: v for k, v in sd.items() if k.startswith("visual.trunk.")}
+        out.update(canonical_state_dict(trunk, depth=depth, layer_scale=layer_scale, source="timm", grid=grid))
+        put("head_proj.weight", sd["visual.head.proj.weight"])
     elif source == "timm":
         put("patch_embed.weight", sd["patch_embed.proj.weight"]); put("patch_embed.bias", sd["patch_embed.proj.bias"])
         put("cls_token", sd["cls_token"].reshape(-1)); put("pos_embed", sd["pos_embed"][0])
@@ -380,6 +403,33 @@ def pad_heads(state: dict, *, dim: int, heads: int, depth: int) -> dict:
     return out
 
 
+def stored_mlp_dim(mlp_dim: int) -> int:
+    """Hidden width of the MLP as the device stores it: the next multiple of 128 (the GEMM kernels' N / K granularity)."""
+    return (int(mlp_dim) + 127) // 128 * 128
+
+
+def pad_mlp(state: dict, *, mlp_dim: int, depth: int, swiglu: bool) -> dict:
+    """Canonical state dict -> the same model with the MLP's hidden width zero-padded to ``stored_mlp_dim`` (Virchow: timm
+    ``mlp_ratio=5.3375`` on dim 1280 gives a packed width of 6832 = 2 x 3416, and 3416 is no multiple of 64).  Padded fc1 rows have
+    zero weights and biases, so their activations are gelu(0) = 0 (or silu(0) * 0 = 0) and meet zero fc2 columns: the function
+    is unchanged.  SwiGLU: the two halves x1 | x2 are padded separately."""
+    hp = stored_mlp_dim(mlp_dim)
+    if hp == mlp_dim:
+        return state
+    out = dict(state)
+    for i in range(depth):
+        b = f"blocks.{i}."
+        w1, b1, w2 = state[b + "fc1.weight"], state[b + "fc1.bias"], state[b + "fc2.weight"]
+        halves = 2 if swiglu else 1
+        w1p = torch.zeros((halves, hp, w1.shape[1]), dtype=w1.dtype); w1p[:, :mlp_dim] = w1.reshape(halves, mlp_dim, -1)
+        b1p = torch.zeros((halves, hp), dtype=b1.dtype); b1p[:, :mlp_dim] = b1.reshape(halves, mlp_dim)
+        w2p = torch.zeros((w2.shape[0], hp), dtype=w2.dtype); w2p[:, :mlp_dim] = w2
+        out[b + "fc1.weight"] = w1p.reshape(halves * hp, -1).contiguous()
+        out[b + "fc1.bias"] = b1p.reshape(-1).contiguous()
+        out[b + "fc2.weight"] = w2p.contiguous()
+    return out
+
+
 def attn_pool_canonical(pool: dict, *, pool_eps: float = 1e-5) -> dict:
     """open_clip ``AttentionalPooler`` (+ the LayerNorm after it) -> ``attn_pool.*`` parameters.
 
@@ -481,7 +531,7 @@ class HipViT:
         hd_true = arch["dim"] // arch["heads"]
         hd_stored = stored_head_dim(arch["dim"], arch["heads"])
         cfg = _lib.VitConfig(arch["image_size"], arch["patch_size"], arch["dim"], arch["depth"],
-                             arch["heads"], arch["mlp_dim"], float(arch["ln_eps"]),
+                             arch["heads"], stored_mlp_dim(arch["mlp_dim"]), float(arch["ln_eps"]),
                              1 if arch.get("layer_scale") else 0, _lib.torch_dtype_code(dtype),
                              1 if attn_pool else (2 if cls_mean else 0), int(arch.get("pool_dim", 0)), int(arch.get("pool_heads", 0)),
                              float(arch.get("pool_ln_eps", 1e-5)),
@@ -491,6 +541,7 @@ class HipViT:
                              1 if arch.get("pre_norm") else 0, 1 if arch.get("act") == "quick_gelu" else 0,
                              int(arch.get("proj_dim", 0)))
         state = pad_heads(state, dim=arch["dim"], heads=arch["heads"], depth=arch["depth"])
+        state = pad_mlp(state, mlp_dim=arch["mlp_dim"], depth=arch["depth"], swiglu=arch.get("mlp") == "swiglu")
         handle = C.c_void_p()
         # hipMalloc / hipMemcpy on the legacy stream must not fall into another thread's stream capture (the SAM2 hipGraph):
         # both sides hold _lib.HIP_CAPTURE_LOCK for their device section
@@ -715,9 +766,11 @@ def register_phikon(registry, *, device, dtype=torch.float32, num_workers: int =
 def register_more_vits(registry, *, device, dtype=torch.float32, num_workers: int = 0) -> None:
     """The other loader files whose model is a plain ViT this engine runs: midnight (models/patch/midnight.py, transformers
     Dinov2Model giant, class token + mean patch token), h_optimus_0 / h_optimus_1 (hoptimus.py), prov_gigapath (gigapath.py),
+    virchow_v1 / virchow_v2 (virchow.py: 80-wide heads and a 3416-wide SwiGLU stored zero-padded, class | mean patch token),
     the two Lunit ViT-S (lunit.py) and pathorchestra (pathorchestra.py).  Checkpoints: HF (midnight) or timm key names in
     ATLASPATCH_WEIGHTS_DIR; each with the transform its loader file writes out (``TRANSFORM_RESIZE`` / ``TRANSFORM_NORM``)."""
     for name, cap in (("midnight", 512), ("h_optimus_0", 512), ("h_optimus_1", 512), ("prov_gigapath", 512),
+                      ("virchow_v1", 512), ("virchow_v2", 512),
                       ("lunit_vit_small_patch16_dino", 4096), ("lunit_vit_small_patch8_dino", 512), ("pathorchestra", 2048)):
         mean, std = TRANSFORM_NORM.get(name, (IMAGENET_MEAN, IMAGENET_STD))
         registry.register(name, lambda n=name, c=cap, mu=mean, sd=std: build_hip_vit_extractor(
@@ -728,10 +781,10 @@ def register_more_vits(registry, *, device, dtype=torch.float32, num_workers: in
 def register_clip(registry, *, device, dtype=torch.float32, num_workers: int = 0) -> None:
     """The CLIP vision towers with a plain ViT: clip_vit_b_32 / b_16 / l_14 / l_14_336 (models/patch/clip.py, open_clip, OpenAI
     weights), plip (plip.py) and quilt_b_32 / quilt_b_16 (quilt.py), both transformers CLIPModel; features = encode_image /
-    get_image_features (projected, not normalised).  Checkpoints: open_clip or HF CLIP state dicts in ATLASPATCH_WEIGHTS_DIR.
+    get_image_features (projected, not normalised); biomedclip (biomedclip.py: timm ViT-B/16 trunk + linear projection).  Checkpoints: open_clip or HF CLIP state dicts in ATLASPATCH_WEIGHTS_DIR.
     (The ResNet CLIPs, quilt_b_16_pmb and omiclip are other architectures.)"""
     for name, cap in (("clip_vit_b_32", 4096), ("clip_vit_b_16", 2048), ("clip_vit_l_14", 1024), ("clip_vit_l_14_336", 256),
-                      ("plip", 4096), ("quilt_b_32", 4096), ("quilt_b_16", 2048)):
+                      ("plip", 4096), ("quilt_b_32", 4096), ("quilt_b_16", 2048), ("biomedclip", 2048)):
         mean, std = TRANSFORM_NORM[name]
         registry.register(name, lambda n=name, c=cap, mu=mean, sd=std: build_hip_vit_extractor(
             name=n, arch=n, device=device, dtype=dtype, random_init_seed=_env_seed(), resize=TRANSFORM_RESIZE[n],

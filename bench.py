@@ -65,6 +65,10 @@ ENCODERS = {
     "clip_vit_l_14": {"label": "CLIP ViT-L/14 image tower (encode_image, 768-d)", "batch": 1024, "mean": OPENAI_CLIP_MEAN, "std": OPENAI_CLIP_STD},
     "clip_vit_l_14_336": {"label": "CLIP ViT-L/14 at 336 px (577 tokens)", "batch": 256, "mean": OPENAI_CLIP_MEAN, "std": OPENAI_CLIP_STD},
     "plip": {"label": "PLIP (HF CLIP ViT-B/32, get_image_features)", "batch": 4096, "mean": OPENAI_CLIP_MEAN, "std": OPENAI_CLIP_STD},
+    "biomedclip": {"label": "BiomedCLIP image tower (timm ViT-B/16 + linear projection, 512-d)", "batch": 2048,
+                   "mean": OPENAI_CLIP_MEAN, "std": OPENAI_CLIP_STD},
+    "virchow_v1": {"label": "Virchow (ViT-H/14, 80-wide heads and a 3416-wide SwiGLU stored padded, class | mean patch token)", "batch": 512},
+    "virchow_v2": {"label": "Virchow2 (as Virchow + 4 register tokens)", "batch": 512},
 }
 
 

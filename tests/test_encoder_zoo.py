@@ -126,6 +126,22 @@ def test_oracle_matches_hf_vit_with_the_phikon_layer_norm_eps():
     assert _rel(got.numpy(), want.numpy()) <= 2e-6
 
 
+def test_mlp_padding_leaves_the_function_unchanged():
+    """pad_mlp (Virchow's 3416-wide SwiGLU -> 3456): zero rows in fc1, zero columns in fc2, both halves of the packed layer."""
+    from atlaspatch_amd.encoders.vit import pad_mlp, random_canonical_state_dict, stored_mlp_dim
+    from oracle import vit_oracle
+    assert stored_mlp_dim(3416) == 3456 and stored_mlp_dim(4096) == 4096
+    for swiglu in (True, False):
+        arch = dict(image_size=28, patch_size=14, dim=128, depth=2, heads=2, mlp_dim=200, ln_eps=1e-6, mlp="swiglu" if swiglu else None)
+        sd = random_canonical_state_dict(arch, seed=7)
+        pad = pad_mlp(sd, mlp_dim=200, depth=2, swiglu=swiglu)
+        assert pad["blocks.0.fc1.weight"].shape == ((2 if swiglu else 1) * 256, 128) and pad["blocks.0.fc2.weight"].shape == (128, 256)
+        x = torch.randn(2, 3, 28, 28, generator=torch.Generator().manual_seed(8))
+        a = vit_oracle.vit_tokens_canonical(sd, x, heads=2, depth=2)
+        b = vit_oracle.vit_tokens_canonical(pad, x, heads=2, depth=2)
+        assert _rel(b.numpy(), a.numpy()) <= 1e-6
+
+
 def _hf_clip(hidden=128, layers=2, heads=2, image=64, patch=32, proj=128):
     from transformers import CLIPConfig, CLIPModel
     torch.manual_seed(0)
@@ -201,7 +217,8 @@ def test_registry_has_the_reference_names_of_the_three_encoder_files():
               "dinov2_small", "dinov2_base", "dinov2_large", "dinov2_giant", "phikon_v1", "phikon_v2",        # dinov2.py:12-17, phikon.py
               "midnight", "h_optimus_0", "h_optimus_1", "prov_gigapath", "lunit_vit_small_patch16_dino",
               "lunit_vit_small_patch8_dino", "pathorchestra",
-              "clip_vit_b_32", "clip_vit_b_16", "clip_vit_l_14", "clip_vit_l_14_336", "plip", "quilt_b_32", "quilt_b_16"):     # clip.py:16-19
+              "clip_vit_b_32", "clip_vit_b_16", "clip_vit_l_14", "clip_vit_l_14_336", "plip", "quilt_b_32", "quilt_b_16",      # clip.py:16-19
+              "biomedclip", "virchow_v1", "virchow_v2"):
         assert n in names and n in ARCHS and n in TRANSFORM_RESIZE
     g = ARCHS["dinov2_giant"]
     assert (g["dim"], g["depth"], g["heads"], g["mlp_dim"]) == (1536, 40, 24, (int(1536 * 4 * 2 / 3) + 7) // 8 * 8)
@@ -269,6 +286,12 @@ MEASURED.update({                     # the transformers-backed encoders (dinov2
     ("clip_vit_l_14_336 L24, f32_stream", "float16"): (7.64e-4, 9.78e-3, 8.78e-3),
     ("plip L12", "float16"): (1.149e-3, 1.942e-2, 1.568e-2),
     ("plip L12, f32_stream", "float16"): (5.95e-4, 1.043e-2, 7.54e-3),
+    ("biomedclip L12", "float16"): (1.178e-3, 1.602e-2, 1.263e-2),
+    ("biomedclip L12, f32_stream", "float16"): (8.87e-4, 1.722e-2, 1.077e-2),
+    ("virchow_v1 L32", "float16"): (2.333e-3, 3.145e-2, 2.537e-2),
+    ("virchow_v1 L32, f32_stream", "float16"): (1.788e-3, 2.851e-2, 2.082e-2),
+    ("virchow_v2 L32", "float16"): (2.349e-3, 3.663e-2, 2.726e-2),
+    ("virchow_v2 L32, f32_stream", "float16"): (1.812e-3, 2.682e-2, 2.235e-2),
 })
 HEADROOM = (1.2, 1.5, 1.25)
 FALLBACK = {"float32": (3.0e-6, 6e-5, 4e-5), "float16": (3.6e-3, 5.2e-2, 3.8e-2)}
@@ -317,7 +340,9 @@ def _with_layer_scale(sd, arch, seed):
                                           ("lunit_vit_small_patch8_dino", torch.float16, 4), ("pathorchestra", torch.float16, 6),
                                           ("clip_vit_b_32", torch.float16, 8), ("clip_vit_b_32", torch.float32, 8),
                                           ("clip_vit_b_16", torch.float16, 8), ("clip_vit_l_14", torch.float16, 6),
-                                          ("clip_vit_l_14_336", torch.float16, 4), ("plip", torch.float16, 8)])
+                                          ("clip_vit_l_14_336", torch.float16, 4), ("plip", torch.float16, 8),
+                                          ("biomedclip", torch.float16, 8), ("virchow_v1", torch.float16, 3),
+                                          ("virchow_v2", torch.float16, 3)])
 def test_encoder_at_real_size_vs_fp32_oracle(name, dtype, n):
     from atlaspatch_amd.encoders.vit import (ARCHS, IMAGENET_MEAN, IMAGENET_STD, TRANSFORM_NORM, TRANSFORM_RESIZE, build_hip_vit_extractor,
                                              random_canonical_state_dict)

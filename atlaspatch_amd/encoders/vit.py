@@ -61,7 +61,7 @@ TRANSFORM_RESIZE = {
     "midnight": (224, "bilinear"), "h_optimus_0": (224, "bilinear"), "h_optimus_1": (224, "bilinear"),
     # virchow.py:14-19: timm create_transform of the hub config (expected: Resize(224, bicubic) + CenterCrop(224), ImageNet
     # mean / std; unverifiable offline)
-    "virchow_v1": (224, "bicubic"), "virchow_v2": (224, "bicubic"),
+    "virchow_v1": (224, "bicubic"), "virchow_v2": (224, "bicubic"), "h0_mini": (224, "bicubic"),
     "prov_gigapath": (256, "bicubic"), "pathorchestra": (224, "bilinear"),
     # lunit.py:58-59: timm create_transform of the hub data config (expected: Resize(256, bicubic) + CenterCrop(224), the
     # checkpoints' own mean / std; unverifiable offline)
@@ -83,6 +83,7 @@ TRANSFORM_NORM = {
     "midnight": ((0.5, 0.5, 0.5), (0.5, 0.5, 0.5)),                                                   # midnight.py:22
     "h_optimus_0": ((0.707223, 0.578729, 0.703617), (0.211883, 0.230117, 0.177517)),                  # hoptimus.py:24-27
     "h_optimus_1": ((0.707223, 0.578729, 0.703617), (0.211883, 0.230117, 0.177517)),
+    "h0_mini": ((0.707223, 0.578729, 0.703617), (0.211883, 0.230117, 0.177517)),          # the hub config's (H-optimus statistics)
     "lunit_vit_small_patch16_dino": ((0.70322989, 0.53606487, 0.66096631), (0.21716536, 0.26081574, 0.20723464)),
     "lunit_vit_small_patch8_dino": ((0.70322989, 0.53606487, 0.66096631), (0.21716536, 0.26081574, 0.20723464)),
 }
@@ -152,6 +153,10 @@ ARCHS = {
     # virchow.py:41-46,94-99 (mlp_layer=SwiGLUPacked, act_layer=SiLU; hub config: ViT-H/14, 1280 / 32 / 16 -> 80-wide heads,
     # mlp_ratio 5.3375 -> packed 6832 = 2 x 3416, init_values 1e-5; Virchow2: 4 register tokens).  Features: class token |
     # mean of the patch tokens (virchow.py:58-61; Virchow2 skips its registers, :111-114) = 2560-d
+    # hoptimus.py:141-146,158-161: H0-mini = vit_base_patch14_reg4_dinov2 with SwiGLUPacked (768 / 12 / 12, packed 3072 = 2 x
+    # 1536, 4 register tokens, no_embed_class), features = class token | mean of the patch tokens (1536-d)
+    "h0_mini": dict(image_size=224, patch_size=14, dim=768, depth=12, heads=12, mlp_dim=1536, ln_eps=1e-6, layer_scale=True,
+                    reg_tokens=4, no_embed_class=True, mlp="swiglu", pool="cls_mean"),
     "virchow_v1": dict(image_size=224, patch_size=14, dim=1280, depth=32, heads=16, mlp_dim=3416, ln_eps=1e-6, layer_scale=True,
                        mlp="swiglu", pool="cls_mean"),
     "virchow_v2": dict(image_size=224, patch_size=14, dim=1280, depth=32, heads=16, mlp_dim=3416, ln_eps=1e-6, layer_scale=True,
@@ -770,7 +775,7 @@ def register_more_vits(registry, *, device, dtype=torch.float32, num_workers: in
     the two Lunit ViT-S (lunit.py) and pathorchestra (pathorchestra.py).  Checkpoints: HF (midnight) or timm key names in
     ATLASPATCH_WEIGHTS_DIR; each with the transform its loader file writes out (``TRANSFORM_RESIZE`` / ``TRANSFORM_NORM``)."""
     for name, cap in (("midnight", 512), ("h_optimus_0", 512), ("h_optimus_1", 512), ("prov_gigapath", 512),
-                      ("virchow_v1", 512), ("virchow_v2", 512),
+                      ("virchow_v1", 512), ("virchow_v2", 512), ("h0_mini", 2048),
                       ("lunit_vit_small_patch16_dino", 4096), ("lunit_vit_small_patch8_dino", 512), ("pathorchestra", 2048)):
         mean, std = TRANSFORM_NORM.get(name, (IMAGENET_MEAN, IMAGENET_STD))
         registry.register(name, lambda n=name, c=cap, mu=mean, sd=std: build_hip_vit_extractor(

@@ -218,7 +218,7 @@ def test_registry_has_the_reference_names_of_the_three_encoder_files():
               "midnight", "h_optimus_0", "h_optimus_1", "prov_gigapath", "lunit_vit_small_patch16_dino",
               "lunit_vit_small_patch8_dino", "pathorchestra",
               "clip_vit_b_32", "clip_vit_b_16", "clip_vit_l_14", "clip_vit_l_14_336", "plip", "quilt_b_32", "quilt_b_16",      # clip.py:16-19
-              "biomedclip", "virchow_v1", "virchow_v2"):
+              "biomedclip", "virchow_v1", "virchow_v2", "h0_mini"):
         assert n in names and n in ARCHS and n in TRANSFORM_RESIZE
     g = ARCHS["dinov2_giant"]
     assert (g["dim"], g["depth"], g["heads"], g["mlp_dim"]) == (1536, 40, 24, (int(1536 * 4 * 2 / 3) + 7) // 8 * 8)
@@ -342,7 +342,7 @@ def _with_layer_scale(sd, arch, seed):
                                           ("clip_vit_b_16", torch.float16, 8), ("clip_vit_l_14", torch.float16, 6),
                                           ("clip_vit_l_14_336", torch.float16, 4), ("plip", torch.float16, 8),
                                           ("biomedclip", torch.float16, 8), ("virchow_v1", torch.float16, 3),
-                                          ("virchow_v2", torch.float16, 3)])
+                                          ("virchow_v2", torch.float16, 3), ("h0_mini", torch.float16, 8)])
 def test_encoder_at_real_size_vs_fp32_oracle(name, dtype, n):
     from atlaspatch_amd.encoders.vit import (ARCHS, IMAGENET_MEAN, IMAGENET_STD, TRANSFORM_NORM, TRANSFORM_RESIZE, build_hip_vit_extractor,
                                              random_canonical_state_dict)

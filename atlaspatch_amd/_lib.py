@@ -36,7 +36,7 @@ class VitConfig(C.Structure):
                 ("ln_eps", C.c_float), ("layer_scale", C.c_int), ("compute_dtype", C.c_int),
                 ("pool", C.c_int), ("pool_dim", C.c_int), ("pool_heads", C.c_int), ("pool_ln_eps", C.c_float),
                 ("reg_tokens", C.c_int), ("no_embed_class", C.c_int), ("mlp_type", C.c_int), ("head_dim", C.c_int),
-                ("attn_scale", C.c_float), ("pre_norm", C.c_int), ("act", C.c_int), ("proj_dim", C.c_int)]
+                ("attn_scale", C.c_float), ("pre_norm", C.c_int), ("act", C.c_int), ("proj_dim", C.c_int), ("rope", C.c_int)]
 
 
 # name -> (restype, argtypes); every symbol include/atlaspatch_hip.h declares

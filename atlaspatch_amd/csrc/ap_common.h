@@ -192,6 +192,12 @@ int launch_rowstats_finalize(const float* partial, int rows, int groups, int dim
                              hipStream_t stream);
 // x T rows (row stride `stride` elements) -> dst f32 [rows, dim] dense
 int launch_stream_to_f32(int dtype, const void* x, long stride, int rows, int dim, float* dst, hipStream_t stream);
+// Rotary position embedding of DINOv3 (transformers DINOv3ViT apply_rotary_pos_emb): in place on the q (which & 1) and k
+// (which & 2) parts of the packed qkv [n * tokens, 3 * heads * head_dim], PATCH tokens only (rows >= prefix of every image):
+//   x'[j] = x[j] cos[p][j] - x[j + h] sin[p][j],   x'[j + h] = x[j + h] cos[p][j + h] + x[j] sin[p][j + h],   h = head_dim / 2
+// cos / sin: f32 [patches, head_dim]; f32 arithmetic, one rounding to the compute type.
+int launch_rope(int dtype, void* qkv, int n, int tokens, int prefix, int heads, int head_dim, const float* cos, const float* sin,
+                int which, hipStream_t stream);
 // AP_POOL_CLS_MEAN: y f32 [n * tokens, dim] (final LayerNorm of every token) -> out f32 [n, 2 * dim] = [row 0 | mean of rows prefix ..]
 int launch_cls_mean_pool(const float* y, int n, int tokens, int prefix, int dim, float* out, hipStream_t stream);
 // Weight folding (ap_vit_finalize).  w32: f32 [rows, ld] (zero padded beyond cols).

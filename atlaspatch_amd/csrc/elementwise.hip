@@ -577,6 +577,77 @@ __global__ void chw_to_patchrows_any_kernel(const TI* __restrict__ x, int n, int
     dst[((size_t)(img * g + py) * g + px) * ld + (c * ps + ky) * ps + kx] = from_f32<TO>((float)x[i]);
 }
 
+// DINOv3 rotary embedding, in place on q / k of the packed qkv (see ap_common.h).  One thread = 8 consecutive channels j .. j + 7 of
+// the first half of one head together with their partners j + h .. in the second half (two 16-byte accesses each way for the
+// 16-bit types); unit index = ((row * parts + part) * heads + head) * (h / 8) + chunk.
+template <typename T> struct Rope8 { };
+template <> struct Rope8<float> {
+    static __device__ __forceinline__ void load(const float* p, float* v) {
+        const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+    }
+    static __device__ __forceinline__ void store(float* p, const float* v) {
+        *(f32x4*)p = f32x4{v[0], v[1], v[2], v[3]};
+        *(f32x4*)(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+};
+template <> struct Rope8<f16> {
+    static __device__ __forceinline__ void load(const f16* p, float* v) {
+        const f16x8 a = *(const f16x8*)p;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)a[e];
+    }
+    static __device__ __forceinline__ void store(f16* p, const float* v) {
+        f16x8 a;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = (f16)v[e];
+        *(f16x8*)p = a;
+    }
+};
+template <> struct Rope8<bf16> {
+    static __device__ __forceinline__ void load(const bf16* p, float* v) {
+        const bf16x8 a = *(const bf16x8*)p;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)a[e];
+    }
+    static __device__ __forceinline__ void store(bf16* p, const float* v) {
+        bf16x8 a;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = (bf16)v[e];
+        *(bf16x8*)p = a;
+    }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void rope_kernel(T* __restrict__ qkv, long units, int tokens, int prefix, int heads, int hd,
+                                                   const float* __restrict__ cosv, const float* __restrict__ sinv, int part0, int parts) {
+    const long u = (long)blockIdx.x * 256 + threadIdx.x;
+    if (u >= units) return;
+    const int h = hd >> 1, cpr = h >> 3;                     // chunks of 8 per half head
+    const int chunk = (int)(u % cpr);
+    long r = u / cpr;
+    const int head = (int)(r % heads); r /= heads;
+    const int part = part0 + (int)(r % parts); r /= parts;   // 0 = q, 1 = k
+    const int patches = tokens - prefix;
+    const long img = r / patches;
+    const int pidx = (int)(r % patches);
+    const long row = img * tokens + prefix + pidx;
+    T* x = qkv + row * (long)(3 * heads * hd) + (long)part * heads * hd + head * hd + chunk * 8;
+    const float* c = cosv + (long)pidx * hd + chunk * 8;
+    const float* s = sinv + (long)pidx * hd + chunk * 8;
+    float a[8], b[8], o1[8], o2[8];
+    Rope8<T>::load(x, a);
+    Rope8<T>::load(x + h, b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        o1[e] = a[e] * c[e] - b[e] * s[e];
+        o2[e] = b[e] * c[h + e] + a[e] * s[h + e];
+    }
+    Rope8<T>::store(x, o1);
+    Rope8<T>::store(x + h, o2);
+}
+
 // AP_POOL_CLS_MEAN (midnight.py:58-61, virchow.py:58-61): one thread per (image, channel); the patch rows are summed in row
 // order in double (deterministic, coalesced across the channel threads) and divided once
 __global__ __launch_bounds__(256) void cls_mean_pool_kernel(const float* __restrict__ y, int tokens, int prefix, int dim,
@@ -661,6 +732,20 @@ int launch_rowstats_finalize(const float* partial, int rows, int groups, int dim
     if (rows <= 0) return AP_OK;
     AP_REQUIRE(groups > 0 && groups % 2 == 0, "rowstats_finalize: groups %d must be even", groups);
     rowstats_finalize_kernel<<<(rows + 31) / 32, 256, 0, stream>>>(partial, rows, groups, dim, eps, rowstats);
+    AP_HIP_CHECK(hipGetLastError());
+    return AP_OK;
+}
+
+int launch_rope(int dtype, void* qkv, int n, int tokens, int prefix, int heads, int head_dim, const float* cos, const float* sin,
+                int which, hipStream_t stream) {
+    AP_REQUIRE(head_dim % 16 == 0 && tokens > prefix && cos && sin && (which & 3), "rope: head_dim %d, %d tokens, prefix %d", head_dim, tokens, prefix);
+    if (n <= 0) return AP_OK;
+    const int part0 = (which & 1) ? 0 : 1, parts = (which & 3) == 3 ? 2 : 1;
+    const long units = (long)n * (tokens - prefix) * parts * heads * (head_dim / 16);
+    dim3 grid((unsigned)((units + 255) / 256)), block(256);
+    if (dtype == AP_F16) rope_kernel<f16><<<grid, block, 0, stream>>>((f16*)qkv, units, tokens, prefix, heads, head_dim, cos, sin, part0, parts);
+    else if (dtype == AP_BF16) rope_kernel<bf16><<<grid, block, 0, stream>>>((bf16*)qkv, units, tokens, prefix, heads, head_dim, cos, sin, part0, parts);
+    else rope_kernel<float><<<grid, block, 0, stream>>>((float*)qkv, units, tokens, prefix, heads, head_dim, cos, sin, part0, parts);
     AP_HIP_CHECK(hipGetLastError());
     return AP_OK;
 }

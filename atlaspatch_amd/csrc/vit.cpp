@@ -66,6 +66,7 @@ struct ap_vit {
     const ap::Param* pe_w = nullptr;
     const float *pe_b = nullptr, *cls = nullptr, *pos = nullptr, *norm_w = nullptr, *norm_b = nullptr;
     const float *pre_w = nullptr, *pre_b = nullptr;        // CLIP ln_pre
+    const float *rope_cos = nullptr, *rope_sin = nullptr;  // DINOv3 rotary tables f32 [patches, head_dim]
     const ap::Param* head_proj = nullptr;                       // CLIP visual projection [P, dim]
     float* zero_bias = nullptr;                             // f32 [proj_dim] zeros (the projection has no bias)
     // options (ap_vit_set_option; the defaults come from the environment once, at creation)
@@ -248,6 +249,8 @@ int blocks_f32_stream(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipS
                 g.out = (char*)w.qkv + (size_t)DA * es; g.ldo = 3 * DA;
                 ScopedTimer t(m, AP_PROF_GEMM_QKV, stream);
                 if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_STORE, g, stream)) != AP_OK) return rc;
+                if (c.rope && (rc = ap::launch_rope(dt, w.qkv, n, m->tokens, m->prefix, c.heads, m->hd, m->rope_cos, m->rope_sin, 2,
+                                                    stream)) != AP_OK) return rc;     // the class rows' q is not rotated
             }
             // n-row GEMMs on the 128x128 kernel: more workgroups than 256x256 tiles would give, bit-identical results
             ScopedTimer t(m, AP_PROF_CLS_TAIL, stream);
@@ -293,6 +296,8 @@ int blocks_f32_stream(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipS
             g.M = M; g.N = 3 * DA; g.K = D; g.bias = bp.qkv_b; g.out = w.qkv; g.ldo = 3 * DA;
             ScopedTimer t(m, AP_PROF_GEMM_QKV, stream);
             if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_STORE, g, stream)) != AP_OK) return rc;
+            if (c.rope && (rc = ap::launch_rope(dt, w.qkv, n, m->tokens, m->prefix, c.heads, m->hd, m->rope_cos, m->rope_sin, 3,
+                                                stream)) != AP_OK) return rc;
         }
         { ScopedTimer t(m, AP_PROF_ATTENTION, stream);
           if ((rc = ap::launch_attention(dt, w.qkv, w.att, n, m->tokens, c.heads, m->hd, m->attn_scale,
@@ -365,6 +370,8 @@ int blocks_fused(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipStream
                 g.out = (char*)w.qkv + (size_t)DA * es; g.ldo = 3 * DA;
                 ScopedTimer t(m, AP_PROF_GEMM_QKV, stream);
                 if ((rc = ap::launch_gemm(dt, ap::EPI_NORM_STORE, g, stream)) != AP_OK) return rc;
+                if (c.rope && (rc = ap::launch_rope(dt, w.qkv, n, m->tokens, m->prefix, c.heads, m->hd, m->rope_cos, m->rope_sin, 2,
+                                                    stream)) != AP_OK) return rc;
             }
             ScopedTimer t(m, AP_PROF_CLS_TAIL, stream);
             if ((rc = ap::launch_stream_to_f32(dt, w.x16, (long)m->tokens * D, n, D, w.tok, stream)) != AP_OK) return rc;
@@ -411,6 +418,8 @@ int blocks_fused(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipStream
             g.out = w.qkv; g.ldo = 3 * DA;
             ScopedTimer t(m, AP_PROF_GEMM_QKV, stream);
             if ((rc = ap::launch_gemm(dt, ap::EPI_NORM_STORE, g, stream)) != AP_OK) return rc;
+            if (c.rope && (rc = ap::launch_rope(dt, w.qkv, n, m->tokens, m->prefix, c.heads, m->hd, m->rope_cos, m->rope_sin, 3,
+                                                stream)) != AP_OK) return rc;
         }
         { ScopedTimer t(m, AP_PROF_ATTENTION, stream);
           if ((rc = ap::launch_attention(dt, w.qkv, w.att, n, m->tokens, c.heads, m->hd, m->attn_scale, stream)) != AP_OK) return rc; }
@@ -567,6 +576,7 @@ int ap_vit_create(const ap_vit_config* cfg, ap_vit** out) {
                    2 * c.pool_dim <= c.mlp_dim && 2 * c.pool_dim <= 3 * c.dim,
                    "vit_create: pool_dim %d / pool_heads %d (heads of 64, multiple of 128)", c.pool_dim, c.pool_heads);
     }
+    AP_REQUIRE(c.rope == 0 || (c.head_dim == 0 || c.head_dim * c.heads == c.dim), "vit_create: rope needs the true head width");
     AP_REQUIRE(c.act == AP_ACT_GELU || (c.act == AP_ACT_QUICK_GELU && c.mlp_type == AP_MLP_GELU), "vit_create: act %d", c.act);
     AP_REQUIRE(c.proj_dim == 0 || (c.pool == AP_POOL_CLS && c.proj_dim % 128 == 0 && c.proj_dim <= c.dim),
                "vit_create: proj_dim %d (class-token pooling, a multiple of 128, at most dim)", c.proj_dim);
@@ -601,6 +611,7 @@ int ap_vit_create(const ap_vit_config* cfg, ap_vit** out) {
     add("norm.weight", 1, D, false);
     add("norm.bias", 1, D, false);
     if (c.pre_norm) { add("pre_norm.weight", 1, D, false); add("pre_norm.bias", 1, D, false); }
+    if (c.rope) { add("rope.cos", m->patches, hd, false); add("rope.sin", m->patches, hd, false); }
     if (c.proj_dim > 0) {
         add("head_proj.weight", c.proj_dim, D, true);
         if (rc == AP_OK && (hipMalloc((void**)&m->zero_bias, (size_t)c.proj_dim * sizeof(float)) != hipSuccess ||
@@ -779,6 +790,7 @@ int ap_vit_finalize(ap_vit* m) {
     m->pe_b = vec("patch_embed.bias"); m->cls = vec("cls_token"); m->pos = vec("pos_embed");
     m->norm_w = vec("norm.weight"); m->norm_b = vec("norm.bias");
     m->pre_w = vec("pre_norm.weight"); m->pre_b = vec("pre_norm.bias");
+    m->rope_cos = vec("rope.cos"); m->rope_sin = vec("rope.sin");
     m->head_proj = m->cfg.proj_dim > 0 ? find(m, "head_proj.weight") : nullptr;
     {   // class / register token rows with their position rows folded in (f32; rebuilt on every finalize: it is tiny)
         if (!m->prefix_dev) AP_HIP_CHECK(hipMalloc((void**)&m->prefix_dev, (size_t)m->prefix * m->cfg.dim * sizeof(float)));

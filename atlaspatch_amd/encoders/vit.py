@@ -71,6 +71,9 @@ TRANSFORM_RESIZE = {
     "clip_vit_b_32": (224, "bicubic"), "clip_vit_b_16": (224, "bicubic"), "clip_vit_l_14": (224, "bicubic"),
     "clip_vit_l_14_336": (336, "bicubic"), "plip": (224, "bicubic"), "quilt_b_32": (224, "bicubic"), "quilt_b_16": (224, "bicubic"),
     "biomedclip": (224, "bicubic"),
+    # dinov3.py:52 AutoImageProcessor of facebook/dinov3-*: 224 x 224, bilinear, no crop (public model cards, unverifiable offline)
+    "dinov3_vits16": (224, "bilinear"), "dinov3_vits16_plus": (224, "bilinear"), "dinov3_vitb16": (224, "bilinear"),
+    "dinov3_vitl16": (224, "bilinear"), "dinov3_vitl16_sat": (224, "bilinear"), "dinov3_vith16_plus": (224, "bilinear"),
 }
 
 # Normalize() constants per registered name (default: ImageNet)
@@ -80,6 +83,7 @@ TRANSFORM_NORM = {
     "clip_vit_l_14": (OPENAI_CLIP_MEAN, OPENAI_CLIP_STD), "clip_vit_l_14_336": (OPENAI_CLIP_MEAN, OPENAI_CLIP_STD),
     "plip": (OPENAI_CLIP_MEAN, OPENAI_CLIP_STD), "quilt_b_32": (OPENAI_CLIP_MEAN, OPENAI_CLIP_STD),
     "quilt_b_16": (OPENAI_CLIP_MEAN, OPENAI_CLIP_STD), "biomedclip": (OPENAI_CLIP_MEAN, OPENAI_CLIP_STD),
+    "dinov3_vitl16_sat": ((0.430, 0.411, 0.296), (0.213, 0.156, 0.143)),        # the satellite checkpoints' statistics
     "midnight": ((0.5, 0.5, 0.5), (0.5, 0.5, 0.5)),                                                   # midnight.py:22
     "h_optimus_0": ((0.707223, 0.578729, 0.703617), (0.211883, 0.230117, 0.177517)),                  # hoptimus.py:24-27
     "h_optimus_1": ((0.707223, 0.578729, 0.703617), (0.211883, 0.230117, 0.177517)),
@@ -189,6 +193,21 @@ ARCHS = {
     # 768 -> 512 without bias; encode_image (not normalised)
     "biomedclip": dict(image_size=224, patch_size=16, dim=768, depth=12, heads=12, mlp_dim=3072, ln_eps=1e-6, layer_scale=False,
                        proj_dim=512),
+    # models/patch/dinov3.py:12-21: transformers DINOv3ViTModel, pooler_output.  Class + 4 register tokens, no position embedding,
+    # rotary embedding (theta 100) on q / k of the patch tokens, LayerScale, LayerNorm 1e-5; "plus" = gated MLP.  (The two
+    # dinov3_vit7b16 names: dim 4096 exceeds the LayerNorm kernels' 2048 -- not registered.)
+    "dinov3_vits16": dict(image_size=224, patch_size=16, dim=384, depth=12, heads=6, mlp_dim=1536, ln_eps=1e-5, layer_scale=True,
+                          reg_tokens=4, no_embed_class=True, rope=True),
+    "dinov3_vits16_plus": dict(image_size=224, patch_size=16, dim=384, depth=12, heads=6, mlp_dim=1536, ln_eps=1e-5, layer_scale=True,
+                               reg_tokens=4, no_embed_class=True, rope=True, mlp="swiglu"),
+    "dinov3_vitb16": dict(image_size=224, patch_size=16, dim=768, depth=12, heads=12, mlp_dim=3072, ln_eps=1e-5, layer_scale=True,
+                          reg_tokens=4, no_embed_class=True, rope=True),
+    "dinov3_vitl16": dict(image_size=224, patch_size=16, dim=1024, depth=24, heads=16, mlp_dim=4096, ln_eps=1e-5, layer_scale=True,
+                          reg_tokens=4, no_embed_class=True, rope=True),
+    "dinov3_vitl16_sat": dict(image_size=224, patch_size=16, dim=1024, depth=24, heads=16, mlp_dim=4096, ln_eps=1e-5, layer_scale=True,
+                              reg_tokens=4, no_embed_class=True, rope=True),
+    "dinov3_vith16_plus": dict(image_size=224, patch_size=16, dim=1280, depth=32, heads=20, mlp_dim=5120, ln_eps=1e-5, layer_scale=True,
+                               reg_tokens=4, no_embed_class=True, rope=True, mlp="swiglu"),
 }
 
 
@@ -205,6 +224,8 @@ def _detect_source(sd: dict) -> str:
         return "hf_clip"
     if "visual.ln_pre.weight" in keys or "ln_pre.weight" in keys:
         return "open_clip"
+    if any(k.startswith("model.layer.") and k.endswith("attention.q_proj.weight") for k in keys) and "embeddings.cls_token" in keys:
+        return "hf_dinov3"
     if "embeddings.register_tokens" in keys or any(".layer_scale1.lambda1" in k for k in keys):
         return "hf_dinov2"
     if any(k.startswith("embeddings.patch_embeddings") for k in keys):
@@ -227,7 +248,22 @@ def resample_position_grid(pos: torch.Tensor, grid: int) -> torch.Tensor:
     return y.permute(0, 2, 3, 1).reshape(grid * grid, -1).contiguous()
 
 
-def canonical_state_dict(sd: dict, *, depth: int, layer_scale: bool, source: str = "auto", grid: Optional[int] = None) -> dict:
+def dinov3_rope_tables(grid: int, head_dim: int, theta: float = 100.0) -> tuple[torch.Tensor, torch.Tensor]:
+    """cos / sin [grid * grid, head_dim] of transformers' DINOv3ViTRopePositionEmbedding in eval mode (float32, as the module forces):
+    patch centres (i + 0.5) / grid mapped to [-1, 1], angles = 2 pi * coord * inv_freq with inv_freq = theta ** -arange(0, 1,
+    4 / head_dim), (y | x) blocks flattened to head_dim / 2 and tiled twice."""
+    import math
+    c = torch.arange(0.5, grid, dtype=torch.float32) / grid
+    coords = torch.stack(torch.meshgrid(c, c, indexing="ij"), dim=-1).flatten(0, 1)
+    coords = 2.0 * coords - 1.0
+    inv_freq = 1 / theta ** torch.arange(0, 1, 4 / head_dim, dtype=torch.float32)
+    angles = 2 * math.pi * coords[:, :, None] * inv_freq[None, None, :]
+    angles = angles.flatten(1, 2).tile(2)
+    return torch.cos(angles).contiguous(), torch.sin(angles).contiguous()
+
+
+def canonical_state_dict(sd: dict, *, depth: int, layer_scale: bool, source: str = "auto", grid: Optional[int] = None,
+                         heads: Optional[int] = None, rope_theta: float = 100.0) -> dict:
     """Return ``{canonical name: float32 CPU tensor}`` for ``ap_vit_set_param``.  ``grid``: patches per side of the input the
     encoder will see; an HF DINOv2 checkpoint trained on another grid has its position rows resampled to it (as the model
     itself does in every forward)."""
@@ -345,6 +381,39 @@ def canonical_state_dict(sd: dict, *, depth: int, layer_scale: bool, source: str
             put(b + "ln2.weight", sd[p + "ln_2.weight"]); put(b + "ln2.bias", sd[p + "ln_2.bias"])
             put(b + "fc1.weight", sd[p + "mlp.c_fc.weight"]); put(b + "fc1.bias", sd[p + "mlp.c_fc.bias"])
             put(b + "fc2.weight", sd[p + "mlp.c_proj.weight"]); put(b + "fc2.bias", sd[p + "mlp.c_proj.bias"])
+    elif source == "hf_dinov3":
+        # transformers DINOv3ViTModel (dinov3.py:52-67): class + register tokens, NO position embedding (zeros here; the rotary
+        # tables rope.cos | rope.sin carry the positions), k_proj without bias, LayerScale, plain or gated (silu(gate) * up = the
+        # packed SwiGLU layout [gate; up]) MLP, LayerNorm 1e-5, pooler_output = final LayerNorm of the class token
+        if grid is None or heads is None:
+            raise ValueError("hf_dinov3: the patch grid and the head count are needed for the rotary tables")
+        d = sd["embeddings.cls_token"].shape[-1]
+        put("patch_embed.weight", sd["embeddings.patch_embeddings.weight"]); put("patch_embed.bias", sd["embeddings.patch_embeddings.bias"])
+        put("cls_token", sd["embeddings.cls_token"].reshape(-1))
+        if sd["embeddings.register_tokens"].shape[1] > 0:
+            put("reg_tokens", sd["embeddings.register_tokens"][0])
+        put("pos_embed", torch.zeros(int(grid) * int(grid), d))
+        put("norm.weight", sd["norm.weight"]); put("norm.bias", sd["norm.bias"])
+        cos, sin = dinov3_rope_tables(int(grid), d // int(heads), rope_theta)
+        put("rope.cos", cos); put("rope.sin", sin)
+        for i in range(depth):
+            p, b = f"model.layer.{i}.", f"blocks.{i}."
+            a = p + "attention."
+            zeros = torch.zeros(d)
+            bias = lambda n: sd[a + n + ".bias"] if a + n + ".bias" in sd else zeros
+            put(b + "ln1.weight", sd[p + "norm1.weight"]); put(b + "ln1.bias", sd[p + "norm1.bias"])
+            put(b + "qkv.weight", torch.cat([sd[a + "q_proj.weight"], sd[a + "k_proj.weight"], sd[a + "v_proj.weight"]], 0))
+            put(b + "qkv.bias", torch.cat([bias("q_proj"), bias("k_proj"), bias("v_proj")], 0))
+            put(b + "proj.weight", sd[a + "o_proj.weight"]); put(b + "proj.bias", sd[a + "o_proj.bias"])
+            put(b + "ln2.weight", sd[p + "norm2.weight"]); put(b + "ln2.bias", sd[p + "norm2.bias"])
+            if p + "mlp.gate_proj.weight" in sd:
+                put(b + "fc1.weight", torch.cat([sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]], 0))
+                put(b + "fc1.bias", torch.cat([sd[p + "mlp.gate_proj.bias"], sd[p + "mlp.up_proj.bias"]], 0))
+            else:
+                put(b + "fc1.weight", sd[p + "mlp.up_proj.weight"]); put(b + "fc1.bias", sd[p + "mlp.up_proj.bias"])
+            put(b + "fc2.weight", sd[p + "mlp.down_proj.weight"]); put(b + "fc2.bias", sd[p + "mlp.down_proj.bias"])
+            if layer_scale:
+                put(b + "ls1", sd[p + "layer_scale1.lambda1"]); put(b + "ls2", sd[p + "layer_scale2.lambda1"])
     elif source == "hf_dinov2":
         # transformers Dinov2Model / Dinov2WithRegistersModel: the position embedding has a class row and patch rows but none
         # for the register tokens, which are inserted AFTER it is added -> canonical no_embed_class form with the class row
@@ -509,6 +578,9 @@ def random_canonical_state_dict(arch: dict, seed: int = 0) -> dict:
             sd[b + "ls2"] = torch.full((d,), 1e-5) + w(d, s=1e-6)
     if arch.get("pool") == "attn":
         sd.update(attn_pool_canonical(random_attn_pool(arch, seed), pool_eps=arch.get("pool_ln_eps", 1e-5)))
+    if arch.get("rope"):
+        sd["pos_embed"] = torch.zeros_like(sd["pos_embed"])
+        sd["rope.cos"], sd["rope.sin"] = dinov3_rope_tables(arch["image_size"] // ps, d // arch["heads"], float(arch.get("rope_theta", 100.0)))
     if arch.get("pre_norm"):
         sd["pre_norm.weight"] = 1.0 + w(d, s=0.1); sd["pre_norm.bias"] = w(d)
     if arch.get("proj_dim"):
@@ -544,7 +616,7 @@ class HipViT:
                              1 if arch.get("mlp") == "swiglu" else 0, hd_stored,
                              0.0 if hd_stored == hd_true else float(1.0 / np.sqrt(np.float32(hd_true))),
                              1 if arch.get("pre_norm") else 0, 1 if arch.get("act") == "quick_gelu" else 0,
-                             int(arch.get("proj_dim", 0)))
+                             int(arch.get("proj_dim", 0)), 1 if arch.get("rope") else 0)
         state = pad_heads(state, dim=arch["dim"], heads=arch["heads"], depth=arch["depth"])
         state = pad_mlp(state, mlp_dim=arch["mlp_dim"], depth=arch["depth"], swiglu=arch.get("mlp") == "swiglu")
         handle = C.c_void_p()
@@ -693,7 +765,8 @@ def build_hip_vit_extractor(*, name: str, arch, device, dtype, state_dict: Optio
             pool_state = {k: v for k, v in state_dict.items() if k.startswith("attn_pool.")}
             state_dict = {k: v for k, v in state_dict.items() if not k.startswith("attn_pool.")}
     state = canonical_state_dict(state_dict, depth=spec["depth"], layer_scale=bool(spec.get("layer_scale")),
-                                 source=source, grid=spec["image_size"] // spec["patch_size"])
+                                 source=source, grid=spec["image_size"] // spec["patch_size"], heads=spec["heads"],
+                                 rope_theta=float(spec.get("rope_theta", 100.0)))
     if pool_state:
         state.update({k: v.detach().to(torch.float32).cpu().contiguous() for k, v in pool_state.items()})
     vit = HipViT(spec, state, device=torch.device(device), dtype=dtype)
@@ -791,6 +864,18 @@ def register_clip(registry, *, device, dtype=torch.float32, num_workers: int = 0
     for name, cap in (("clip_vit_b_32", 4096), ("clip_vit_b_16", 2048), ("clip_vit_l_14", 1024), ("clip_vit_l_14_336", 256),
                       ("plip", 4096), ("quilt_b_32", 4096), ("quilt_b_16", 2048), ("biomedclip", 2048)):
         mean, std = TRANSFORM_NORM[name]
+        registry.register(name, lambda n=name, c=cap, mu=mean, sd=std: build_hip_vit_extractor(
+            name=n, arch=n, device=device, dtype=dtype, random_init_seed=_env_seed(), resize=TRANSFORM_RESIZE[n],
+            expect_size=None, max_batch=c, mean=mu, std=sd))
+
+
+def register_dinov3(registry, *, device, dtype=torch.float32, num_workers: int = 0) -> None:
+    """dinov3_vits16 / vits16_plus / vitb16 / vitl16 / vitl16_sat / vith16_plus (models/patch/dinov3.py:12-19): transformers'
+    DINOv3ViTModel, ``pooler_output``.  Rotary position embedding applied in place on q / k after the qkv GEMM (``ap::launch_rope``);
+    HF state dicts in ATLASPATCH_WEIGHTS_DIR."""
+    for name, cap in (("dinov3_vits16", 4096), ("dinov3_vits16_plus", 4096), ("dinov3_vitb16", 2048), ("dinov3_vitl16", 2048),
+                      ("dinov3_vitl16_sat", 2048), ("dinov3_vith16_plus", 1024)):
+        mean, std = TRANSFORM_NORM.get(name, (IMAGENET_MEAN, IMAGENET_STD))
         registry.register(name, lambda n=name, c=cap, mu=mean, sd=std: build_hip_vit_extractor(
             name=n, arch=n, device=device, dtype=dtype, random_init_seed=_env_seed(), resize=TRANSFORM_RESIZE[n],
             expect_size=None, max_batch=c, mean=mu, std=sd))

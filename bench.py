@@ -69,6 +69,11 @@ ENCODERS = {
                    "mean": OPENAI_CLIP_MEAN, "std": OPENAI_CLIP_STD},
     "virchow_v1": {"label": "Virchow (ViT-H/14, 80-wide heads and a 3416-wide SwiGLU stored padded, class | mean patch token)", "batch": 512},
     "virchow_v2": {"label": "Virchow2 (as Virchow + 4 register tokens)", "batch": 512},
+    # DINOv3 (dinov3.py): rotary embedding on q / k in place after the qkv GEMM
+    "dinov3_vits16": {"label": "DINOv3 ViT-S/16 (201 tokens, RoPE)", "batch": 4096},
+    "dinov3_vitb16": {"label": "DINOv3 ViT-B/16 (201 tokens, RoPE)", "batch": 2048},
+    "dinov3_vitl16": {"label": "DINOv3 ViT-L/16 (201 tokens, RoPE)", "batch": 2048},
+    "dinov3_vith16_plus": {"label": "DINOv3 ViT-H+/16 (201 tokens, RoPE, gated MLP)", "batch": 1024},
 }
 
 

@@ -211,6 +211,10 @@ typedef struct ap_vit_config {
     int proj_dim;        /* 0, or P: the pooled vector (AP_POOL_CLS: final LN of the class token) is multiplied by
                             head_proj.weight [P, dim] without bias (CLIP visual projection: encode_image / get_image_features);
                             multiple of 128; ap_vit_embed_dim = P */
+    int rope;            /* 1: no absolute position embedding use beyond pos_embed (upload zeros) and a rotary embedding on q / k of the
+                            PATCH tokens in every block (transformers DINOv3ViTModel, models/patch/dinov3.py): parameters
+                            rope.cos | rope.sin f32 [patches, head_dim] (the host builds them as the HF module does);
+                            head_dim must be the true head width */
 } ap_vit_config;
 #define AP_ACT_GELU 0
 #define AP_ACT_QUICK_GELU 1

@@ -186,6 +186,16 @@ def vit_tokens_canonical(sd: dict, x: torch.Tensor, *, heads: int, depth: int, e
         qkv = h @ sd[p + "qkv.weight"].T + sd[p + "qkv.bias"]
         t = tok.shape[1]
         q, k, v = qkv.view(n, t, 3, heads, dh).permute(2, 0, 3, 1, 4)
+        if "rope.cos" in sd:
+            # transformers DINOv3ViT apply_rotary_pos_emb (models/patch/dinov3.py -> AutoModel): patch tokens only
+            cos, sin = sd["rope.cos"], sd["rope.sin"]
+            pre = t - cos.shape[0]
+
+            def rot(x):
+                xp = x[:, :, pre:]
+                x1, x2 = xp[..., : dh // 2], xp[..., dh // 2:]
+                return torch.cat([x[:, :, :pre], xp * cos + torch.cat([-x2, x1], dim=-1) * sin], dim=2)
+            q, k = rot(q), rot(k)
         att = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(dh), dim=-1)
         ctx = (att @ v).transpose(1, 2).reshape(n, t, d)
         out = ctx @ sd[p + "proj.weight"].T + sd[p + "proj.bias"]

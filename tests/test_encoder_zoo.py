@@ -126,6 +126,35 @@ def test_oracle_matches_hf_vit_with_the_phikon_layer_norm_eps():
     assert _rel(got.numpy(), want.numpy()) <= 2e-6
 
 
+def _hf_dinov3(hidden=128, layers=2, heads=2, inter=256, image=64, gated=False):
+    from transformers import DINOv3ViTConfig, DINOv3ViTModel
+    torch.manual_seed(0)
+    cfg = DINOv3ViTConfig(hidden_size=hidden, intermediate_size=inter, num_attention_heads=heads, num_hidden_layers=layers,
+                          num_register_tokens=4, image_size=image, patch_size=16, use_gated_mlp=gated, hidden_act="silu" if gated else "gelu")
+    return _seed_params(DINOv3ViTModel(cfg).eval())
+
+
+@pytest.mark.parametrize("gated", [False, True])
+def test_oracle_matches_hf_dinov3_with_the_rotary_embedding(gated):
+    """models/patch/dinov3.py:52-67 calls transformers' DINOv3ViTModel and returns pooler_output -- importable here: class + 4
+    register tokens, no position embedding, rotary embedding on q / k of the patch tokens only, k_proj without bias, LayerScale,
+    plain or gated MLP, LayerNorm 1e-5.  The oracle through the hf_dinov3 adapter (rotary tables rebuilt as the HF module builds
+    them) reproduces it."""
+    from atlaspatch_amd.encoders.vit import canonical_state_dict
+    from oracle import vit_oracle
+    model = _hf_dinov3(gated=gated)
+    x = torch.randn(3, 3, 64, 64, generator=torch.Generator().manual_seed(9))
+    with torch.inference_mode():
+        out = model(pixel_values=x)
+        cos, sin = model.rope_embeddings(x)
+    sd = canonical_state_dict(dict(model.state_dict()), depth=2, layer_scale=True, grid=4, heads=2)          # auto-detected: hf_dinov3
+    assert torch.equal(sd["rope.cos"], cos) and torch.equal(sd["rope.sin"], sin) and sd["reg_tokens"].shape == (4, 128)
+    assert float(sd["pos_embed"].abs().max()) == 0.0 and float(sd["blocks.0.qkv.bias"][128:256].abs().max()) == 0.0    # no k bias
+    tok = vit_oracle.vit_tokens_canonical(sd, x, heads=2, depth=2, eps=1e-5)
+    assert _rel(tok.numpy(), out.last_hidden_state.numpy()) <= 2e-6
+    assert _rel(tok[:, 0].numpy(), out.pooler_output.numpy()) <= 2e-6
+
+
 def test_mlp_padding_leaves_the_function_unchanged():
     """pad_mlp (Virchow's 3416-wide SwiGLU -> 3456): zero rows in fc1, zero columns in fc2, both halves of the packed layer."""
     from atlaspatch_amd.encoders.vit import pad_mlp, random_canonical_state_dict, stored_mlp_dim
@@ -218,7 +247,8 @@ def test_registry_has_the_reference_names_of_the_three_encoder_files():
               "midnight", "h_optimus_0", "h_optimus_1", "prov_gigapath", "lunit_vit_small_patch16_dino",
               "lunit_vit_small_patch8_dino", "pathorchestra",
               "clip_vit_b_32", "clip_vit_b_16", "clip_vit_l_14", "clip_vit_l_14_336", "plip", "quilt_b_32", "quilt_b_16",      # clip.py:16-19
-              "biomedclip", "virchow_v1", "virchow_v2", "h0_mini"):
+              "biomedclip", "virchow_v1", "virchow_v2", "h0_mini",
+              "dinov3_vits16", "dinov3_vits16_plus", "dinov3_vitb16", "dinov3_vitl16", "dinov3_vitl16_sat", "dinov3_vith16_plus"):
         assert n in names and n in ARCHS and n in TRANSFORM_RESIZE
     g = ARCHS["dinov2_giant"]
     assert (g["dim"], g["depth"], g["heads"], g["mlp_dim"]) == (1536, 40, 24, (int(1536 * 4 * 2 / 3) + 7) // 8 * 8)
@@ -292,6 +322,20 @@ MEASURED.update({                     # the transformers-backed encoders (dinov2
     ("virchow_v1 L32, f32_stream", "float16"): (1.788e-3, 2.851e-2, 2.082e-2),
     ("virchow_v2 L32", "float16"): (2.349e-3, 3.663e-2, 2.726e-2),
     ("virchow_v2 L32, f32_stream", "float16"): (1.812e-3, 2.682e-2, 2.235e-2),
+    ("h0_mini L12", "float16"): (8.81e-4, 1.533e-2, 9.67e-3),
+    ("h0_mini L12, f32_stream", "float16"): (5.61e-4, 1.009e-2, 7.89e-3),
+    # DINOv3 (rotary embedding in f32, one rounding)
+    ("dinov3_vits16 L12", "float16"): (1.238e-3, 1.568e-2, 1.276e-2),
+    ("dinov3_vits16 L12, f32_stream", "float16"): (8.05e-4, 1.204e-2, 9.60e-3),
+    ("dinov3_vits16 L12", "float32"): (1.381e-6, 2.111e-5, 1.757e-5),
+    ("dinov3_vits16_plus L12", "float16"): (1.179e-3, 1.587e-2, 1.170e-2),
+    ("dinov3_vits16_plus L12, f32_stream", "float16"): (8.18e-4, 8.69e-3, 7.55e-3),
+    ("dinov3_vitb16 L12", "float16"): (1.290e-3, 1.795e-2, 1.456e-2),
+    ("dinov3_vitb16 L12, f32_stream", "float16"): (8.99e-4, 1.632e-2, 1.145e-2),
+    ("dinov3_vitl16 L24", "float16"): (1.627e-3, 2.168e-2, 1.434e-2),
+    ("dinov3_vitl16 L24, f32_stream", "float16"): (9.62e-4, 1.380e-2, 1.103e-2),
+    ("dinov3_vith16_plus L32", "float16"): (3.209e-3, 3.538e-2, 2.964e-2),
+    ("dinov3_vith16_plus L32, f32_stream", "float16"): (2.457e-3, 2.948e-2, 2.717e-2),
 })
 HEADROOM = (1.2, 1.5, 1.25)
 FALLBACK = {"float32": (3.0e-6, 6e-5, 4e-5), "float16": (3.6e-3, 5.2e-2, 3.8e-2)}
@@ -342,7 +386,10 @@ def _with_layer_scale(sd, arch, seed):
                                           ("clip_vit_b_16", torch.float16, 8), ("clip_vit_l_14", torch.float16, 6),
                                           ("clip_vit_l_14_336", torch.float16, 4), ("plip", torch.float16, 8),
                                           ("biomedclip", torch.float16, 8), ("virchow_v1", torch.float16, 3),
-                                          ("virchow_v2", torch.float16, 3), ("h0_mini", torch.float16, 8)])
+                                          ("virchow_v2", torch.float16, 3), ("h0_mini", torch.float16, 8),
+                                          ("dinov3_vits16", torch.float16, 8), ("dinov3_vits16", torch.float32, 8),
+                                          ("dinov3_vits16_plus", torch.float16, 8), ("dinov3_vitb16", torch.float16, 8),
+                                          ("dinov3_vitl16", torch.float16, 6), ("dinov3_vith16_plus", torch.float16, 4)])
 def test_encoder_at_real_size_vs_fp32_oracle(name, dtype, n):
     from atlaspatch_amd.encoders.vit import (ARCHS, IMAGENET_MEAN, IMAGENET_STD, TRANSFORM_NORM, TRANSFORM_RESIZE, build_hip_vit_extractor,
                                              random_canonical_state_dict)
@@ -481,4 +528,37 @@ def test_clip_tower_on_the_device_vs_hf_get_image_features(dtype, tol):
     assert got.shape == want.shape == (6, 256)
     assert _rel(got, want) <= tol, _rel(got, want)
     if dtype != torch.float32:
+        assert _rel(got2, want) <= tol, _rel(got2, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.float16, 4e-3)])
+@pytest.mark.parametrize("gated", [False, True])
+def test_dinov3_on_the_device_vs_the_hf_model(dtype, tol, gated):
+    """dinov3.py:63-67 on the device: an HF DINOv3ViTModel state dict (dim 384, 4 blocks, 4 register tokens) through the hf_dinov3
+    adapter -- rotary embedding applied in place after the qkv GEMM -- against the HF model's pooler_output, both dataflows and
+    the full last block."""
+    from atlaspatch_amd.encoders.vit import build_hip_vit_extractor
+    from oracle import vit_oracle
+    model = _hf_dinov3(hidden=384, layers=4, heads=6, inter=1536 if not gated else 1024, image=224, gated=gated)
+    arch = dict(image_size=224, patch_size=16, dim=384, depth=4, heads=6, mlp_dim=1536 if not gated else 1024, ln_eps=1e-5, layer_scale=True,
+                reg_tokens=4, no_embed_class=True, rope=True, mlp="swiglu" if gated else None)
+    ex = build_hip_vit_extractor(name="dinov3_vits16", arch=arch, state_dict=dict(model.state_dict()), device=torch.device("cuda:0"),
+                                 dtype=dtype, resize=(224, "bilinear"), expect_size=None, max_batch=64)
+    tiles = _tiles(6, 67)
+    got = ex.extract_batch(tiles, batch_size=32)
+    ex.vit.set_option("full_last_block", True)
+    got_full = ex.extract_batch(tiles, batch_size=32)
+    got2 = None
+    if dtype != torch.float32:
+        ex.vit.set_option("full_last_block", False)
+        ex.vit.set_option("f32_stream", True)
+        got2 = ex.extract_batch(tiles, batch_size=32)
+    ex.cleanup()
+    x = vit_oracle.transform_resize_crop(tiles, resize=(224, "bilinear"), crop=224)
+    with torch.inference_mode():
+        want = model(pixel_values=x).pooler_output.numpy()
+    assert got.shape == want.shape == (6, 384)
+    assert _rel(got, want) <= tol and _rel(got_full, want) <= tol, (_rel(got, want), _rel(got_full, want))
+    if got2 is not None:
         assert _rel(got2, want) <= tol, _rel(got2, want)

@@ -151,6 +151,34 @@ def test_cli_process_conch_and_uni_fp16(tmp_path, monkeypatch):
     assert np.abs(conch).max() > 0.1 and np.unique(np.round(conch[:, 0], 3)).size > 1
 
 
+def test_cli_process_with_the_widened_encoder_families(tmp_path, monkeypatch):
+    """`process` with one encoder of every family added past the three starred files -- transformers DINOv2 (dinov2_small), DINOv3
+    with the rotary embedding (dinov3_vits16), a CLIP tower with its projection head (plip, 512-d) and class | mean patch token
+    pooling (h0_mini, 1536-d) -- all in one H5, rows aligned with coords, and the CLI's --feature-extractors help lists them."""
+    from click.testing import CliRunner
+    from atlaspatch_amd.cli import cli
+    from atlaspatch_amd.utils.h5 import h5
+
+    monkeypatch.setenv("ATLASPATCH_RANDOM_INIT", "1")
+    slide, raw = _make_slide(str(tmp_path), "s5.synth", width=5000, height=4000, seed=5)
+    out = tmp_path / "out"
+    names = {"dinov2_small": 384, "dinov3_vits16": 384, "plip": 512, "h0_mini": 1536}
+    args = ["process", slide, "-o", str(out), "--patch-size", "256", "--target-mag", "20",
+            "--feature-extractors", ",".join(names), "--feature-precision", "float16"]
+    res = CliRunner().invoke(cli, args, catch_exceptions=False)
+    assert res.exit_code == 0 and "failures: 0" in res.output, res.output
+    with h5.File(out / "patches" / "s5.h5", "r") as f:
+        n = f["coords"].shape[0]
+        feats = {k: f["features"][k][:] for k in names}
+    assert n > 0
+    for k, d in names.items():
+        assert feats[k].shape == (n, d) and np.isfinite(feats[k]).all() and np.abs(feats[k]).max() > 0.05, k
+    # (random-init LayerScale is 1e-5, so the LayerScale encoders' features barely depend on the tile; the CLIP tower has none)
+    assert np.unique(np.round(feats["plip"][:, 0], 3)).size > 1
+    helptext = CliRunner().invoke(cli, ["process", "--help"]).output
+    assert "dinov3_vits16" in helptext and "clip_vit_l_14" in helptext
+
+
 def test_cli_no_fast_mode_and_save_images(tmp_path):
     """segment-and-get-coords --no-fast-mode --save-images: rows = oracle coords minus tiles the cv2-restated
     is_black / is_white reject (reference extraction.py:105-116), one PNG per kept row with the tile's pixels."""

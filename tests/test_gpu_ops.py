@@ -660,6 +660,33 @@ def test_vit_set_params_equals_per_tensor_uploads_and_rejects_bad_entries(env):
     batched.release(); single.release()
 
 
+def test_vit_create_rejects_configurations_the_kernels_cannot_run():
+    """ap_vit_create validates the ABI-v18 fields: every rejected configuration names itself in ap_last_error and leaves no
+    handle behind."""
+    import ctypes as C
+    from atlaspatch_amd import _lib
+    lib = _lib.load()
+    base = dict(image_size=224, patch_size=16, dim=768, depth=2, heads=12, mlp_dim=3072, ln_eps=1e-6, layer_scale=0, compute_dtype=1,
+                pool=0, pool_dim=0, pool_heads=0, pool_ln_eps=1e-5, reg_tokens=0, no_embed_class=0, mlp_type=0, head_dim=0,
+                attn_scale=0.0, pre_norm=0, act=0, proj_dim=0, rope=0)
+
+    def create(**kw):
+        cfg = _lib.VitConfig(*[{**base, **kw}[name] for name, _ in _lib.VitConfig._fields_])
+        h = C.c_void_p()
+        rc = lib.ap_vit_create(C.byref(cfg), C.byref(h))
+        if rc == 0:
+            lib.ap_vit_destroy(h)
+        return rc, lib.ap_last_error().decode()
+
+    assert create()[0] == 0
+    assert create(pool=2)[0] == 0 and create(pre_norm=1, act=1, proj_dim=512)[0] == 0 and create(rope=1)[0] == 0
+    for kw, word in ((dict(pool=3), "pool"), (dict(proj_dim=500), "proj_dim"), (dict(proj_dim=1024), "proj_dim"),
+                     (dict(proj_dim=512, pool=2), "proj_dim"), (dict(act=1, mlp_type=1), "act"), (dict(act=7), "act"),
+                     (dict(rope=1, dim=1280, heads=16, mlp_dim=5120, head_dim=128), "rope")):
+        rc, msg = create(**kw)
+        assert rc != 0 and word in msg, (kw, rc, msg)
+
+
 def test_clock_probe_reports_a_plausible_shader_clock():
     """ap_clock_probe (bench.py's clock line): s_memtime / s_memrealtime stamps per compute unit around a few GEMM-sized launches give
     a shader clock inside the part's range on every XCD."""

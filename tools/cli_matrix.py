@@ -21,7 +21,12 @@ with tempfile.TemporaryDirectory() as tmp:
              (["--feature-extractors", "vit_l_16", "--feature-precision", "float16", "--target-mag", "10", "--save-images",
                "--visualize-grids", "--visualize-mask", "--visualize-contours"], "mag20->10 (512 reads, cv2 resize) + images + overlays", slides[1]),
              (["--feature-extractors", "vit_b_16", "--feature-precision", "float16", "--no-fast-mode", "--step-size", "128",
-               "--target-mag", "5"], "mag20->5 (1024 reads), no-fast-mode, overlap", slides[1])]
+               "--target-mag", "5"], "mag20->5 (1024 reads), no-fast-mode, overlap", slides[1]),
+             # the widened encoder families off the default tile size / precision
+             (["--feature-extractors", "dinov2_small,clip_vit_b_32,h0_mini", "--feature-precision", "bfloat16", "--patch-size", "512"],
+              "bf16, 512-px tiles: DINOv2 / CLIP projection / class | mean pooling", slides[0]),
+             (["--feature-extractors", "dinov3_vits16,phikon_v1,lunit_vit_small_patch16_dino", "--feature-precision", "float32"],
+              "f32: DINOv3 rotary, HF ViT eps 1e-12, Lunit", slides[1])]
     for k, (extra, label, target) in enumerate(cases):
         out = os.path.join(tmp, f"out{k}")
         args = ["process", target, "-o", out] + (["--target-mag", "20"] if "--target-mag" not in extra else []) + \

@@ -210,9 +210,10 @@ int launch_fold_ln(int dtype, const float* w32, int rows, int cols, int ld, cons
 int launch_fold_ls(int dtype, const float* w32, int rows, int cols, int ld, const float* ls, const float* bias_in,
                    void* wout, float* bias_out, hipStream_t stream);
 // prefix rows of the token stream (class token, then register tokens): prefix f32 [prefix_rows, dim] = the token values with
-// their position-embedding rows already added (ap_vit_finalize).  fused path: x[img * tokens + j] = T(prefix[j]) and the rows'
-// partial sums; f32 path: tok[img * tokens + j] = prefix[j]
-int launch_cls_stream(int dtype, const float* prefix, int prefix_rows, int n, int tokens, int dim, void* x, float* partial,
+// their position-embedding rows already added (ap_vit_finalize).  fused path: x[img * tokens + j] = T(prefix[img * img_rows + j])
+// and the rows' partial sums (img_rows = 0: one prefix shared by every image; img_rows = prefix_rows = 1: the exact f32 class
+// rows [n, dim] rounded back into the stream); f32 path: tok[img * tokens + j] = prefix[j]
+int launch_cls_stream(int dtype, const float* prefix, int prefix_rows, int img_rows, int n, int tokens, int dim, void* x, float* partial,
                       hipStream_t stream);
 int launch_cls_init(float* tok, const float* prefix, int prefix_rows, int n, int tokens, int dim, hipStream_t stream);
 // out[m][j] = T(silu(x[m][j]) * x[m][h + j]), x: T [rows, 2h] dense, out: T [rows, h] dense (timm SwiGLUPacked; f32 math)

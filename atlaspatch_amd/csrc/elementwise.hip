@@ -329,11 +329,11 @@ __global__ __launch_bounds__(256) void rowstats_finalize_kernel(const float* __r
 // class-token rows of the fused path: x[img * tokens][:] = T(cls + pos[0]) and the row's partial sums per 64-column group
 // (one wave per (image, group): lane = column).  Only this kernel ever produces these rows, so its summation order is theirs.
 template <typename T>
-__global__ __launch_bounds__(64) void cls_stream_kernel(const float* __restrict__ prefix, int prefix_rows, int tokens,
+__global__ __launch_bounds__(64) void cls_stream_kernel(const float* __restrict__ prefix, int prefix_rows, int img_rows, int tokens,
                                                         int dim, T* __restrict__ x, float* __restrict__ partial) {
     const int img = blockIdx.x / prefix_rows, j = blockIdx.x - img * prefix_rows, grp = blockIdx.y, col = grp * 64 + threadIdx.x;
     const size_t row = (size_t)img * tokens + j;
-    const T v = from_f32<T>(prefix[(size_t)j * dim + col]);
+    const T v = from_f32<T>(prefix[((size_t)img * img_rows + j) * dim + col]);
     x[row * dim + col] = v;
     const float f = (float)v;
     const float s = wave_sum(f), q = wave_sum(f * f);
@@ -715,13 +715,13 @@ int launch_stream_init(int dtype, const float* tok, int rows, int dim, float eps
     return AP_OK;
 }
 
-int launch_cls_stream(int dtype, const float* prefix, int prefix_rows, int n, int tokens, int dim, void* x, float* partial,
+int launch_cls_stream(int dtype, const float* prefix, int prefix_rows, int img_rows, int n, int tokens, int dim, void* x, float* partial,
                       hipStream_t stream) {
     AP_REQUIRE(dim % 64 == 0 && prefix_rows > 0, "cls_stream: dim %d must be a multiple of 64", dim);
     if (n <= 0) return AP_OK;
     dim3 grid(n * prefix_rows, dim / 64), block(64);
-    if (dtype == AP_F16) cls_stream_kernel<f16><<<grid, block, 0, stream>>>(prefix, prefix_rows, tokens, dim, (f16*)x, partial);
-    else if (dtype == AP_BF16) cls_stream_kernel<bf16><<<grid, block, 0, stream>>>(prefix, prefix_rows, tokens, dim, (bf16*)x, partial);
+    if (dtype == AP_F16) cls_stream_kernel<f16><<<grid, block, 0, stream>>>(prefix, prefix_rows, img_rows, tokens, dim, (f16*)x, partial);
+    else if (dtype == AP_BF16) cls_stream_kernel<bf16><<<grid, block, 0, stream>>>(prefix, prefix_rows, img_rows, tokens, dim, (bf16*)x, partial);
     else { set_error("cls_stream: dtype %d (f16 / bf16 only)", dtype); return AP_ERR_INVALID; }
     AP_HIP_CHECK(hipGetLastError());
     return AP_OK;

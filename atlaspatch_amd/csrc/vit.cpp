@@ -71,6 +71,7 @@ struct ap_vit {
     float* zero_bias = nullptr;                             // f32 [proj_dim] zeros (the projection has no bias)
     // options (ap_vit_set_option; the defaults come from the environment once, at creation)
     bool full_last_block = false, two_half_overlap = false, f32_stream = false;
+    bool exact_cls = true;      // fused dataflow: the class rows' residual stream is also kept in f32 (blocks_fused)
     std::vector<ap::FusedBlock> fused;      // filled by ap_vit_finalize for f16 / bf16
     std::vector<void*> fused_allocs;
     void* pos16 = nullptr;                  // position embedding in the compute type (fused patch embedding), in fused_allocs
@@ -133,6 +134,7 @@ const Param* find(const ap_vit* m, const std::string& name) {
 struct Workspace {
     float* tok; void* xn; void* qkv; void* att; void* hid; void* hid2; void* delta; void* delta2;
     void* x16; float* rowstats; float* partial;      // fused-LayerNorm path: T stream [M, D], f32 [M, 2], f32 [M, D / 64, 2]
+    float* cls32;                                    //   and the class rows' exact residual stream, f32 [n, D]
     size_t total;
 };
 
@@ -157,9 +159,11 @@ Workspace carve(const ap_vit* m, int n, char* base) {
     const size_t o_x16 = has_fused ? take(M * D * es) : 0;
     const size_t o_rs = has_fused ? take(M * 2 * sizeof(float)) : 0;
     const size_t o_part = has_fused ? take(M * (D / 64) * 2 * sizeof(float)) : 0;
+    const size_t o_cls32 = has_fused ? take((size_t)n * D * sizeof(float)) : 0;
     w.x16 = has_fused ? base + o_x16 : nullptr;
     w.rowstats = has_fused ? (float*)(base + o_rs) : nullptr;
     w.partial = has_fused ? (float*)(base + o_part) : nullptr;
+    w.cls32 = has_fused ? (float*)(base + o_cls32) : nullptr;
     w.tok = (float*)(base + o_tok); w.xn = base + o_xn; w.qkv = base + o_qkv;
     w.att = base + o_att; w.hid = base + o_hid; w.delta = base + o_delta; w.delta2 = base + o_delta2; w.total = off;
     w.hid2 = m->cfg.mlp_type == AP_MLP_SWIGLU ? (char*)w.hid + M * (size_t)(2 * m->cfg.mlp_dim) * es : w.hid;
@@ -206,7 +210,7 @@ int patch_embed_stream(ap_vit* m, int n, const Workspace& w, hipStream_t stream)
     { ScopedTimer t(m, AP_PROF_GEMM_PATCH_EMBED, stream);
       if ((rc = ap::launch_gemm(dt, ap::EPI_PATCH_STREAM, g, stream)) != AP_OK) return rc; }
     ScopedTimer t(m, AP_PROF_LAYERNORM, stream);
-    if ((rc = ap::launch_cls_stream(dt, m->prefix_dev, m->prefix, n, m->tokens, D, w.x16, w.partial, stream)) != AP_OK) return rc;
+    if ((rc = ap::launch_cls_stream(dt, m->prefix_dev, m->prefix, 0, n, m->tokens, D, w.x16, w.partial, stream)) != AP_OK) return rc;
     return ap::launch_rowstats_finalize(w.partial, n * m->tokens, D / 64, D, c.ln_eps, w.rowstats, stream);
 }
 
@@ -352,6 +356,31 @@ int blocks_fused(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipStream
     const size_t es = ap::dtype_size(dt);
     int rc;
     const bool cls_tail = c.pool == AP_POOL_CLS && !m->full_last_block;
+    // Exact class rows (default for the class-token poolings; AP_VIT_OPT_EXACT_CLS): the features ARE the class row of the
+    // residual stream, and of the 16-bit stream's error in them almost all is the class row's OWN 2 x depth roundings (the
+    // patch rows' reach it only through attention, averaged over the tokens: 1.26e-3 -> 7.7e-4 against the CPU fp32 path on
+    // ViT-B/16, float16).  So the class rows are ALSO carried in f32 (cls32 [n, D]): after every proj / fc2 launch an n-row
+    // GEMM adds the unrounded branch to cls32 (same folded weights, f32 in place), and the stream's class row -- the A
+    // operand of the next GEMM -- becomes T(cls32) with its partial sums.  0.2 % more arithmetic, two small launches per GEMM.
+    const bool exact_cls = m->exact_cls && (c.pool == AP_POOL_CLS || c.pool == AP_POOL_CLS_MEAN);
+    const long cls_stride = (long)m->tokens;         // rows between two images' class rows
+    if (exact_cls) {
+        ScopedTimer t(m, AP_PROF_CLS_TAIL, stream);
+        // the class rows as the stream starts: the row the patch embedding (or CLIP's ln_pre) left in f32, or the shared prefix row
+        if (c.pre_norm) {
+            AP_HIP_CHECK(hipMemcpy2DAsync(w.cls32, (size_t)D * 4, w.tok, (size_t)cls_stride * D * 4, (size_t)D * 4, n,
+                                          hipMemcpyDeviceToDevice, stream));
+        } else if ((rc = ap::launch_cls_init(w.cls32, m->prefix_dev, 1, n, 1, D, stream)) != AP_OK) return rc;
+    }
+    // cls32 += branch of the class rows (A: their rows of the branch input, row stride lda), then stream row <- T(cls32)
+    auto exact_cls_update = [&](const void* A, int lda, const void* W, int ldw, int K, const float* bias) -> int {
+        ScopedTimer t(m, AP_PROF_CLS_TAIL, stream);
+        ap::GemmArgs g{};
+        g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = n; g.N = D; g.K = K; g.bias = bias; g.out = w.cls32; g.ldo = D;
+        int r = ap::launch_gemm_impl(dt, ap::EPI_BIAS_RESID, g, 128, 0, stream);
+        if (r != AP_OK) return r;
+        return ap::launch_cls_stream(dt, w.cls32, 1, 1, n, m->tokens, D, w.x16, w.partial, stream);
+    };
     auto finalize_stats = [&]() -> int {
         ScopedTimer t(m, AP_PROF_LAYERNORM, stream);
         return ap::launch_rowstats_finalize(w.partial, M, G, D, c.ln_eps, w.rowstats, stream);
@@ -374,7 +403,8 @@ int blocks_fused(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipStream
                                                     stream)) != AP_OK) return rc;
             }
             ScopedTimer t(m, AP_PROF_CLS_TAIL, stream);
-            if ((rc = ap::launch_stream_to_f32(dt, w.x16, (long)m->tokens * D, n, D, w.tok, stream)) != AP_OK) return rc;
+            if (exact_cls) AP_HIP_CHECK(hipMemcpyAsync(w.tok, w.cls32, (size_t)n * D * 4, hipMemcpyDeviceToDevice, stream));
+            else if ((rc = ap::launch_stream_to_f32(dt, w.x16, (long)m->tokens * D, n, D, w.tok, stream)) != AP_OK) return rc;
             if ((rc = ap::launch_add2_layernorm(dt, dt, w.tok, D, nullptr, 0, nullptr, nullptr, 0, nullptr, /*store=*/0,
                                                 n, D, bp.ln1_w, bp.ln1_b, c.ln_eps, w.xn, stream)) != AP_OK) return rc;
             char* q_cls = (char*)w.att;                                   // T [n, DA]
@@ -430,6 +460,7 @@ int blocks_fused(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipStream
             ScopedTimer t(m, AP_PROF_GEMM_PROJ, stream);
             if ((rc = ap::launch_gemm(dt, ap::EPI_RESID_STATS, g, stream)) != AP_OK) return rc;
         }
+        if (exact_cls && (rc = exact_cls_update(w.att, (int)cls_stride * DA, fb.proj_w, bp.proj->ld, DA, fb.proj_b)) != AP_OK) return rc;
         if ((rc = finalize_stats()) != AP_OK) return rc;
         {
             ap::GemmArgs g{};
@@ -448,10 +479,14 @@ int blocks_fused(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipStream
             ScopedTimer t(m, AP_PROF_GEMM_FC2, stream);
             if ((rc = ap::launch_gemm(dt, ap::EPI_RESID_STATS, g, stream)) != AP_OK) return rc;
         }
+        if (exact_cls && (rc = exact_cls_update(w.hid2, (int)cls_stride * H, fb.fc2_w, bp.fc2->ld, H, fb.fc2_b)) != AP_OK) return rc;
         if (i + 1 < c.depth && (rc = finalize_stats()) != AP_OK) return rc;
     }
     // every block ran on the stream (attentional pooling, or AP_VIT_OPT_FULL_LAST_BLOCK): widen it for the final LayerNorm
     if ((rc = ap::launch_stream_to_f32(dt, w.x16, D, M, D, w.tok, stream)) != AP_OK) return rc;
+    if (exact_cls)
+        AP_HIP_CHECK(hipMemcpy2DAsync(w.tok, (size_t)cls_stride * D * 4, w.cls32, (size_t)D * 4, (size_t)D * 4, n,
+                                      hipMemcpyDeviceToDevice, stream));
     st.pending = nullptr; st.pending_ls = nullptr; st.pending_stride = 0; st.tok_stride = (long)m->tokens * D;
     return AP_OK;
 }
@@ -598,6 +633,7 @@ int ap_vit_create(const ap_vit_config* cfg, ap_vit** out) {
     m->full_last_block = getenv("AP_VIT_FULL_LAST_BLOCK") != nullptr;     // defaults only; ap_vit_set_option changes them
     m->two_half_overlap = getenv("AP_VIT_OVERLAP") != nullptr;
     m->f32_stream = getenv("AP_VIT_F32_STREAM") != nullptr;
+    m->exact_cls = getenv("AP_VIT_NO_EXACT_CLS") == nullptr;
     int rc = AP_OK;
     auto add = [&](const std::string& name, int rows, int cols, bool matrix) {
         if (rc == AP_OK) rc = alloc_param(m, name, rows, cols, matrix);
@@ -874,6 +910,7 @@ int ap_vit_set_option(ap_vit* m, int option, int value) {
     if (option == AP_VIT_OPT_FULL_LAST_BLOCK) m->full_last_block = value != 0;
     else if (option == AP_VIT_OPT_TWO_HALF_OVERLAP) m->two_half_overlap = value != 0;
     else if (option == AP_VIT_OPT_F32_STREAM) m->f32_stream = value != 0;
+    else if (option == AP_VIT_OPT_EXACT_CLS) m->exact_cls = value != 0;
     else { ap::set_error("vit_set_option: unknown option %d", option); return AP_ERR_INVALID; }
     return AP_OK;
 }

@@ -773,6 +773,22 @@ def main():
         finally:
             ex.vit.set_option("f32_stream", False)
 
+    # ... and without the class rows' float32 side stream (option exact_cls off: the plain 16-bit stream of rounds 2-3)
+    plain16 = None
+    exact_cls_on = fused and not os.environ.get("AP_VIT_NO_EXACT_CLS") and arch.get("pool", "cls") in ("cls", "cls_mean")
+    if world == 1 and exact_cls_on:
+        ex.vit.set_option("exact_cls", False)
+        try:
+            step(0, feats[:B])
+            torch.cuda.synchronize(device)
+            t1 = time.perf_counter()
+            for i in range(K):
+                step(i, feats[i * B:(i + 1) * B])
+            torch.cuda.synchronize(device)
+            plain16 = {"patches_per_s": round(K * B / (time.perf_counter() - t1), 1)}
+        finally:
+            ex.vit.set_option("exact_cls", True)
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -877,7 +893,10 @@ def main():
                                    if cls_tail_possible else "every block for every token (attentional pooler reads all tokens)",
                            "value_with_full_last_block": None if full_value is None else round(full_value, 1)},
         "dataflow": ("fused_layernorm: residual stream in the compute type, LayerNorm folded into the qkv / fc1 GEMMs, residual "
-                     "add + row sums in the proj / fc2 epilogues" if fused else "f32 residual stream + add+LayerNorm launches"),
+                     "add + row sums in the proj / fc2 epilogues" + ("; the class rows' stream also carried in float32 (exact_cls)"
+                                                                     if exact_cls_on else "")
+                     if fused else "f32 residual stream + add+LayerNorm launches"),
+        "plain_16bit_stream_dataflow": plain16,
         "f32_stream_dataflow": f32s,
         "kernel_ms_per_step": kernel_ms, "hbm_kernels": hbm_kernels,
         "coords": {"cells": cells, "rows": int(n_slide), **coords_stats,
@@ -910,6 +929,12 @@ def main():
                 errs["f32_stream_" + short] = relf(ex.extract_batch(patches, batch_size=32))
             finally:
                 ex.vit.set_option("f32_stream", False)
+            if exact_cls_on:
+                ex.vit.set_option("exact_cls", False)
+                try:
+                    errs["plain_16bit_stream_" + short] = relf(ex.extract_batch(patches, batch_size=32))
+                finally:
+                    ex.vit.set_option("exact_cls", True)
         f32_ok = arch.get("pool") != "attn" and geo["tokens"] <= 288 and arch["dim"] // arch["heads"] == 64
         if short != "f32" and f32_ok:          # conch_v1 / vit_h_14: f16 / bf16 only (the f32 attention kernel: 288 tokens, 64 wide)
             ex32 = build_hip_vit_extractor(name=args.encoder, arch=args.encoder, device=device, dtype=torch.float32,
@@ -934,6 +959,9 @@ def main():
     modes[main_key] = {"patches_per_s": round(value, 1), "rel_err_vs_cpu_fp32": errs.get(main_key), "is_value": True}
     if f32s is not None:
         modes["f32_stream_" + short] = {"patches_per_s": f32s["patches_per_s"], "rel_err_vs_cpu_fp32": errs.get("f32_stream_" + short)}
+    if plain16 is not None:
+        modes["plain_16bit_stream_" + short] = {"patches_per_s": plain16["patches_per_s"],
+                                                "rel_err_vs_cpu_fp32": errs.get("plain_16bit_stream_" + short)}
     f32m = (line.get("rates") or {}).get("float32_mode")
     if f32m:
         modes["float32_mode"] = {"patches_per_s": f32m["patches_per_s"], "rel_err_vs_cpu_fp32": errs.get("float32_mode")}

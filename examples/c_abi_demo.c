@@ -59,7 +59,7 @@ int main(int argc, char** argv) {
     char name[128];
     int cus = 0;
     size_t hbm = 0;
-    if (ap_abi_version() != 18) { fprintf(stderr, "ABI %d, header is 18\n", ap_abi_version()); return 1; }
+    if (ap_abi_version() != 19) { fprintf(stderr, "ABI %d, header is 19\n", ap_abi_version()); return 1; }
     CHECK(ap_device_info(0, name, (int)sizeof(name), &cus, &hbm));
     fprintf(stderr, "device 0: %s, %d CUs, %.0f GB\n", name, cus, (double)hbm / 1e9);
 

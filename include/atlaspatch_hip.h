@@ -256,10 +256,18 @@ int ap_vit_finalize(ap_vit* m);
  *   AP_VIT_OPT_F32_STREAM         f16 / bf16 only: keep the residual stream in float32 and normalise it with standalone
  *                                 add+LayerNorm launches (round 1's dataflow; environment default AP_VIT_F32_STREAM).
  *                                 The default for f16 / bf16 keeps the stream in the compute type -- what the reference's
- *                                 own model.half() does -- with LayerNorm fused into the neighbouring GEMMs */
+ *                                 own model.half() does -- with LayerNorm fused into the neighbouring GEMMs
+ *   AP_VIT_OPT_EXACT_CLS          (ABI v19; default ON, environment AP_VIT_NO_EXACT_CLS turns the default off) f16 / bf16 with
+ *                                 the stream in the compute type and a class-token pooling (AP_POOL_CLS, AP_POOL_CLS_MEAN):
+ *                                 the class rows' residual stream is additionally carried in float32 -- after every proj /
+ *                                 fc2 launch an n-row GEMM adds the unrounded branch of the class rows to it, and the
+ *                                 stream's class row becomes its rounding.  The features are the class row of the stream and
+ *                                 nearly all of the 16-bit stream's error in them is that row's own 2 x depth roundings:
+ *                                 ViT-B/16 float16 1.26e-3 -> 7.7e-4 against the CPU fp32 path, for < 1 % of the step */
 #define AP_VIT_OPT_FULL_LAST_BLOCK 0
 #define AP_VIT_OPT_TWO_HALF_OVERLAP 1
 #define AP_VIT_OPT_F32_STREAM 2
+#define AP_VIT_OPT_EXACT_CLS 3
 int ap_vit_set_option(ap_vit* m, int option, int value);
 
 size_t ap_vit_workspace_bytes(const ap_vit* m, int n);

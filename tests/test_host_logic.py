@@ -257,7 +257,7 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/atlaspatch_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert _lib.load().ap_abi_version() == 18
+    assert _lib.load().ap_abi_version() == 19
 
 
 def test_product_has_no_cpu_fallback():

@@ -140,6 +140,10 @@ struct GemmArgs {
     int skew_ticks;          // gemm256 only: start-time spread across an XCD's workgroups (100 MHz ticks)
     long long* trace;        // gemm256 diagnostics: per (workgroup, tile) 8 x 100-MHz time stamps, or null
     int trace_tiles;         //   tiles recorded per workgroup
+    // EPI_RESID_STATS, exact class rows (vit.cpp): rows m = img * cls_tokens ALSO leave their unrounded branch value
+    // (accumulator, bias included) in cls_branch[img][n], f32 [M / cls_tokens, N]; cls_tokens = 0: off.  M < 2^24.
+    float* cls_branch;
+    int cls_tokens;
 };
 void set_gemm_trace(long long* buf, int tiles_per_wg);
 
@@ -216,6 +220,9 @@ int launch_fold_ls(int dtype, const float* w32, int rows, int cols, int ld, cons
 int launch_cls_stream(int dtype, const float* prefix, int prefix_rows, int img_rows, int n, int tokens, int dim, void* x, float* partial,
                       hipStream_t stream);
 int launch_cls_init(float* tok, const float* prefix, int prefix_rows, int n, int tokens, int dim, hipStream_t stream);
+// exact class rows: cls32[img] += branch[img] (f32 [n, dim] both), x[img * tokens] = T(cls32[img]) and that row's partial sums
+int launch_cls_exact_update(int dtype, float* cls32, const float* branch, int n, int tokens, int dim, void* x, float* partial,
+                            hipStream_t stream);
 // out[m][j] = T(silu(x[m][j]) * x[m][h + j]), x: T [rows, 2h] dense, out: T [rows, h] dense (timm SwiGLUPacked; f32 math)
 int launch_swiglu(int dtype, const void* x, int rows, int h, void* out, hipStream_t stream);
 // prefix[j][:] = tokens[j][:] (+ pos[j][:] when pos != nullptr), f32

@@ -309,6 +309,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
                 orow = (size_t)m + (size_t)(img + 1) * g.R;
                 srow = (const T*)g.pos16 + (size_t)(g.pos_row0 + p) * g.N;
             }
+            // exact class rows: the unrounded branch of row img * cls_tokens goes to cls_branch[img] as well
+            float* cbr = nullptr;
+            if constexpr (!kPatch) {
+                if (g.cls_tokens > 0 && live) {
+                    const int img = m / g.cls_tokens;
+                    if (m == img * g.cls_tokens) cbr = g.cls_branch + (size_t)img * g.N;
+                }
+            }
             float cs8[8], cq8[8];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
@@ -319,6 +327,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
                     f32x4 v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[nt][mt][g4 * 4 + e];
+                    if constexpr (!kPatch) { if (cbr) *(f32x4*)(cbr + n) = v; }
                     const u32x2 y = resid_add4<T>(pack4t<T>(v), *(const u32x2*)(srow + n));
                     if (live) *(u32x2*)px = y;
                     // chain: lower lane (columns 0-3 of the chunk) first, then the partner continues with columns 4-7

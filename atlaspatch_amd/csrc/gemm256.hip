@@ -466,6 +466,32 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) res_ld(j);
             __builtin_amdgcn_sched_barrier(0);
+            // exact class rows (vit.cpp): a row m = img * cls_tokens also leaves its unrounded accumulators (bias included) in
+            // cls_branch[img].  At most one lane in 197 (ViT-B) takes the branch; m / cls_tokens by a float estimate, corrected.
+            if constexpr (!kPatch) {
+                if (g.cls_tokens > 0) {
+                    const float inv_t = 1.0f / (float)g.cls_tokens;
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb) {
+                        const int m = m0 + mb * 32 + l31;
+                        int q = (int)((float)m * inv_t);
+                        const int r = m - q * g.cls_tokens;
+                        q = r < 0 ? q - 1 : (r >= g.cls_tokens ? q + 1 : q);
+                        if (m == q * g.cls_tokens && m < g.M) {
+                            float* cbr = g.cls_branch + (size_t)q * g.N + n0 + hi * 4;
+#pragma unroll
+                            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                                for (int g4 = 0; g4 < 4; ++g4) {
+                                    f32x4 v;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) v[e] = acc[nb][mb][g4 * 4 + e];
+                                    *(f32x4*)(cbr + nb * 32 + g4 * 8) = v;
+                                }
+                        }
+                    }
+                }
+            }
             // The accumulators (bias included) are rounded to T between the two groups of loads: the first group and the
             // bias land in the main loop's 64 fragment registers, the packing frees 64 more for the second group.
 #pragma unroll

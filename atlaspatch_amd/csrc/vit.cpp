@@ -135,6 +135,7 @@ struct Workspace {
     float* tok; void* xn; void* qkv; void* att; void* hid; void* hid2; void* delta; void* delta2;
     void* x16; float* rowstats; float* partial;      // fused-LayerNorm path: T stream [M, D], f32 [M, 2], f32 [M, D / 64, 2]
     float* cls32;                                    //   and the class rows' exact residual stream, f32 [n, D]
+    float* cls_branch;                               //   + their unrounded branch of the last proj / fc2 launch, f32 [n, D]
     size_t total;
 };
 
@@ -160,10 +161,12 @@ Workspace carve(const ap_vit* m, int n, char* base) {
     const size_t o_rs = has_fused ? take(M * 2 * sizeof(float)) : 0;
     const size_t o_part = has_fused ? take(M * (D / 64) * 2 * sizeof(float)) : 0;
     const size_t o_cls32 = has_fused ? take((size_t)n * D * sizeof(float)) : 0;
+    const size_t o_clsbr = has_fused ? take((size_t)n * D * sizeof(float)) : 0;
     w.x16 = has_fused ? base + o_x16 : nullptr;
     w.rowstats = has_fused ? (float*)(base + o_rs) : nullptr;
     w.partial = has_fused ? (float*)(base + o_part) : nullptr;
     w.cls32 = has_fused ? (float*)(base + o_cls32) : nullptr;
+    w.cls_branch = has_fused ? (float*)(base + o_clsbr) : nullptr;
     w.tok = (float*)(base + o_tok); w.xn = base + o_xn; w.qkv = base + o_qkv;
     w.att = base + o_att; w.hid = base + o_hid; w.delta = base + o_delta; w.delta2 = base + o_delta2; w.total = off;
     w.hid2 = m->cfg.mlp_type == AP_MLP_SWIGLU ? (char*)w.hid + M * (size_t)(2 * m->cfg.mlp_dim) * es : w.hid;
@@ -359,10 +362,11 @@ int blocks_fused(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipStream
     // Exact class rows (default for the class-token poolings; AP_VIT_OPT_EXACT_CLS): the features ARE the class row of the
     // residual stream, and of the 16-bit stream's error in them almost all is the class row's OWN 2 x depth roundings (the
     // patch rows' reach it only through attention, averaged over the tokens: 1.26e-3 -> 7.7e-4 against the CPU fp32 path on
-    // ViT-B/16, float16).  So the class rows are ALSO carried in f32 (cls32 [n, D]): after every proj / fc2 launch an n-row
-    // GEMM adds the unrounded branch to cls32 (same folded weights, f32 in place), and the stream's class row -- the A
-    // operand of the next GEMM -- becomes T(cls32) with its partial sums.  0.2 % more arithmetic, two small launches per GEMM.
-    const bool exact_cls = m->exact_cls && (c.pool == AP_POOL_CLS || c.pool == AP_POOL_CLS_MEAN);
+    // ViT-B/16, float16).  So the class rows are ALSO carried in f32 (cls32 [n, D]): every proj / fc2 launch leaves the class
+    // rows' unrounded branch (accumulator + bias, f32) in cls_branch beside its normal output (GemmArgs::cls_branch), a tiny
+    // kernel adds it to cls32, and the stream's class row -- the A operand of the next GEMM -- becomes T(cls32) with its
+    // partial sums.  One 64-thread-per-group launch per GEMM; M >= 2^24 rows (the epilogue's row / tokens estimate) turns it off.
+    const bool exact_cls = m->exact_cls && (c.pool == AP_POOL_CLS || c.pool == AP_POOL_CLS_MEAN) && M < (1 << 24);
     const long cls_stride = (long)m->tokens;         // rows between two images' class rows
     if (exact_cls) {
         ScopedTimer t(m, AP_PROF_CLS_TAIL, stream);
@@ -372,14 +376,10 @@ int blocks_fused(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipStream
                                           hipMemcpyDeviceToDevice, stream));
         } else if ((rc = ap::launch_cls_init(w.cls32, m->prefix_dev, 1, n, 1, D, stream)) != AP_OK) return rc;
     }
-    // cls32 += branch of the class rows (A: their rows of the branch input, row stride lda), then stream row <- T(cls32)
-    auto exact_cls_update = [&](const void* A, int lda, const void* W, int ldw, int K, const float* bias) -> int {
-        ScopedTimer t(m, AP_PROF_CLS_TAIL, stream);
-        ap::GemmArgs g{};
-        g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = n; g.N = D; g.K = K; g.bias = bias; g.out = w.cls32; g.ldo = D;
-        int r = ap::launch_gemm_impl(dt, ap::EPI_BIAS_RESID, g, 128, 0, stream);
-        if (r != AP_OK) return r;
-        return ap::launch_cls_stream(dt, w.cls32, 1, 1, n, m->tokens, D, w.x16, w.partial, stream);
+    // cls32 += the branch the launch before left in cls_branch, then stream row <- T(cls32)
+    auto exact_cls_update = [&]() -> int {
+        ScopedTimer t(m, AP_PROF_LAYERNORM, stream);
+        return ap::launch_cls_exact_update(dt, w.cls32, w.cls_branch, n, m->tokens, D, w.x16, w.partial, stream);
     };
     auto finalize_stats = [&]() -> int {
         ScopedTimer t(m, AP_PROF_LAYERNORM, stream);
@@ -457,10 +457,11 @@ int blocks_fused(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipStream
             ap::GemmArgs g{};
             g.A = w.att; g.lda = DA; g.W = fb.proj_w; g.ldw = bp.proj->ld;
             g.M = M; g.N = D; g.K = DA; g.bias = fb.proj_b; g.out = w.x16; g.ldo = D; g.partial = w.partial;
+            if (exact_cls) { g.cls_branch = w.cls_branch; g.cls_tokens = m->tokens; }
             ScopedTimer t(m, AP_PROF_GEMM_PROJ, stream);
             if ((rc = ap::launch_gemm(dt, ap::EPI_RESID_STATS, g, stream)) != AP_OK) return rc;
         }
-        if (exact_cls && (rc = exact_cls_update(w.att, (int)cls_stride * DA, fb.proj_w, bp.proj->ld, DA, fb.proj_b)) != AP_OK) return rc;
+        if (exact_cls && (rc = exact_cls_update()) != AP_OK) return rc;
         if ((rc = finalize_stats()) != AP_OK) return rc;
         {
             ap::GemmArgs g{};
@@ -476,10 +477,11 @@ int blocks_fused(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipStream
             ap::GemmArgs g{};
             g.A = w.hid2; g.lda = H; g.W = fb.fc2_w; g.ldw = bp.fc2->ld;
             g.M = M; g.N = D; g.K = H; g.bias = fb.fc2_b; g.out = w.x16; g.ldo = D; g.partial = w.partial;
+            if (exact_cls) { g.cls_branch = w.cls_branch; g.cls_tokens = m->tokens; }
             ScopedTimer t(m, AP_PROF_GEMM_FC2, stream);
             if ((rc = ap::launch_gemm(dt, ap::EPI_RESID_STATS, g, stream)) != AP_OK) return rc;
         }
-        if (exact_cls && (rc = exact_cls_update(w.hid2, (int)cls_stride * H, fb.fc2_w, bp.fc2->ld, H, fb.fc2_b)) != AP_OK) return rc;
+        if (exact_cls && (rc = exact_cls_update()) != AP_OK) return rc;
         if (i + 1 < c.depth && (rc = finalize_stats()) != AP_OK) return rc;
     }
     // every block ran on the stream (attentional pooling, or AP_VIT_OPT_FULL_LAST_BLOCK): widen it for the final LayerNorm

@@ -346,9 +346,10 @@ __global__ __launch_bounds__(64) void cls_stream_kernel(const float* __restrict_
 // exact class rows (vit.cpp): cls32[img] += branch[img] (f32, the unrounded branch a RESID_STATS launch left for row img * tokens),
 // then the stream's class row becomes T(cls32[img]) with its partial sums -- cls_stream_kernel's order (one wave per (image, group))
 template <typename T>
-__global__ __launch_bounds__(64) void cls_exact_update_kernel(float* __restrict__ cls32, const float* __restrict__ branch, int tokens,
-                                                              int dim, T* __restrict__ x, float* __restrict__ partial) {
-    const int img = blockIdx.x, grp = blockIdx.y, col = grp * 64 + threadIdx.x;
+__global__ __launch_bounds__(256) void cls_exact_update_kernel(float* __restrict__ cls32, const float* __restrict__ branch, int tokens,
+                                                               int dim, T* __restrict__ x, float* __restrict__ partial) {
+    const int img = blockIdx.x, grp = blockIdx.y * 4 + (threadIdx.x >> 6), col = grp * 64 + (threadIdx.x & 63);
+    if (col >= dim) return;                                       // whole waves: dim % 64 == 0
     const size_t row = (size_t)img * tokens, at = (size_t)img * dim + col;
     const float c = cls32[at] + branch[at];
     cls32[at] = c;
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(64) void cls_exact_update_kernel(float* __restrict_
     x[row * dim + col] = v;
     const float f = (float)v;
     const float s = wave_sum(f), q = wave_sum(f * f);
-    if (threadIdx.x == 0) {
+    if ((threadIdx.x & 63) == 0) {
         partial[(row * (dim >> 6) + grp) * 2] = s;
         partial[(row * (dim >> 6) + grp) * 2 + 1] = q;
     }
@@ -750,7 +751,7 @@ int launch_cls_exact_update(int dtype, float* cls32, const float* branch, int n,
                             hipStream_t stream) {
     AP_REQUIRE(dim % 64 == 0, "cls_exact_update: dim %d must be a multiple of 64", dim);
     if (n <= 0) return AP_OK;
-    dim3 grid(n, dim / 64), block(64);
+    dim3 grid(n, (dim + 255) / 256), block(256);
     if (dtype == AP_F16) cls_exact_update_kernel<f16><<<grid, block, 0, stream>>>(cls32, branch, tokens, dim, (f16*)x, partial);
     else if (dtype == AP_BF16) cls_exact_update_kernel<bf16><<<grid, block, 0, stream>>>(cls32, branch, tokens, dim, (bf16*)x, partial);
     else { set_error("cls_exact_update: dtype %d (f16 / bf16 only)", dtype); return AP_ERR_INVALID; }

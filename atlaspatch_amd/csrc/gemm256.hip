@@ -408,8 +408,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
         stamp(ti, 1);
         // lane-derived epilogue constants are recomputed per tile from a FRESH lane id (v_mbcnt: no register has to stay
         // live -- or be spilled, as an opaque copy of `lane` was in the BIAS_GELU instantiation -- across the K loop)
-        int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-        asm volatile("" : "+v"(lane_e));
+        // (the v_mbcnt pair itself is volatile asm: through the builtins hipcc hoisted it in front of the tile loop in the
+        // BIAS_QGELU instantiation and spilled THAT register)
+        int lane_e;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
         const int hi = lane_e >> 5, l31 = lane_e & 31;
         const int id = tw.first + ti * tw.stride;
         int tr, tc;

@@ -194,6 +194,10 @@ int launch_stream_init(int dtype, const float* tok, int rows, int dim, float eps
 // partial f32 [rows, groups, 2] (sum, sum of squares per 64-column group) -> rowstats f32 [rows, 2]
 int launch_rowstats_finalize(const float* partial, int rows, int groups, int dim, float eps, float* rowstats,
                              hipStream_t stream);
+// ... with the exact class rows folded in (vit.cpp): n extra workgroups do cls32[img] += branch[img], x[img * tokens] = T(cls32[img])
+// and write that row's statistics themselves; cls32 = nullptr: the plain form
+int launch_rowstats_finalize_cls(const float* partial, int rows, int groups, int dim, float eps, float* rowstats, int dtype,
+                                 float* cls32, const float* branch, void* x, int n, int tokens, hipStream_t stream);
 // x T rows (row stride `stride` elements) -> dst f32 [rows, dim] dense
 int launch_stream_to_f32(int dtype, const void* x, long stride, int rows, int dim, float* dst, hipStream_t stream);
 // Rotary position embedding of DINOv3 (transformers DINOv3ViT apply_rotary_pos_emb): in place on the q (which & 1) and k

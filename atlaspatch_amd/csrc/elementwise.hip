@@ -299,12 +299,50 @@ __global__ __launch_bounds__(256) void stream_init_kernel(const float* __restric
 // Eight lanes per row, one 16-byte load (two groups) per lane: a wave reads 8 rows x (groups * 8) contiguous bytes
 // (a thread per row with a 96-byte stride measured 36 us per call at 403 456 rows).  The lane sums are combined in a
 // fixed butterfly order (deterministic), the mean / variance arithmetic is done in double.
+// exact class rows (vit.cpp), folded into the same launch: workgroups past the row blocks each take ONE image's class row --
+// cls32[img] += branch[img] (f32), the stream row img * tokens becomes its rounding to the compute type, and the row's statistics
+// are written directly (fixed order: a thread's columns ascending, wave butterfly, waves 0..3) -- and the row blocks leave the
+// rows img * tokens alone.  cls.tokens = 0: plain finalisation.
+struct ClsExact { float* cls32; const float* branch; void* x; int tokens; int n; int dtype; };
+
 __global__ __launch_bounds__(256) void rowstats_finalize_kernel(const float* __restrict__ partial, int rows, int groups, int dim,
-                                                                float eps, float* __restrict__ rowstats) {
+                                                                float eps, float* __restrict__ rowstats, int row_blocks, ClsExact cls) {
+    if ((int)blockIdx.x >= row_blocks) {
+        __shared__ float red[8];
+        const int img = blockIdx.x - row_blocks;
+        const size_t row = (size_t)img * cls.tokens;
+        float s = 0.f, q = 0.f;
+        for (int col = threadIdx.x; col < dim; col += 256) {
+            const size_t at = (size_t)img * dim + col;
+            const float c = cls.cls32[at] + cls.branch[at];
+            cls.cls32[at] = c;
+            float f;
+            if (cls.dtype == AP_F16) { const f16 v = (f16)c; ((f16*)cls.x)[row * dim + col] = v; f = (float)v; }
+            else { const bf16 v = (bf16)c; ((bf16*)cls.x)[row * dim + col] = v; f = (float)v; }
+            s += f;
+            q += f * f;
+        }
+        s = wave_sum(s);
+        q = wave_sum(q);
+        if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = s; red[4 + (threadIdx.x >> 6)] = q; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double ss = ((double)red[0] + red[1]) + ((double)red[2] + red[3]);
+            const double qq = ((double)red[4] + red[5]) + ((double)red[6] + red[7]);
+            const double mean = ss / dim;
+            double var = qq / dim - mean * mean;
+            var = var > 0.0 ? var : 0.0;
+            const double rstd = 1.0 / sqrt(var + (double)eps);
+            rowstats[2 * row] = (float)rstd;
+            rowstats[2 * row + 1] = (float)(-mean * rstd);
+        }
+        return;
+    }
     const int l8 = threadIdx.x & 7;
     int row = blockIdx.x * 32 + (threadIdx.x >> 3);
-    const bool live = row < rows;
+    bool live = row < rows;
     if (!live) row = rows - 1;                                   // keep all lanes in the DPP reductions
+    if (cls.tokens > 0 && row % cls.tokens == 0) live = false;   // a class row: the workgroup of its image writes its statistics
     const f32x4* p = (const f32x4*)(partial + (size_t)row * groups * 2);
     float s = 0.f, q = 0.f;
     for (int g2 = l8; g2 * 2 < groups; g2 += 8) {                // groups is even (dim % 128 == 0)
@@ -761,9 +799,18 @@ int launch_cls_exact_update(int dtype, float* cls32, const float* branch, int n,
 
 int launch_rowstats_finalize(const float* partial, int rows, int groups, int dim, float eps, float* rowstats,
                              hipStream_t stream) {
+    return launch_rowstats_finalize_cls(partial, rows, groups, dim, eps, rowstats, AP_F16, nullptr, nullptr, nullptr, 0, 0, stream);
+}
+
+int launch_rowstats_finalize_cls(const float* partial, int rows, int groups, int dim, float eps, float* rowstats, int dtype,
+                                 float* cls32, const float* branch, void* x, int n, int tokens, hipStream_t stream) {
     if (rows <= 0) return AP_OK;
     AP_REQUIRE(groups > 0 && groups % 2 == 0, "rowstats_finalize: groups %d must be even", groups);
-    rowstats_finalize_kernel<<<(rows + 31) / 32, 256, 0, stream>>>(partial, rows, groups, dim, eps, rowstats);
+    AP_REQUIRE(!cls32 || ((dtype == AP_F16 || dtype == AP_BF16) && branch && x && tokens > 0 && n * (long)tokens == rows),
+               "rowstats_finalize: exact class rows need f16 / bf16, the branch buffer, the stream and rows == n * tokens");
+    const int row_blocks = (rows + 31) / 32;
+    const ClsExact cls{cls32, branch, x, cls32 ? tokens : 0, cls32 ? n : 0, dtype};
+    rowstats_finalize_kernel<<<row_blocks + cls.n, 256, 0, stream>>>(partial, rows, groups, dim, eps, rowstats, row_blocks, cls);
     AP_HIP_CHECK(hipGetLastError());
     return AP_OK;
 }

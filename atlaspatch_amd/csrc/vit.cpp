@@ -381,9 +381,12 @@ int blocks_fused(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipStream
         ScopedTimer t(m, AP_PROF_LAYERNORM, stream);
         return ap::launch_cls_exact_update(dt, w.cls32, w.cls_branch, n, m->tokens, D, w.x16, w.partial, stream);
     };
+    // statistics of the new rows; with the exact class rows the same launch folds the branch into cls32 and re-rounds the
+    // stream's class rows (launch_rowstats_finalize_cls)
     auto finalize_stats = [&]() -> int {
         ScopedTimer t(m, AP_PROF_LAYERNORM, stream);
-        return ap::launch_rowstats_finalize(w.partial, M, G, D, c.ln_eps, w.rowstats, stream);
+        return ap::launch_rowstats_finalize_cls(w.partial, M, G, D, c.ln_eps, w.rowstats, dt, exact_cls ? w.cls32 : nullptr,
+                                                w.cls_branch, w.x16, n, m->tokens, stream);
     };
     for (int i = 0; i < c.depth; ++i) {
         const ap::BlockParams& bp = m->blocks[i];
@@ -461,7 +464,6 @@ int blocks_fused(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipStream
             ScopedTimer t(m, AP_PROF_GEMM_PROJ, stream);
             if ((rc = ap::launch_gemm(dt, ap::EPI_RESID_STATS, g, stream)) != AP_OK) return rc;
         }
-        if (exact_cls && (rc = exact_cls_update()) != AP_OK) return rc;
         if ((rc = finalize_stats()) != AP_OK) return rc;
         {
             ap::GemmArgs g{};
@@ -481,8 +483,8 @@ int blocks_fused(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipStream
             ScopedTimer t(m, AP_PROF_GEMM_FC2, stream);
             if ((rc = ap::launch_gemm(dt, ap::EPI_RESID_STATS, g, stream)) != AP_OK) return rc;
         }
-        if (exact_cls && (rc = exact_cls_update()) != AP_OK) return rc;
-        if (i + 1 < c.depth && (rc = finalize_stats()) != AP_OK) return rc;
+        if (i + 1 < c.depth) { if ((rc = finalize_stats()) != AP_OK) return rc; }
+        else if (exact_cls && (rc = exact_cls_update()) != AP_OK) return rc;      // last block, every token: no statistics follow
     }
     // every block ran on the stream (attentional pooling, or AP_VIT_OPT_FULL_LAST_BLOCK): widen it for the final LayerNorm
     if ((rc = ap::launch_stream_to_f32(dt, w.x16, D, M, D, w.tok, stream)) != AP_OK) return rc;

@@ -139,3 +139,24 @@ def test_general_area_is_box_integration_within_float32_rounding(shape, dsize):
     got = R.resize(a, dsize, R.INTER_AREA).astype(np.float64)
     want = _area_f64(a, *dsize)
     assert np.abs(got - want).max() <= 0.5 + 2e-3
+
+
+@pytest.mark.parametrize("interp,mode", [(R.INTER_LINEAR, "bilinear"), (R.INTER_CUBIC, "bicubic")])
+@pytest.mark.parametrize("src_hw,dst_hw", [((256, 256), (224, 224)), ((97, 131), (224, 302)), ((300, 256), (131, 97)),
+                                           ((64, 48), (200, 333)), ((512, 384), (300, 300))])
+def test_against_torch_interpolate_an_independent_implementation_of_the_same_convention(interp, mode, src_hw, dst_hw):
+    """torch.nn.functional.interpolate(align_corners=False, antialias=False) samples at the same half-pixel-centre positions
+    as cv2.resize and its bicubic uses the same A = -0.75 kernel -- independent code (ATen), float arithmetic, borders by index
+    clamping.  The restatement must agree with it up to the 8-bit paths' own rounding: OpenCV quantises the coefficients to
+    11 bits (2^-11 per tap) and rounds twice (fixed-point intermediate, final cast); every pixel within 1 LSB (2 for bicubic,
+    where four taps per axis accumulate the coefficient quantisation), and the mean absolute deviation near the rounding's
+    own 0.25 LSB.  (Exact-halving and identity shapes are routed to other code paths by cv2.resize and are tested above.)"""
+    import torch
+    a = _rng_img(*src_hw, seed=5)
+    got = R.resize(a, (dst_hw[1], dst_hw[0]), interp).astype(np.float64)
+    x = torch.from_numpy(a).permute(2, 0, 1)[None].double()
+    ref = torch.nn.functional.interpolate(x, size=dst_hw, mode=mode, align_corners=False, antialias=False)[0].permute(1, 2, 0)
+    ref = ref.clamp(0, 255).numpy()
+    d = np.abs(got - ref)
+    assert d.max() <= (1.0 if interp == R.INTER_LINEAR else 2.0) + 1e-6, d.max()
+    assert d.mean() <= 0.32, d.mean()

@@ -182,10 +182,11 @@ __global__ __launch_bounds__(256) void layernorm16_kernel(float* __restrict__ x,
     }
 }
 
-// Generic kernel: one wave per row, whole row held in registers (dim <= 64 * 4 * kMaxVec).
-constexpr int kMaxVec = 8;
+// Generic kernel: one wave per row, whole row held in registers (dim <= 64 * 4 * MAXV: kMaxVec = 8 for rows up to 2048 wide,
+// kMaxVecWide = 16 up to 4096 -- DINOv3 ViT-7B; the same per-lane order, so a dim served by both would give the same bits).
+constexpr int kMaxVec = 8, kMaxVecWide = 16;
 
-template <typename TD, typename TO>
+template <typename TD, typename TO, int MAXV>
 __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, long stride,
                                                         LnAdds add, int rows, int dim,
                                                         const float* __restrict__ gamma,
@@ -196,10 +197,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, l
     if (row >= rows) return;
     const int nvec = dim >> 2;
     f32x4* src = (f32x4*)(x + (size_t)row * stride);
-    f32x4 v[kMaxVec];
+    f32x4 v[MAXV];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < kMaxVec; ++i) {
+    for (int i = 0; i < MAXV; ++i) {
         const int idx = lane + i * 64;
         if (idx < nvec) {
             v[i] = src[idx];
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, l
     const float mean = wave_sum(s) / (float)dim;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < kMaxVec; ++i) {
+    for (int i = 0; i < MAXV; ++i) {
         const int idx = lane + i * 64;
         if (idx < nvec) {
 #pragma unroll
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, l
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)dim + eps);
     TO* dst = out + (size_t)row * dim;
 #pragma unroll
-    for (int i = 0; i < kMaxVec; ++i) {
+    for (int i = 0; i < MAXV; ++i) {
         const int idx = lane + i * 64;
         if (idx < nvec) {
             const f32x4 ga = ((const f32x4*)gamma)[idx];
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, l
 // ---- fused-LayerNorm path (16-bit residual stream; vit.cpp::run_blocks_fused) -------------------------------
 // stream_init: the f32 token matrix the patch-embed GEMM wrote -> the T stream + the row statistics of the ROUNDED
 // row (what the first fused GEMM multiplies): two-pass mean / variance like the LayerNorm kernels.  One wave per row.
-template <typename T>
+template <typename T, int MAXV>
 __global__ __launch_bounds__(256) void stream_init_kernel(const float* __restrict__ tok, int rows, int dim, float eps,
                                                           T* __restrict__ x, float* __restrict__ rowstats) {
     const int lane = threadIdx.x & 63;
@@ -261,10 +262,10 @@ __global__ __launch_bounds__(256) void stream_init_kernel(const float* __restric
     const int nvec = dim >> 2;
     const f32x4* src = (const f32x4*)(tok + (size_t)row * dim);
     T* dst = x + (size_t)row * dim;
-    f32x4 v[kMaxVec];
+    f32x4 v[MAXV];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < kMaxVec; ++i) {
+    for (int i = 0; i < MAXV; ++i) {
         const int idx = lane + i * 64;
         if (idx < nvec) {
             f32x4 a = src[idx];
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(256) void stream_init_kernel(const float* __restric
     const float mean = wave_sum(s) / (float)dim;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < kMaxVec; ++i) {
+    for (int i = 0; i < MAXV; ++i) {
         const int idx = lane + i * 64;
         if (idx < nvec) {
 #pragma unroll
@@ -547,7 +548,8 @@ int launch_ln_typed(float* x, long stride, const LnAdds& add, int rows, int dim,
             }
         }
         dim3 grid((rows + 3) / 4), block(256);
-        layernorm_kernel<TD, TO><<<grid, block, 0, stream>>>(x, stride, add, rows, dim, gamma, beta, eps, o);
+        if (dim <= 64 * 4 * kMaxVec) layernorm_kernel<TD, TO, kMaxVec><<<grid, block, 0, stream>>>(x, stride, add, rows, dim, gamma, beta, eps, o);
+        else layernorm_kernel<TD, TO, kMaxVecWide><<<grid, block, 0, stream>>>(x, stride, add, rows, dim, gamma, beta, eps, o);
     }
     AP_HIP_CHECK(hipGetLastError());
     return AP_OK;
@@ -726,7 +728,7 @@ int launch_add2_layernorm(int delta_dtype, int out_dtype, float* x, long stride,
                           const float* ls0, const void* delta1, long dstride1, const float* ls1, int store,
                           int rows, int dim, const float* gamma, const float* beta, float eps, void* out,
                           hipStream_t stream) {
-    AP_REQUIRE(dim % 4 == 0 && dim <= 64 * 4 * kMaxVec, "layernorm: unsupported dim %d", dim);
+    AP_REQUIRE(dim % 4 == 0 && dim <= 64 * 4 * kMaxVecWide, "layernorm: unsupported dim %d", dim);
     AP_REQUIRE(stride % 4 == 0 && (!delta0 || dstride0 % 4 == 0) && (!delta1 || dstride1 % 4 == 0),
                "layernorm: row strides must be multiples of 4");
     if (rows <= 0) return AP_OK;
@@ -763,11 +765,14 @@ int launch_layernorm_f32out(const float* x, long stride, int rows, int dim, cons
 
 int launch_stream_init(int dtype, const float* tok, int rows, int dim, float eps, void* x, float* rowstats,
                        hipStream_t stream) {
-    AP_REQUIRE(dim % 4 == 0 && dim <= 64 * 4 * kMaxVec, "stream_init: unsupported dim %d", dim);
+    AP_REQUIRE(dim % 4 == 0 && dim <= 64 * 4 * kMaxVecWide, "stream_init: unsupported dim %d", dim);
     if (rows <= 0) return AP_OK;
     dim3 grid((rows + 3) / 4), block(256);
-    if (dtype == AP_F16) stream_init_kernel<f16><<<grid, block, 0, stream>>>(tok, rows, dim, eps, (f16*)x, rowstats);
-    else if (dtype == AP_BF16) stream_init_kernel<bf16><<<grid, block, 0, stream>>>(tok, rows, dim, eps, (bf16*)x, rowstats);
+    const bool wide = dim > 64 * 4 * kMaxVec;
+    if (dtype == AP_F16 && !wide) stream_init_kernel<f16, kMaxVec><<<grid, block, 0, stream>>>(tok, rows, dim, eps, (f16*)x, rowstats);
+    else if (dtype == AP_F16) stream_init_kernel<f16, kMaxVecWide><<<grid, block, 0, stream>>>(tok, rows, dim, eps, (f16*)x, rowstats);
+    else if (dtype == AP_BF16 && !wide) stream_init_kernel<bf16, kMaxVec><<<grid, block, 0, stream>>>(tok, rows, dim, eps, (bf16*)x, rowstats);
+    else if (dtype == AP_BF16) stream_init_kernel<bf16, kMaxVecWide><<<grid, block, 0, stream>>>(tok, rows, dim, eps, (bf16*)x, rowstats);
     else { set_error("stream_init: dtype %d (f16 / bf16 only)", dtype); return AP_ERR_INVALID; }
     AP_HIP_CHECK(hipGetLastError());
     return AP_OK;

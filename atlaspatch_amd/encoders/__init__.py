@@ -20,7 +20,7 @@ def build_default_registry(*, device="cuda", num_workers: int = 0,
     """Built-in extractors of this build: the ViT family (vit_b_16 / b_32 / l_16 / l_32 / h_14, uni_v1, uni_v2, conch_v1, and the
     transformers-backed dinov2_small / base / large / giant, phikon_v1 / v2, midnight; the timm-hub ViTs h_optimus_0 / 1,
     prov_gigapath, lunit_vit_small_patch16 / 8_dino, pathorchestra; the CLIP towers clip_vit_b_32 / b_16 / l_14 / l_14_336, plip,
-    quilt_b_32 / b_16, biomedclip; virchow_v1 / v2, h0_mini; six dinov3_* names with the rotary embedding) on the
+    quilt_b_32 / b_16, biomedclip; virchow_v1 / v2, h0_mini; eight dinov3_* names with the rotary embedding) on the
     native HIP path, registered in the reference's order (models/patch/__init__.py:58-80).  Builders are
     lazy (nothing touches the GPU until ``create``), so this is safe on a CPU-only host, exactly
     like the reference's registry which the CLI instantiates at import (cli.py:50)."""

@@ -74,6 +74,7 @@ TRANSFORM_RESIZE = {
     # dinov3.py:52 AutoImageProcessor of facebook/dinov3-*: 224 x 224, bilinear, no crop (public model cards, unverifiable offline)
     "dinov3_vits16": (224, "bilinear"), "dinov3_vits16_plus": (224, "bilinear"), "dinov3_vitb16": (224, "bilinear"),
     "dinov3_vitl16": (224, "bilinear"), "dinov3_vitl16_sat": (224, "bilinear"), "dinov3_vith16_plus": (224, "bilinear"),
+    "dinov3_vit7b16": (224, "bilinear"), "dinov3_vit7b16_sat": (224, "bilinear"),
 }
 
 # Normalize() constants per registered name (default: ImageNet)
@@ -194,8 +195,9 @@ ARCHS = {
     "biomedclip": dict(image_size=224, patch_size=16, dim=768, depth=12, heads=12, mlp_dim=3072, ln_eps=1e-6, layer_scale=False,
                        proj_dim=512),
     # models/patch/dinov3.py:12-21: transformers DINOv3ViTModel, pooler_output.  Class + 4 register tokens, no position embedding,
-    # rotary embedding (theta 100) on q / k of the patch tokens, LayerScale, LayerNorm 1e-5; "plus" = gated MLP.  (The two
-    # dinov3_vit7b16 names: dim 4096 exceeds the LayerNorm kernels' 2048 -- not registered.)
+    # rotary embedding (theta 100) on q / k of the patch tokens, LayerScale, LayerNorm 1e-5; "plus" = gated MLP.  The two
+    # dinov3_vit7b16 names (dinov3.py:20-21): dim 4096, 40 blocks, 32 heads of 128, gated MLP 8192 (6.7 G parameters, 13.4 GB in
+    # float16; public hub config, unverifiable offline) -- the rows wider than 2048 take the LayerNorm kernels' 16-vector form.
     "dinov3_vits16": dict(image_size=224, patch_size=16, dim=384, depth=12, heads=6, mlp_dim=1536, ln_eps=1e-5, layer_scale=True,
                           reg_tokens=4, no_embed_class=True, rope=True),
     "dinov3_vits16_plus": dict(image_size=224, patch_size=16, dim=384, depth=12, heads=6, mlp_dim=1536, ln_eps=1e-5, layer_scale=True,
@@ -207,6 +209,10 @@ ARCHS = {
     "dinov3_vitl16_sat": dict(image_size=224, patch_size=16, dim=1024, depth=24, heads=16, mlp_dim=4096, ln_eps=1e-5, layer_scale=True,
                               reg_tokens=4, no_embed_class=True, rope=True),
     "dinov3_vith16_plus": dict(image_size=224, patch_size=16, dim=1280, depth=32, heads=20, mlp_dim=5120, ln_eps=1e-5, layer_scale=True,
+                               reg_tokens=4, no_embed_class=True, rope=True, mlp="swiglu"),
+    "dinov3_vit7b16": dict(image_size=224, patch_size=16, dim=4096, depth=40, heads=32, mlp_dim=8192, ln_eps=1e-5, layer_scale=True,
+                           reg_tokens=4, no_embed_class=True, rope=True, mlp="swiglu"),
+    "dinov3_vit7b16_sat": dict(image_size=224, patch_size=16, dim=4096, depth=40, heads=32, mlp_dim=8192, ln_eps=1e-5, layer_scale=True,
                                reg_tokens=4, no_embed_class=True, rope=True, mlp="swiglu"),
 }
 
@@ -872,11 +878,11 @@ def register_clip(registry, *, device, dtype=torch.float32, num_workers: int = 0
 
 
 def register_dinov3(registry, *, device, dtype=torch.float32, num_workers: int = 0) -> None:
-    """dinov3_vits16 / vits16_plus / vitb16 / vitl16 / vitl16_sat / vith16_plus (models/patch/dinov3.py:12-19): transformers'
-    DINOv3ViTModel, ``pooler_output``.  Rotary position embedding applied in place on q / k after the qkv GEMM (``ap::launch_rope``);
+    """dinov3_vits16 / vits16_plus / vitb16 / vitl16 / vitl16_sat / vith16_plus / vit7b16 / vit7b16_sat (models/patch/dinov3.py:12-21):
+    transformers' DINOv3ViTModel, ``pooler_output``.  Rotary position embedding applied in place on q / k after the qkv GEMM (``ap::launch_rope``);
     HF state dicts in ATLASPATCH_WEIGHTS_DIR."""
     for name, cap in (("dinov3_vits16", 4096), ("dinov3_vits16_plus", 4096), ("dinov3_vitb16", 2048), ("dinov3_vitl16", 2048),
-                      ("dinov3_vitl16_sat", 2048), ("dinov3_vith16_plus", 1024)):
+                      ("dinov3_vitl16_sat", 2048), ("dinov3_vith16_plus", 1024), ("dinov3_vit7b16", 512), ("dinov3_vit7b16_sat", 512)):
         mean, std = TRANSFORM_NORM.get(name, (IMAGENET_MEAN, IMAGENET_STD))
         registry.register(name, lambda n=name, c=cap, mu=mean, sd=std: build_hip_vit_extractor(
             name=n, arch=n, device=device, dtype=dtype, random_init_seed=_env_seed(), resize=TRANSFORM_RESIZE[n],

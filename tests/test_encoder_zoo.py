@@ -248,7 +248,8 @@ def test_registry_has_the_reference_names_of_the_three_encoder_files():
               "lunit_vit_small_patch8_dino", "pathorchestra",
               "clip_vit_b_32", "clip_vit_b_16", "clip_vit_l_14", "clip_vit_l_14_336", "plip", "quilt_b_32", "quilt_b_16",      # clip.py:16-19
               "biomedclip", "virchow_v1", "virchow_v2", "h0_mini",
-              "dinov3_vits16", "dinov3_vits16_plus", "dinov3_vitb16", "dinov3_vitl16", "dinov3_vitl16_sat", "dinov3_vith16_plus"):
+              "dinov3_vits16", "dinov3_vits16_plus", "dinov3_vitb16", "dinov3_vitl16", "dinov3_vitl16_sat", "dinov3_vith16_plus",
+              "dinov3_vit7b16", "dinov3_vit7b16_sat"):
         assert n in names and n in ARCHS and n in TRANSFORM_RESIZE
     g = ARCHS["dinov2_giant"]
     assert (g["dim"], g["depth"], g["heads"], g["mlp_dim"]) == (1536, 40, 24, (int(1536 * 4 * 2 / 3) + 7) // 8 * 8)
@@ -335,6 +336,7 @@ MEASURED.update({                     # the transformers-backed encoders (dinov2
     ("dinov3_vitl16 L24", "float16"): (8.77e-4, 1.38e-2, 9.24e-3),
     ("dinov3_vitl16 L24, f32_stream", "float16"): (9.62e-4, 1.380e-2, 1.103e-2),
     ("dinov3_vith16_plus L32", "float16"): (2.18e-3, 3.23e-2, 2.09e-2),
+    ("dinov3_vit7b16 width L3", "float16"): (1.469e-3, 1.766e-2, 1.343e-2),        # real width (4096 / 8192), 3 of the 40 blocks
     ("dinov3_vith16_plus L32, f32_stream", "float16"): (2.457e-3, 2.948e-2, 2.717e-2),
 })
 HEADROOM = (1.2, 1.5, 1.25)
@@ -420,6 +422,32 @@ def test_encoder_at_real_size_vs_fp32_oracle(name, dtype, n):
     _check(got, want, dtype, f"{name} L{arch['depth']}")
     if got_f32s is not None:
         _check(got_f32s, want, dtype, f"{name} L{arch['depth']}, f32_stream")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float16])          # float32: the f32 attention kernel serves 64-wide heads only
+def test_dinov3_vit7b16_width_at_reduced_depth(dtype):
+    """dinov3.py:20-21 (dinov3_vit7b16, dinov3_vit7b16_sat): dim 4096, 32 heads of 128, gated MLP 8192, 4 register tokens, rotary
+    embedding -- the real width at depth 3 (0.5 G parameters; the 40-block model is 6.7 G): rows wider than 2048 in the LayerNorm /
+    stream kernels, K = 4096 / 8192 GEMMs, the 128-wide attention kernel without padding.  Against the fp32 oracle, whose rotary
+    and gated-MLP forms are pinned against transformers' DINOv3ViTModel above."""
+    from atlaspatch_amd.encoders.vit import ARCHS, TRANSFORM_RESIZE, build_hip_vit_extractor, random_canonical_state_dict
+    from oracle import vit_oracle
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    name = "dinov3_vit7b16"
+    arch = dict(ARCHS[name], depth=3)
+    assert (ARCHS[name]["dim"], ARCHS[name]["depth"], ARCHS[name]["heads"], ARCHS[name]["mlp_dim"]) == (4096, 40, 32, 8192)
+    sd = _with_layer_scale(random_canonical_state_dict(arch, seed=41), arch, 42)
+    ex = build_hip_vit_extractor(name=name, arch=arch, state_dict=sd, source="canonical", device=torch.device("cuda:0"), dtype=dtype,
+                                 resize=TRANSFORM_RESIZE[name], expect_size=None, max_batch=16)
+    tiles = _tiles(3, 43)
+    got = ex.extract_batch(tiles, batch_size=32)
+    assert np.array_equal(got, ex.extract_batch(tiles, batch_size=2))
+    ex.cleanup()
+    want = vit_oracle.canonical_extract(sd, tiles, heads=arch["heads"], depth=arch["depth"], image_size=arch["image_size"],
+                                        resize=TRANSFORM_RESIZE[name], batch=1, eps=arch["ln_eps"], pool="cls")
+    assert got.shape == want.shape == (3, 4096)
+    _check(got, want, dtype, "dinov3_vit7b16 width L3")
 
 
 @pytest.mark.gpu

@@ -133,20 +133,20 @@ MEASURED = {
     ("G1 L2", "bfloat16"): (4.81e-3, 9.61e-2, 5.52e-2),
     ("vit_b_16 L12 vs reference golden", "float32"): (2.11e-6, 2.70e-5, 2.05e-5),
     ("vit_b_16 L12 vs oracle", "float32"): (2.03e-6, 3.43e-5, 2.31e-5),
-    ("vit_b_16 L12 vs reference golden", "float16"): (7.74e-4, 1.33e-2, 8.35e-3),
-    ("vit_b_16 L12 vs oracle", "float16"): (8.03e-4, 1.60e-2, 9.17e-3),
+    ("vit_b_16 L12 vs reference golden", "float16"): (7.72e-4, 1.59e-2, 8.86e-3),
+    ("vit_b_16 L12 vs oracle", "float16"): (8.01e-4, 1.60e-2, 8.72e-3),
     ("vit_b_16 L12 vs oracle, plain 16-bit stream", "float16"): (1.256e-3, 1.617e-2, 1.260e-2),
     ("vit_b_16 L12 vs reference golden, plain 16-bit stream", "float16"): (1.260e-3, 1.884e-2, 1.311e-2),
     ("vit_b_16 L12 vs oracle, f32_stream", "float16"): (8.71e-4, 1.421e-2, 9.04e-3),
     ("vit_b_16 L12 vs reference golden, f32_stream", "float16"): (8.51e-4, 1.268e-2, 9.94e-3),
-    ("massive activations, fused", "float16"): (2.78e-4, 1.10e-3, 9.36e-4),
+    ("massive activations, fused", "float16"): (2.77e-4, 1.16e-3, 8.99e-4),
     ("massive activations, f32_stream", "float16"): (2.46e-4, 1.15e-3, 8.2e-4),
     ("massive activations, fused", "bfloat16"): (1.98e-3, 8.11e-3, 7.02e-3),
     ("massive activations, f32_stream", "bfloat16"): (1.94e-3, 7.84e-3, 6.45e-3),
-    ("uni_v1 L24", "float16"): (8.35e-4, 1.13e-2, 9.29e-3),
+    ("uni_v1 L24", "float16"): (8.38e-4, 1.25e-2, 9.10e-3),
     ("uni_v1 L24, f32_stream", "float16"): (9.39e-4, 1.441e-2, 9.97e-3),
     ("uni_v1 L24", "float32"): (2.36e-6, 2.89e-5, 2.18e-5),
-    ("vit_l_16 L24", "float16"): (8.63e-4, 1.16e-2, 9.34e-3),
+    ("vit_l_16 L24", "float16"): (8.60e-4, 1.18e-2, 8.95e-3),
     ("vit_l_16 L24, f32_stream", "float16"): (9.24e-4, 1.334e-2, 1.048e-2),
     ("conch_v1 L12 @448", "float16"): (6.54e-4, 9.79e-3, 7.86e-3),
 }

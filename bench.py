@@ -74,6 +74,8 @@ ENCODERS = {
     "dinov3_vitb16": {"label": "DINOv3 ViT-B/16 (201 tokens, RoPE)", "batch": 2048},
     "dinov3_vitl16": {"label": "DINOv3 ViT-L/16 (201 tokens, RoPE)", "batch": 2048},
     "dinov3_vith16_plus": {"label": "DINOv3 ViT-H+/16 (201 tokens, RoPE, gated MLP)", "batch": 1024},
+    "dinov3_vit7b16": {"label": "DINOv3 ViT-7B/16 (201 tokens, dim 4096, 40 blocks, RoPE, gated MLP 8192; 6.7 G parameters: run "
+                                "with --no-cpu-baseline, the fp32 oracle of this size is not a bounded sample)", "batch": 256},
 }
 
 

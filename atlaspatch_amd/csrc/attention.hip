@@ -308,7 +308,8 @@ int launch_by_len(const void* qkv, void* out, int n, int tokens, int heads, floa
 
 int launch_attention(int dtype, const void* qkv, void* out, int n, int tokens, int heads,
                      int head_dim, float scale, hipStream_t stream) {
-    AP_REQUIRE(head_dim == kHD || (head_dim == 128 && dtype != AP_F32), "attention: head_dim %d unsupported (64; 128 in f16 / bf16)", head_dim);
+    AP_REQUIRE(head_dim == kHD || ((head_dim == 96 || head_dim == 128) && dtype != AP_F32),
+               "attention: head_dim %d unsupported (64; 96 / 128 in f16 / bf16)", head_dim);
     AP_REQUIRE(tokens > 0 && heads > 0 && scale > 0.f, "attention: bad shape");
     if (n <= 0) return AP_OK;
     // f16 / bf16: the tiled online-softmax kernel (attention_flash.hip; any length, 0.37 ms vs 0.49 ms for

@@ -1,8 +1,13 @@
-// Tiled ("flash") multi-head attention for f16 / bf16, heads stored 64 or 128 wide, any sequence length:
+// Tiled ("flash") multi-head attention for f16 / bf16, heads stored 64, 96 or 128 wide, any sequence length:
 //     out = softmax(q k^T * scale) v      per (image, head), f32 softmax, online rescaling.
 // (The text below describes the 64-wide instantiation; HD = 128 -- vit_h_14's 80-wide heads, zero-padded -- has 256-byte
 // rows: two DMA pieces per thread, operand and tile, K chunks XOR-swizzled by row & 15, V 64-byte windows by row & 3, four
-// 32-channel output blocks, 128 KiB of LDS.)
+// 32-channel output blocks, 128 KiB of LDS.  HD = 96 -- the 80-wide heads of ViT-H/14 and Virchow, zero-padded: 192-byte rows,
+// 12 chunks per row: the 768 chunks of a tile are staged as one piece by every thread and a second by waves 0-3; K chunks
+// XOR-swizzled by (row >> 2) & 3 inside their 64-byte window (consecutive rows already step 192 bytes = three quarters of the
+// 256-byte bank line, so 16 rows x one chunk land in 16 different 16-byte slots), V rows unswizzled (four rows of a transpose
+// load fall in four different 64-byte quarters by the row stride alone), three 32-channel output blocks, 96 KiB of LDS and 150 registers: one workgroup per CU like HD = 128 (a ring of three
+// buffers would admit two, but not inside 128 registers: 18 spilled).)
 //
 // One workgroup = 8 waves = eight 32-query blocks of one (image, head); it walks the keys in tiles
 // of 64.  K and V tiles arrive by LDS-DMA (global_load_lds, 16 B per lane, one K and one V piece
@@ -110,8 +115,10 @@ void attention_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int 
     constexpr int kTileBytes = kKV * RB;             // one K or V tile (64 rows)
     constexpr int NKK = HD / 16;                     // k-steps of S^T = K Q^T
     constexpr int NIT = HD / 32;                     // 32-channel output blocks
-    constexpr int NPC = kTileBytes / (kNW * 64 * 16);   // DMA pieces per thread, operand and tile (1 or 2)
-    constexpr int CPR = RB / 16;                     // 16-byte chunks per row (8 or 16)
+    constexpr int NPC = (kTileBytes + kNW * 64 * 16 - 1) / (kNW * 64 * 16);   // DMA pieces per thread, operand and tile (1 or 2; HD = 96:
+                                                     //   the second piece exists for the first half of the threads only)
+    constexpr int CPR = RB / 16;                     // 16-byte chunks per row (8, 12 or 16)
+    constexpr int kChunks = kTileBytes / 16;         // chunks of one operand tile
     __shared__ __attribute__((aligned(16))) char smem[kNB * 2 * kTileBytes];     // [buf][K | V]
     using Frag = typename FMma<T>::Frag;
 
@@ -145,6 +152,9 @@ void attention_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int 
         if constexpr (HD == 64) {
             kchunk[pc] = (uint32_t)((spos ^ ((row >> 1) & 7)) << 4);
             vchunk[pc] = (uint32_t)((spos ^ (((row >> 1) & 1) << 2)) << 4);
+        } else if constexpr (HD == 96) {
+            kchunk[pc] = (uint32_t)((spos ^ ((row >> 2) & 3)) << 4);
+            vchunk[pc] = (uint32_t)(spos << 4);
         } else {
             kchunk[pc] = (uint32_t)((spos ^ (row & 15)) << 4);
             vchunk[pc] = (uint32_t)((spos ^ ((row & 3) << 2)) << 4);
@@ -154,6 +164,7 @@ void attention_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int 
     auto stage = [&](int j) {
 #pragma unroll
         for (int pc = 0; pc < NPC; ++pc) {
+            if (pc * (kNW * 64) + wave * 64 >= kChunks) break;            // HD = 96: no second piece for waves 4-7 (wave-uniform)
             int row = j * kKV + srow[pc];
             row = row < tokens ? row : tokens - 1;
             const uint32_t roff = (uint32_t)row * ldb;
@@ -189,7 +200,7 @@ void attention_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int 
     for (int kk = 0; kk < NKK; ++kk) asm volatile("" :: "v"(qf[kk]));
 
     // ---- fragment addresses inside a buffer
-    const int xr = HD == 64 ? (l31 >> 1) & 7 : l31 & 15;
+    const int xr = HD == 64 ? (l31 >> 1) & 7 : (HD == 96 ? (l31 >> 2) & 3 : l31 & 15);
     uint32_t ka[NKK];                             // K: row l31 (+32 per key block), chunk (2 kk + hi) ^ xr
 #pragma unroll
     for (int kk = 0; kk < NKK; ++kk) ka[kk] = (uint32_t)(l31 * RB + (((kk * 2 + hi) ^ xr) << 4));
@@ -201,7 +212,7 @@ void attention_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int 
     uint32_t va[NIT];                                                    // it = 32-channel block (row swizzle folded in)
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        const int chunk = (it * 4 + (vcol >> 4)) ^ ((HD == 64 ? (vrow >> 1) & 1 : vrow & 3) << 2);
+        const int chunk = (it * 4 + (vcol >> 4)) ^ ((HD == 64 ? (vrow >> 1) & 1 : (HD == 96 ? 0 : vrow & 3)) << 2);
         va[it] = (uint32_t)(kTileBytes + vrow * RB + (chunk << 4) + (vcol & 15));
     }
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -284,31 +295,29 @@ void attention_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int 
         l_run += ps2[0] + ps2[1];
 
         // ---------------- O^T += V^T P^T
-        const uint32_t v0 = bufa + va[0], v1 = bufa + va[1];
         auto pv_step = [&](auto SP) {                                     // one 16-key step
             constexpr int sp = decltype(SP)::value;
             Frag pf;
 #pragma unroll
             for (int e = 0; e < 8; ++e) pf[e] = (T)st[sp >> 1][(sp & 1) * 8 + e];
-            u32x2 v0a = tr_read<sp * 16 * RB>(v0), v0b = tr_read<sp * 16 * RB + 8 * RB>(v0);
-            u32x2 v1a = tr_read<sp * 16 * RB>(v1), v1b = tr_read<sp * 16 * RB + 8 * RB>(v1);
-            if constexpr (HD == 64) {
-                // the loads' destinations count as written only from here on (hipcc does not track asm loads)
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v0a), "+v"(v0b), "+v"(v1a), "+v"(v1b) :: "memory");
-                const u32x4 f0 = {v0a[0], v0a[1], v0b[0], v0b[1]}, f1 = {v1a[0], v1a[1], v1b[0], v1b[1]};
-                ot[0] = FMma<T>::run(__builtin_bit_cast(Frag, f0), pf, ot[0]);
-                ot[1] = FMma<T>::run(__builtin_bit_cast(Frag, f1), pf, ot[1]);
-            } else {
-                const uint32_t v2 = bufa + va[NIT - 2], v3 = bufa + va[NIT - 1];
-                u32x2 v2a = tr_read<sp * 16 * RB>(v2), v2b = tr_read<sp * 16 * RB + 8 * RB>(v2);
-                u32x2 v3a = tr_read<sp * 16 * RB>(v3), v3b = tr_read<sp * 16 * RB + 8 * RB>(v3);
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v0a), "+v"(v0b), "+v"(v1a), "+v"(v1b), "+v"(v2a), "+v"(v2b), "+v"(v3a), "+v"(v3b) :: "memory");
-                const u32x4 f0 = {v0a[0], v0a[1], v0b[0], v0b[1]}, f1 = {v1a[0], v1a[1], v1b[0], v1b[1]};
-                const u32x4 f2 = {v2a[0], v2a[1], v2b[0], v2b[1]}, f3 = {v3a[0], v3a[1], v3b[0], v3b[1]};
-                ot[0] = FMma<T>::run(__builtin_bit_cast(Frag, f0), pf, ot[0]);
-                ot[1] = FMma<T>::run(__builtin_bit_cast(Frag, f1), pf, ot[1]);
-                ot[NIT - 2] = FMma<T>::run(__builtin_bit_cast(Frag, f2), pf, ot[NIT - 2]);
-                ot[NIT - 1] = FMma<T>::run(__builtin_bit_cast(Frag, f3), pf, ot[NIT - 1]);
+            u32x2 va_[NIT], vb_[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                va_[it] = tr_read<sp * 16 * RB>(bufa + va[it]);
+                vb_[it] = tr_read<sp * 16 * RB + 8 * RB>(bufa + va[it]);
+            }
+            // the loads' destinations count as written only from here on (hipcc does not track asm loads)
+            if constexpr (NIT == 2)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(va_[0]), "+v"(vb_[0]), "+v"(va_[1]), "+v"(vb_[1]) :: "memory");
+            else if constexpr (NIT == 3)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(va_[0]), "+v"(vb_[0]), "+v"(va_[1]), "+v"(vb_[1]), "+v"(va_[2]), "+v"(vb_[2]) :: "memory");
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(va_[0]), "+v"(vb_[0]), "+v"(va_[1]), "+v"(vb_[1]), "+v"(va_[2]), "+v"(vb_[2]),
+                             "+v"(va_[NIT - 1]), "+v"(vb_[NIT - 1]) :: "memory");
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const u32x4 f = {va_[it][0], va_[it][1], vb_[it][0], vb_[it][1]};
+                ot[it] = FMma<T>::run(__builtin_bit_cast(Frag, f), pf, ot[it]);
             }
         };
         pv_step(IntC<0>{});
@@ -355,16 +364,17 @@ void attention_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int 
                 u32x2 o;
                 o[0] = (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
                 o[1] = (uint32_t)__builtin_bit_cast(uint16_t, cc) | ((uint32_t)__builtin_bit_cast(uint16_t, d) << 16);
-                *(u32x2*)(stg + l31 * RB + (((it * 4 + g4) ^ (l31 & (CPR - 1))) << 4) + hi * 8) = o;
+                *(u32x2*)(stg + l31 * RB + (((it * 4 + g4) ^ (l31 & (HD == 96 ? 3 : CPR - 1))) << 4) + hi * 8) = o;
             }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        constexpr int kRowsPer = 64 / CPR;            // rows one wave-wide 16-byte read covers (8 or 4)
+        constexpr int kSwz = HD == 96 ? 3 : CPR - 1;  // chunk swizzle mask of the staging rows (inside the 12 chunks at HD = 96)
 #pragma unroll
-        for (int i = 0; i < 32 / kRowsPer; ++i) {
-            const int row = lane / CPR + kRowsPer * i, ch = lane % CPR;
-            const u32x4 v = *(const u32x4*)(stg + row * RB + ((ch ^ (row & (CPR - 1))) << 4));
+        for (int i = 0; i < 32 * CPR / 64; ++i) {     // 32 rows x CPR chunks, one 16-byte chunk per lane and step
+            const int idx = i * 64 + lane;
+            const int row = idx / CPR, ch = idx % CPR;
+            const u32x4 v = *(const u32x4*)(stg + row * RB + ((ch ^ (row & kSwz)) << 4));
             const int q = qb * 32 + row;
             if (q < tokens) *(u32x4*)(out + ((size_t)img * tokens + q) * dim + head * kHD + ch * 8) = v;
         }
@@ -376,7 +386,7 @@ void attention_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int 
 int launch_attention_flash(int dtype, const void* qkv, void* out, int n, int tokens, int heads, int head_dim, float scale,
                            hipStream_t stream) {
     AP_REQUIRE(dtype == AP_F16 || dtype == AP_BF16, "attention_flash: f16 / bf16 only");
-    AP_REQUIRE(head_dim == 64 || head_dim == 128, "attention_flash: head_dim %d (64 / 128)", head_dim);
+    AP_REQUIRE(head_dim == 64 || head_dim == 96 || head_dim == 128, "attention_flash: head_dim %d (64 / 96 / 128)", head_dim);
     AP_REQUIRE((size_t)tokens * 3 * heads * head_dim * 2 < 0xffffffffull, "attention_flash: sequence too long");
     if (n <= 0) return AP_OK;
     const int nqb = (tokens + 31) / 32;
@@ -384,6 +394,7 @@ int launch_attention_flash(int dtype, const void* qkv, void* out, int n, int tok
     dim3 grid((unsigned)((units + 7) / 8 * 8 * parts)), block(kNW * 64);
 #define AP_FLASH(T, HD) attention_flash_kernel<T, HD><<<grid, block, 0, stream>>>((const T*)qkv, (T*)out, tokens, heads, parts, units, scale)
     if (head_dim == 64) { if (dtype == AP_F16) AP_FLASH(f16, 64); else AP_FLASH(bf16, 64); }
+    else if (head_dim == 96) { if (dtype == AP_F16) AP_FLASH(f16, 96); else AP_FLASH(bf16, 96); }
     else { if (dtype == AP_F16) AP_FLASH(f16, 128); else AP_FLASH(bf16, 128); }
 #undef AP_FLASH
     AP_HIP_CHECK(hipGetLastError());

@@ -95,8 +95,9 @@ template <typename T, int HD>
 __global__ __launch_bounds__(256) void attn_cls_kernel(const T* __restrict__ q, const T* __restrict__ kv, int ld, int koff,
                                                        int voff, T* __restrict__ out, int tokens, int heads, float scale) {
     // thread = (row slot r of kRows, channel octet sub of kSub): every K / V access is a 16-byte load and a wave covers
-    // whole rows per step (HD = 64: eight 128-byte rows; HD = 128: four 256-byte rows)
-    constexpr int kSub = HD / 8, kRows = 256 / kSub;
+    // whole rows per step (HD = 64: eight 128-byte rows; HD = 128: four 256-byte rows; HD = 96: four 192-byte rows, the octets
+    // 12 .. 15 of a row slot idle -- kSub stays a power of two for the lane exchanges)
+    constexpr int kOct = HD / 8, kSub = HD == 64 ? 8 : 16, kRows = 256 / kSub;
     extern __shared__ __attribute__((aligned(16))) float sm[];       // scores[tokens] | red[4] | part[kRows][HD]
     float* scores = sm;
     float* red = sm + ((tokens + 3) & ~3);
@@ -105,13 +106,15 @@ __global__ __launch_bounds__(256) void attn_cls_kernel(const T* __restrict__ q, 
     const int img = blockIdx.x / heads, head = blockIdx.x - img * heads;
     const int P = heads * HD;
     const int sub = threadIdx.x & (kSub - 1), r = threadIdx.x / kSub;
-    const T* kbase = kv + (size_t)img * tokens * ld + koff + head * HD + sub * 8;
-    const T* vbase = kv + (size_t)img * tokens * ld + voff + head * HD + sub * 8;
+    const bool oct = sub < kOct;
+    const int subc = oct ? sub : 0;                                   // idle octets read (and ignore) octet 0
+    const T* kbase = kv + (size_t)img * tokens * ld + koff + head * HD + subc * 8;
+    const T* vbase = kv + (size_t)img * tokens * ld + voff + head * HD + subc * 8;
     float qr[8];
     {
-        const V8 qq = *(const V8*)(q + (size_t)img * P + head * HD + sub * 8);
+        const V8 qq = *(const V8*)(q + (size_t)img * P + head * HD + subc * 8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) qr[e] = (float)qq[e];
+        for (int e = 0; e < 8; ++e) qr[e] = oct ? (float)qq[e] : 0.f;
     }
     float mx = -INFINITY;
     for (int t = r; t < tokens; t += kRows) {
@@ -142,8 +145,10 @@ __global__ __launch_bounds__(256) void attn_cls_kernel(const T* __restrict__ q, 
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = __builtin_fmaf(p, (float)vv[e], acc[e]);
     }
+    if (oct) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) part[r * HD + sub * 8 + e] = acc[e];
+        for (int e = 0; e < 8; ++e) part[r * HD + sub * 8 + e] = acc[e];
+    }
     __syncthreads();
     if (threadIdx.x < HD) {
         const int c = threadIdx.x;
@@ -171,14 +176,14 @@ int launch_attn_pool(int dtype, const void* kv, const float* q, void* out, int n
 
 int launch_attention_cls(int dtype, const void* q, const void* kv, int ld, int koff, int voff, void* out, int n,
                          int tokens, int heads, int head_dim, float scale, hipStream_t stream) {
-    AP_REQUIRE(head_dim == 64 || head_dim == 128, "attention_cls: head_dim %d unsupported (64 / 128)", head_dim);
+    AP_REQUIRE(head_dim == 64 || head_dim == 96 || head_dim == 128, "attention_cls: head_dim %d unsupported (64 / 96 / 128)", head_dim);
     AP_REQUIRE(tokens > 0 && tokens <= 12000, "attention_cls: %d tokens unsupported", tokens);
     AP_REQUIRE(ld % 8 == 0 && koff % 8 == 0 && voff % 8 == 0, "attention_cls: misaligned layout");
     if (n <= 0) return AP_OK;
     const size_t lds = ((size_t)((tokens + 3) & ~3) + 4 + 32 * 64) * sizeof(float);       // part: kRows * HD = 2048 floats either way
     dim3 grid(n * heads), block(256);
 #define AP_CLS(T, HD) attn_cls_kernel<T, HD><<<grid, block, lds, stream>>>((const T*)q, (const T*)kv, ld, koff, voff, (T*)out, tokens, heads, scale)
-#define AP_CLS_HD(T) do { if (head_dim == 64) AP_CLS(T, 64); else AP_CLS(T, 128); } while (0)
+#define AP_CLS_HD(T) do { if (head_dim == 64) AP_CLS(T, 64); else if (head_dim == 96) AP_CLS(T, 96); else AP_CLS(T, 128); } while (0)
     if (dtype == AP_F16) AP_CLS_HD(f16);
     else if (dtype == AP_BF16) AP_CLS_HD(bf16);
     else if (dtype == AP_F32) AP_CLS_HD(float);

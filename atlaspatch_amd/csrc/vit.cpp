@@ -599,8 +599,8 @@ int ap_vit_create(const ap_vit_config* cfg, ap_vit** out) {
                "vit_create: patch size %d unsupported by this build (even, 4 .. 32)", c.patch_size);
     AP_REQUIRE(c.dim > 0 && c.heads > 0 && c.dim % c.heads == 0, "vit_create: dim %d / heads %d", c.dim, c.heads);
     const int hd = c.head_dim > 0 ? c.head_dim : c.dim / c.heads;
-    AP_REQUIRE(hd == 64 || hd == 128,
-               "vit_create: head_dim %d: q / k / v heads must be stored 64 or 128 wide (zero-pad other widths and set attn_scale)", hd);
+    AP_REQUIRE(hd == 64 || hd == 128 || (hd == 96 && c.compute_dtype != AP_F32),
+               "vit_create: head_dim %d: q / k / v heads must be stored 64, 96 (f16 / bf16) or 128 wide (zero-pad other widths and set attn_scale)", hd);
     AP_REQUIRE(c.dim % 128 == 0 && c.mlp_dim % 128 == 0, "vit_create: dim and mlp_dim must be multiples of 128");
     AP_REQUIRE(c.reg_tokens >= 0 && c.reg_tokens <= 64, "vit_create: reg_tokens %d", c.reg_tokens);
     AP_REQUIRE(c.mlp_type == AP_MLP_GELU || c.mlp_type == AP_MLP_SWIGLU, "vit_create: mlp_type %d", c.mlp_type);

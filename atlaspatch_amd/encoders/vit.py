@@ -102,7 +102,7 @@ ARCHS = {
     "uni_v1": dict(image_size=224, patch_size=16, dim=1024, depth=24, heads=16, mlp_dim=4096,
                    ln_eps=1e-6, layer_scale=True),
     # the rest of models/patch/vit.py:9-15 (torchvision): patch 32 (50 tokens); ViT-H/14 at the SWAG end-to-end weights'
-    # 518 px (37 x 37 + 1 = 1370 tokens), heads 80 wide (stored zero-padded to 128 on the device, softmax scale 1/sqrt(80))
+    # 518 px (37 x 37 + 1 = 1370 tokens), heads 80 wide (stored zero-padded to 96 on the device, softmax scale 1/sqrt(80))
     "vit_b_32": dict(image_size=224, patch_size=32, dim=768, depth=12, heads=12, mlp_dim=3072,
                      ln_eps=1e-6, layer_scale=False),
     "vit_l_32": dict(image_size=224, patch_size=32, dim=1024, depth=24, heads=16, mlp_dim=4096,
@@ -451,10 +451,13 @@ def canonical_state_dict(sd: dict, *, depth: int, layer_scale: bool, source: str
 
 
 def stored_head_dim(dim: int, heads: int) -> int:
-    """Width of one q / k / v head as the device stores it: 64 or 128 (other true widths are zero-padded up)."""
+    """Width of one q / k / v head as the device stores it: 64, 96 or 128 (other true widths are zero-padded up; 96 -- the 80-wide
+    heads of ViT-H/14 and Virchow -- exists in the float16 / bfloat16 attention kernels only, like 128)."""
     hd = dim // heads
     if hd <= 64:
         return 64
+    if hd <= 96:
+        return 96
     if hd <= 128:
         return 128
     raise ValueError(f"head width {hd} (dim {dim} / heads {heads}) exceeds 128")

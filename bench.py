@@ -39,7 +39,7 @@ ENCODERS = {
     # the rest of the reference's three encoder files (round 4)
     "vit_b_32": {"label": "ViT-B/32 (50 tokens)", "batch": 4096},
     "vit_l_32": {"label": "ViT-L/32 (50 tokens)", "batch": 4096},
-    "vit_h_14": {"label": "ViT-H/14 at torchvision's SWAG_E2E 518 px (1370 tokens, 80-wide heads stored 128 wide, Resize(518, "
+    "vit_h_14": {"label": "ViT-H/14 at torchvision's SWAG_E2E 518 px (1370 tokens, 80-wide heads stored 96 wide, Resize(518, "
                           "bicubic) on the device)", "batch": 128},
     "uni_v2": {"label": "UNI2-h (ViT-H/14 at 224 px, 8 register tokens, SwiGLU, LayerScale; Resize(224, bicubic) on the device)",
                "batch": 1024},

@@ -200,8 +200,9 @@ typedef struct ap_vit_config {
                             AP_MLP_SWIGLU: timm SwiGLUPacked -- fc1 [2 * mlp_dim, dim], silu(x[:, :mlp_dim]) * x[:, mlp_dim:],
                             fc2 [dim, mlp_dim] (uni_v2: mlp_dim 4096) */
     int head_dim;        /* 0 = dim / heads (must be 64); else the width of one head of q / k / v as STORED: qkv.weight has
-                            3 * heads * head_dim rows, proj.weight heads * head_dim columns (64 or 128).  A model whose true
-                            head width is not 64 / 128 (vit_h_14: 80) is uploaded zero-padded to 128 with attn_scale set */
+                            3 * heads * head_dim rows, proj.weight heads * head_dim columns (64, 128, or -- float16 / bfloat16 --
+                            96).  A model whose true head width is none of these (vit_h_14, Virchow: 80) is uploaded zero-padded
+                            to the next one (96) with attn_scale set */
     float attn_scale;    /* 0 = 1 / sqrt(head_dim); else the softmax scale (vit_h_14: 1 / sqrt(80)) */
     /* ---- ABI v18: CLIP vision towers (models/patch/clip.py, plip.py, quilt.py: open_clip VisionTransformer / transformers
      *      CLIPVisionModel).  All zero = the v17 behaviour. */
@@ -370,7 +371,7 @@ int ap_layernorm(int out_dtype, const float* x, long stride, int rows, int dim,
 
 /* Multi-head self-attention on packed projections: qkv T [n * tokens, 3 * heads * head_dim]
  * (q | k | v), out T [n * tokens, heads * head_dim]; softmax(q k^T / sqrt(head_dim)) v in f32
- * (F.scaled_dot_product_attention without mask / dropout).  head_dim must be 64. */
+ * (F.scaled_dot_product_attention without mask / dropout).  head_dim: 64 (any dtype), 96 or 128 (float16 / bfloat16). */
 int ap_attention(int dtype, const void* qkv, void* out, int n, int tokens, int heads, int head_dim,
                  ap_stream_t stream);
 

@@ -217,14 +217,15 @@ def test_oracle_matches_hf_clip_get_image_features(patch, image):
 
 
 def test_head_padding_leaves_the_function_unchanged():
-    """pad_heads: 80-wide heads stored 128 wide (zero rows in q / k / v, zero columns in proj) with the softmax scale kept at
+    """pad_heads: 80-wide heads stored 96 wide (zero rows in q / k / v, zero columns in proj) with the softmax scale kept at
     1 / sqrt(80) -- checked with an explicit attention on the padded tensors."""
     from atlaspatch_amd.encoders.vit import pad_heads, random_canonical_state_dict, stored_head_dim
     arch = dict(image_size=28, patch_size=14, dim=160, depth=1, heads=2, mlp_dim=320, ln_eps=1e-6)
     sd = random_canonical_state_dict(arch, seed=5)
-    assert stored_head_dim(160, 2) == 128 and stored_head_dim(768, 12) == 64 and stored_head_dim(1280, 16) == 128
+    assert stored_head_dim(160, 2) == 96 and stored_head_dim(768, 12) == 64 and stored_head_dim(1280, 16) == 96
+    assert stored_head_dim(200, 2) == 128 and stored_head_dim(4096, 32) == 128
     pad = pad_heads(sd, dim=160, heads=2, depth=1)
-    assert pad["blocks.0.qkv.weight"].shape == (3 * 2 * 128, 160) and pad["blocks.0.proj.weight"].shape == (160, 256)
+    assert pad["blocks.0.qkv.weight"].shape == (3 * 2 * 96, 160) and pad["blocks.0.proj.weight"].shape == (160, 192)
     h = torch.randn(2, 5, 160, generator=torch.Generator().manual_seed(6))
 
     def attn(s, hd, scale):
@@ -232,7 +233,7 @@ def test_head_padding_leaves_the_function_unchanged():
         q, k, v = qkv.view(2, 5, 3, 2, hd).permute(2, 0, 3, 1, 4)
         ctx = (torch.softmax(q @ k.transpose(-1, -2) * scale, -1) @ v).transpose(1, 2).reshape(2, 5, 2 * hd)
         return ctx @ s["blocks.0.proj.weight"].T + s["blocks.0.proj.bias"]
-    assert _rel(attn(pad, 128, 1 / math.sqrt(80)).numpy(), attn(sd, 80, 1 / math.sqrt(80)).numpy()) <= 1e-6
+    assert _rel(attn(pad, 96, 1 / math.sqrt(80)).numpy(), attn(sd, 80, 1 / math.sqrt(80)).numpy()) <= 1e-6
     assert pad_heads(sd | {}, dim=128, heads=2, depth=0) is not None          # 64-wide: returned as is
 
 

@@ -296,18 +296,20 @@ def test_attention_vs_torch(env, dt, tol, shape):
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.float16, 4e-3), (torch.bfloat16, 3e-2)])
-@pytest.mark.parametrize("shape", [(2, 197, 4), (1, 1370, 16), (3, 50, 2), (1, 150, 3), (2, 448, 5), (9, 1, 1), (1, 2000, 1)])
-def test_attention_128_wide_heads_vs_torch(env, dt, tol, shape):
-    """The HD = 128 instantiation of the tiled kernel (vit_h_14's 80-wide heads are stored zero-padded to 128): full 128-wide
-    random heads against torch, incl. 1370 tokens (vit_h_14 at 518 px) and key-tile counts of every residue mod 4."""
+@pytest.mark.parametrize("shape", [(2, 197, 4), (1, 1370, 16), (3, 50, 2), (1, 150, 3), (2, 448, 5), (9, 1, 1), (1, 2000, 1), (2, 257, 16)])
+@pytest.mark.parametrize("hd", [96, 128])
+def test_attention_wide_heads_vs_torch(env, dt, tol, shape, hd):
+    """The HD = 96 and HD = 128 instantiations of the tiled kernel (the 80-wide heads of vit_h_14 / Virchow are stored zero-padded
+    to 96; 128 = DINOv3 ViT-7B): full-width random heads against torch, incl. 1370 tokens (vit_h_14 at 518 px), 257 (Virchow) and
+    key-tile counts of every residue mod 4."""
     _lib, lib, dev, stream = env
     n, T, H = shape
     g = torch.Generator(device=dev).manual_seed(T + 7)
-    qkv = (torch.randn((n * T, 3 * H * 128), device=dev, generator=g) * 1.2).to(dt)
-    out = torch.full((n * T, H * 128), float("nan"), device=dev, dtype=dt)
-    _lib.check(lib.ap_attention(_lib.torch_dtype_code(dt), qkv.data_ptr(), out.data_ptr(), n, T, H, 128, stream))
+    qkv = (torch.randn((n * T, 3 * H * hd), device=dev, generator=g) * 1.2).to(dt)
+    out = torch.full((n * T, H * hd), float("nan"), device=dev, dtype=dt)
+    _lib.check(lib.ap_attention(_lib.torch_dtype_code(dt), qkv.data_ptr(), out.data_ptr(), n, T, H, hd, stream))
     torch.cuda.synchronize()
-    assert (out.float() - _attn_ref(qkv, n, T, H, 128)).abs().max().item() <= tol
+    assert (out.float() - _attn_ref(qkv, n, T, H, hd)).abs().max().item() <= tol
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.float16, 4e-3), (torch.bfloat16, 3e-2)])
@@ -334,7 +336,8 @@ def test_operator_error_paths(env):
     assert lib.ap_gemm(1, 0, None, 0, None, 0, 1, 1, 1, None, None, None, 0, 0, 0, stream) == -1
     assert lib.ap_gemm(1, 7, x.data_ptr(), 128, x.data_ptr(), 128, 4, 128, 128, x.data_ptr(), None, x.data_ptr(), 128, 0, 0,
                        stream) == -1
-    assert lib.ap_attention(1, x.data_ptr(), x.data_ptr(), 1, 4, 1, 32, stream) == -1     # head_dim not 64 / 128
+    assert lib.ap_attention(1, x.data_ptr(), x.data_ptr(), 1, 4, 1, 32, stream) == -1     # head_dim not 64 / 96 / 128
+    assert lib.ap_attention(0, x.data_ptr(), x.data_ptr(), 1, 4, 1, 96, stream) == -1     # 96-wide heads: f16 / bf16 only
     assert lib.ap_attention(0, x.data_ptr(), x.data_ptr(), 1, 4, 1, 128, stream) == -1    # 128-wide heads: f16 / bf16 only
     assert b"head_dim" in lib.ap_last_error()
     # fused-LayerNorm operators: missing operands, float32, bad kernel choice, shapes the persistent kernel cannot take

@@ -74,6 +74,17 @@ ENCODERS = {
     "dinov3_vitb16": {"label": "DINOv3 ViT-B/16 (201 tokens, RoPE)", "batch": 2048},
     "dinov3_vitl16": {"label": "DINOv3 ViT-L/16 (201 tokens, RoPE)", "batch": 2048},
     "dinov3_vith16_plus": {"label": "DINOv3 ViT-H+/16 (201 tokens, RoPE, gated MLP)", "batch": 1024},
+    # the remaining registered names: same architectures as a line above (other weights / normalisation)
+    "vit_l_16": {"label": "ViT-L/16 (torchvision; the architecture of uni_v1 without LayerScale)", "batch": 2048},
+    "h_optimus_1": {"label": "H-optimus-1 (as H-optimus-0)", "batch": 512,
+                    "mean": (0.707223, 0.578729, 0.703617), "std": (0.211883, 0.230117, 0.177517)},
+    "h0_mini": {"label": "H0-mini (ViT-B/14, 4 register tokens, class token + mean patch token)", "batch": 2048,
+                "mean": (0.707223, 0.578729, 0.703617), "std": (0.211883, 0.230117, 0.177517)},
+    "quilt_b_32": {"label": "QuiltNet-B-32 (open_clip ViT-B/32 image tower)", "batch": 4096, "mean": OPENAI_CLIP_MEAN, "std": OPENAI_CLIP_STD},
+    "quilt_b_16": {"label": "QuiltNet-B-16 (open_clip ViT-B/16 image tower)", "batch": 2048, "mean": OPENAI_CLIP_MEAN, "std": OPENAI_CLIP_STD},
+    "dinov3_vits16_plus": {"label": "DINOv3 ViT-S+/16 (201 tokens, RoPE, gated MLP)", "batch": 4096},
+    "dinov3_vitl16_sat": {"label": "DINOv3 ViT-L/16, satellite weights (as dinov3_vitl16)", "batch": 2048},
+    "dinov3_vit7b16_sat": {"label": "DINOv3 ViT-7B/16, satellite weights (as dinov3_vit7b16; run with --no-cpu-baseline)", "batch": 256},
     "dinov3_vit7b16": {"label": "DINOv3 ViT-7B/16 (201 tokens, dim 4096, 40 blocks, RoPE, gated MLP 8192; 6.7 G parameters: run "
                                 "with --no-cpu-baseline, the fp32 oracle of this size is not a bounded sample)", "batch": 256},
 }

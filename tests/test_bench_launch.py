@@ -38,7 +38,11 @@ def test_encoder_geometry_matches_the_surveyed_flop_counts():
                                    "dinov2_large", "dinov2_giant", "phikon_v1", "phikon_v2", "midnight", "h_optimus_0", "prov_gigapath",
                                    "lunit_vit_small_patch16_dino", "lunit_vit_small_patch8_dino", "pathorchestra", "clip_vit_b_32",
                                    "clip_vit_b_16", "clip_vit_l_14", "clip_vit_l_14_336", "plip", "biomedclip", "virchow_v1", "virchow_v2",
-                                   "dinov3_vits16", "dinov3_vitb16", "dinov3_vitl16", "dinov3_vith16_plus", "dinov3_vit7b16"}
+                                   "dinov3_vits16", "dinov3_vitb16", "dinov3_vitl16", "dinov3_vith16_plus", "dinov3_vit7b16",
+                                   "vit_l_16", "h_optimus_1", "h0_mini", "quilt_b_32", "quilt_b_16", "dinov3_vits16_plus",
+                                   "dinov3_vitl16_sat", "dinov3_vit7b16_sat"}
+    from atlaspatch_amd.encoders import build_default_registry
+    assert set(bench.ENCODERS) == set(build_default_registry(device="cpu").available())       # every registered name has a bench line
     # round 4: the rest of the encoder files.  uni_v2 = 265 tokens (1 + 8 registers + 256 patches), SwiGLU packed fc1;
     # vit_h_14 = 1370 tokens at 518 px
     g = bench.encoder_geometry(ARCHS["uni_v2"])

@@ -292,7 +292,9 @@ int launch_nw(const void* qkv, void* out, int n, int tokens, int heads, float sc
 template <typename T, int NKT>
 int launch_one(const void* qkv, void* out, int n, int tokens, int heads, float scale, hipStream_t stream) {
     static const int waves = [] { const char* e = getenv("AP_ATTN_WAVES"); return e ? atoi(e) : 4; }();
-    if (sizeof(T) == 2 && waves == 8) return launch_nw<T, NKT, 8>(qkv, out, n, tokens, heads, scale, stream);
+    if constexpr (sizeof(T) == 2) {              // (the float kernel exists with 4 waves only: with 8 its 9-tile form spills)
+        if (waves == 8) return launch_nw<T, NKT, 8>(qkv, out, n, tokens, heads, scale, stream);
+    }
     return launch_nw<T, NKT, 4>(qkv, out, n, tokens, heads, scale, stream);
 }
 

@@ -30,13 +30,21 @@ class HipLibraryError(RuntimeError):
     pass
 
 
+ABI_VERSION = 20                # include/atlaspatch_hip.h: AP_ABI_VERSION; load() refuses a library that reports another
+
+
 class VitConfig(C.Structure):
-    _fields_ = [("image_size", C.c_int), ("patch_size", C.c_int), ("dim", C.c_int),
+    """``ap_vit_config`` (ABI v20).  ``struct_size`` is filled in here, so positional construction starts at
+    ``image_size`` as it did before the field existed."""
+    _fields_ = [("struct_size", C.c_uint32), ("image_size", C.c_int), ("patch_size", C.c_int), ("dim", C.c_int),
                 ("depth", C.c_int), ("heads", C.c_int), ("mlp_dim", C.c_int),
                 ("ln_eps", C.c_float), ("layer_scale", C.c_int), ("compute_dtype", C.c_int),
                 ("pool", C.c_int), ("pool_dim", C.c_int), ("pool_heads", C.c_int), ("pool_ln_eps", C.c_float),
                 ("reg_tokens", C.c_int), ("no_embed_class", C.c_int), ("mlp_type", C.c_int), ("head_dim", C.c_int),
                 ("attn_scale", C.c_float), ("pre_norm", C.c_int), ("act", C.c_int), ("proj_dim", C.c_int), ("rope", C.c_int)]
+
+    def __init__(self, *args, **kw):
+        super().__init__(C.sizeof(type(self)), *args, **kw)
 
 
 # name -> (restype, argtypes); every symbol include/atlaspatch_hip.h declares
@@ -62,6 +70,8 @@ SIGNATURES = {
                                    C.c_void_p]),
     "ap_tile_content_counts": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                          C.c_void_p]),
+    "ap_sizeof_vit_config": (C.c_size_t, []),
+    "ap_vit_config_init": (C.c_int, [C.POINTER(VitConfig), C.c_size_t]),
     "ap_vit_create": (C.c_int, [C.POINTER(VitConfig), C.POINTER(C.c_void_p)]),
     "ap_vit_destroy": (None, [C.c_void_p]),
     "ap_vit_set_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t]),
@@ -164,6 +174,11 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        got = lib.ap_abi_version()
+        if got != ABI_VERSION or lib.ap_sizeof_vit_config() != C.sizeof(VitConfig):
+            raise HipLibraryError(
+                f"{path} reports ABI {got} with a {lib.ap_sizeof_vit_config()}-byte ap_vit_config; this binding is written "
+                f"for ABI {ABI_VERSION} / {C.sizeof(VitConfig)} bytes (include/atlaspatch_hip.h). Rebuild the library.")
         _lib = lib
         return _lib
 

@@ -25,7 +25,7 @@ void set_error(const char* fmt, ...) {
 
 extern "C" {
 
-int ap_abi_version(void) { return 19; }
+int ap_abi_version(void) { return AP_ABI_VERSION; }
 
 const char* ap_last_error(void) { return ap::g_error; }
 

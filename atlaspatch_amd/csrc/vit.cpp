@@ -590,9 +590,41 @@ int check_forward_args(const ap_vit* m, int n, const void* in, const float* out,
 
 extern "C" {
 
+size_t ap_sizeof_vit_config(void) { return sizeof(ap_vit_config); }
+
+int ap_vit_config_init(ap_vit_config* cfg, size_t sizeof_caller) {
+    AP_REQUIRE(cfg, "vit_config_init: null argument");
+    AP_REQUIRE(sizeof_caller >= AP_VIT_CONFIG_SIZE_V20 && sizeof_caller % 4 == 0 && sizeof_caller <= 4096,
+               "vit_config_init: %zu is not the size of an ap_vit_config (ABI v20: %u bytes, this library: %zu)", sizeof_caller,
+               AP_VIT_CONFIG_SIZE_V20, sizeof(ap_vit_config));
+    memset(cfg, 0, sizeof_caller);
+    cfg->struct_size = (uint32_t)sizeof_caller;
+    return AP_OK;
+}
+
 int ap_vit_create(const ap_vit_config* cfg, ap_vit** out) {
     AP_REQUIRE(cfg && out, "vit_create: null argument");
-    const ap_vit_config& c = *cfg;
+    static_assert(sizeof(ap_vit_config) == AP_VIT_CONFIG_SIZE_V20, "ap_vit_config grew: append only, keep AP_VIT_CONFIG_SIZE_V20, and drop this assert");
+    // ---- growth-safe hand-over (ABI v20): never read a byte the caller did not declare, and only sizes this structure has had.
+    // A binding written for ABI <= 19 (no size member, image_size first) presents 224 / 448 / 518 here: refused unread.
+    static const size_t known_sizes[] = {AP_VIT_CONFIG_SIZE_V20};          // append sizeof(ap_vit_config) of every later ABI
+    const size_t given = cfg->struct_size;
+    bool known = false;
+    for (size_t k : known_sizes) known = known || given == k;
+    if (!known && given > sizeof(ap_vit_config) && given % 4 == 0 && given <= 4096 && (given - sizeof(ap_vit_config)) <= 64) {
+        ap::set_error("vit_create: cfg->struct_size = %zu is larger than this library's ap_vit_config (%zu bytes, ABI %d): the binding was "
+                      "generated from a newer include/atlaspatch_hip.h than the library was built from", given, sizeof(ap_vit_config),
+                      AP_ABI_VERSION);
+        return AP_ERR_UNSUPPORTED;
+    }
+    AP_REQUIRE(known,
+               "vit_create: cfg->struct_size = %zu is not a size ap_vit_config has had (ABI v20: %u bytes; this library: %zu): fill the "
+               "structure with ap_vit_config_init(&cfg, sizeof cfg); a binding written for ABI <= 19 (no struct_size member, "
+               "image_size first) must be regenerated from include/atlaspatch_hip.h", given, AP_VIT_CONFIG_SIZE_V20, sizeof(ap_vit_config));
+    ap_vit_config c;
+    memset(&c, 0, sizeof(c));
+    memcpy(&c, cfg, given < sizeof(c) ? given : sizeof(c));        // an older caller's missing tail stays zero = the old behaviour
+    c.struct_size = (uint32_t)sizeof(c);
     AP_REQUIRE(c.image_size > 0 && c.patch_size > 0 && c.image_size % c.patch_size == 0,
                "vit_create: image %d / patch %d", c.image_size, c.patch_size);
     AP_REQUIRE(c.patch_size >= 4 && c.patch_size <= 32 && c.patch_size % 2 == 0,
@@ -837,6 +869,9 @@ int ap_vit_finalize(ap_vit* m) {
         int prc = ap::launch_prefix_build(m->cls, vec("reg_tokens"), m->cfg.reg_tokens, m->cfg.no_embed_class ? nullptr : m->pos,
                                           m->cfg.dim, m->prefix_dev, nullptr);
         if (prc != AP_OK) return prc;
+        // the build ran on the legacy stream: a first forward on a non-blocking stream is not ordered behind it, and two of
+        // the three ways out of this function (float32; nothing to fold again) used to return without waiting
+        AP_HIP_CHECK(hipDeviceSynchronize());
     }
     m->blocks.resize(m->cfg.depth);
     for (int i = 0; i < m->cfg.depth; ++i) {

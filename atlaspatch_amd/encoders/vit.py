@@ -11,6 +11,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import re
 import logging
 import os
 from pathlib import Path
@@ -84,7 +85,8 @@ TRANSFORM_NORM = {
     "clip_vit_l_14": (OPENAI_CLIP_MEAN, OPENAI_CLIP_STD), "clip_vit_l_14_336": (OPENAI_CLIP_MEAN, OPENAI_CLIP_STD),
     "plip": (OPENAI_CLIP_MEAN, OPENAI_CLIP_STD), "quilt_b_32": (OPENAI_CLIP_MEAN, OPENAI_CLIP_STD),
     "quilt_b_16": (OPENAI_CLIP_MEAN, OPENAI_CLIP_STD), "biomedclip": (OPENAI_CLIP_MEAN, OPENAI_CLIP_STD),
-    "dinov3_vitl16_sat": ((0.430, 0.411, 0.296), (0.213, 0.156, 0.143)),        # the satellite checkpoints' statistics
+    "dinov3_vitl16_sat": ((0.430, 0.411, 0.296), (0.213, 0.156, 0.143)),        # the satellite (SAT-493M) checkpoints' statistics
+    "dinov3_vit7b16_sat": ((0.430, 0.411, 0.296), (0.213, 0.156, 0.143)),       # (their AutoImageProcessor config, dinov3.py:39-41)
     "midnight": ((0.5, 0.5, 0.5), (0.5, 0.5, 0.5)),                                                   # midnight.py:22
     "h_optimus_0": ((0.707223, 0.578729, 0.703617), (0.211883, 0.230117, 0.177517)),                  # hoptimus.py:24-27
     "h_optimus_1": ((0.707223, 0.578729, 0.703617), (0.211883, 0.230117, 0.177517)),
@@ -230,7 +232,9 @@ def _detect_source(sd: dict) -> str:
         return "hf_clip"
     if "visual.ln_pre.weight" in keys or "ln_pre.weight" in keys:
         return "open_clip"
-    if any(k.startswith("model.layer.") and k.endswith("attention.q_proj.weight") for k in keys) and "embeddings.cls_token" in keys:
+    # DINOv3ViTModel: `model.layer.<i>.` in memory (transformers 5), `layer.<i>.` in the published model.safetensors
+    # (transformers renames on load: conversion_mapping `(?<!model\.)layer.` -> `model.layer.`); accept both
+    if any(re.match(r"(model\.)?layer\.\d+\.attention\.q_proj\.weight$", k) for k in keys) and "embeddings.cls_token" in keys:
         return "hf_dinov3"
     if "embeddings.register_tokens" in keys or any(".layer_scale1.lambda1" in k for k in keys):
         return "hf_dinov2"
@@ -402,8 +406,9 @@ def canonical_state_dict(sd: dict, *, depth: int, layer_scale: bool, source: str
         put("norm.weight", sd["norm.weight"]); put("norm.bias", sd["norm.bias"])
         cos, sin = dinov3_rope_tables(int(grid), d // int(heads), rope_theta)
         put("rope.cos", cos); put("rope.sin", sin)
+        root = "model.layer." if any(k.startswith("model.layer.") for k in sd) else "layer."      # in-memory / on-disk names
         for i in range(depth):
-            p, b = f"model.layer.{i}.", f"blocks.{i}."
+            p, b = f"{root}{i}.", f"blocks.{i}."
             a = p + "attention."
             zeros = torch.zeros(d)
             bias = lambda n: sd[a + n + ".bias"] if a + n + ".bias" in sd else zeros

@@ -9,7 +9,11 @@ interpreter lock for the Python part, next to a SAM2 forward of 5 ms per slide. 
 only -- the passports arrive formatted, so the HIP library is not loaded: 0.3 s to start, side by side, in the background).  A job
 = the ``H5PatchWriter`` keyword arguments, the output path, the int32 [N, 5] coords and their S160 passports; the child runs the
 very same ``H5PatchWriter.write_coords_array`` -> identical bytes on disk (tests/test_host_logic.py).  Any failure to start or
-talk to a child makes the caller write in-process instead.
+talk to a child makes the caller write in-process instead: a child that does not answer within ``ATLASPATCH_H5_PROC_TIMEOUT``
+seconds (default 60: an NFS stall, a stopped process) is killed by a watchdog, which turns the blocked pipe I/O into an error; a
+child that REPORTS a write error stays in the pool and the caller retries the write in-process, where the exception (if it is
+real) surfaces with its own traceback; a dead child is replaced in the background, so one failure does not send the rest of the
+run in-process.
 
 Protocol (stdin / stdout of the child, binary): 8-byte little-endian length + pickle of {"kwargs", "path", "rows"} followed by
 rows * 20 bytes of coords and rows * 160 bytes of passports; reply: 8-byte length + pickle of {"ok": n} or {"error": text}.
@@ -51,6 +55,41 @@ def _recv(stream):
     return pickle.loads(_read_exact(stream, n))
 
 
+def _timeout() -> float:
+    try:
+        return max(1.0, float(os.environ.get("ATLASPATCH_H5_PROC_TIMEOUT", "60")))
+    except ValueError:
+        return 60.0
+
+
+class _Watchdog:
+    """Kills ``proc`` when the guarded section takes longer than ``seconds``: the blocked read / write then fails with EOF /
+    EPIPE and the caller falls back.  (select() on the pipes would cover reads only; a 10-MB job also blocks in write.)"""
+
+    def __init__(self, proc, seconds: float) -> None:
+        self.fired = False
+        self._timer = threading.Timer(seconds, self._fire, args=(proc,))
+        self._timer.daemon = True
+
+    def _fire(self, proc) -> None:
+        self.fired = True
+        try:
+            proc.kill()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def __enter__(self):
+        self._timer.start()
+        return self
+
+    def __exit__(self, *exc) -> None:
+        self._timer.cancel()
+
+
+class ChildWriteError(RuntimeError):
+    pass
+
+
 class _Worker:
     def __init__(self) -> None:
         env = dict(os.environ)
@@ -59,17 +98,26 @@ class _Worker:
         env["PYTHONPATH"] = root + (os.pathsep + env["PYTHONPATH"] if env.get("PYTHONPATH") else "")
         self.proc = subprocess.Popen([sys.executable, "-m", "atlaspatch_amd.services.h5_writer_proc"], stdin=subprocess.PIPE,
                                      stdout=subprocess.PIPE, env=env, close_fds=True)
-        hello = _recv(self.proc.stdout)
-        if hello.get("ready") is not True:
-            raise RuntimeError(f"h5 writer did not start: {hello}")
+        try:
+            with _Watchdog(self.proc, _timeout()):
+                hello = _recv(self.proc.stdout)
+            if hello.get("ready") is not True:
+                raise RuntimeError(f"h5 writer did not start: {hello}")
+        except BaseException:
+            self.proc.kill()                                  # never leave a half-started child behind
+            self.proc.wait()
+            raise
 
     def write(self, kwargs: dict, path: str, coords: np.ndarray, passports: np.ndarray) -> int:
-        _send(self.proc.stdin, {"kwargs": kwargs, "path": path, "rows": int(coords.shape[0])}, coords.tobytes())
-        self.proc.stdin.write(memoryview(passports).cast("B"))
-        self.proc.stdin.flush()
-        reply = _recv(self.proc.stdout)
+        """-> rows written; raises ``ChildWriteError`` when the child reports a failed write (it is still healthy), an I/O error
+        when the child is gone or was killed by the watchdog."""
+        with _Watchdog(self.proc, _timeout()):
+            _send(self.proc.stdin, {"kwargs": kwargs, "path": path, "rows": int(coords.shape[0])}, coords.tobytes())
+            self.proc.stdin.write(memoryview(passports).cast("B"))
+            self.proc.stdin.flush()
+            reply = _recv(self.proc.stdout)
         if "error" in reply:
-            raise RuntimeError(f"h5 writer process: {reply['error']}")
+            raise ChildWriteError(reply["error"])
         return int(reply["ok"])
 
     def close(self) -> None:
@@ -80,6 +128,10 @@ class _Worker:
                 self.proc.wait(timeout=5)
         except Exception:  # noqa: BLE001
             self.proc.kill()
+        try:
+            self.proc.wait(timeout=5)
+        except Exception:  # noqa: BLE001
+            pass
 
 
 class H5WriterPool:
@@ -94,15 +146,12 @@ class H5WriterPool:
         self._starting = False
         self._lock = threading.Lock()
         self._closed = False
-        self.broken = False
+        self.broken = False                           # the LAST start attempt failed (cleared by the next successful one)
         self.jobs = 0
+        self.child_errors = 0                         # jobs a child reported as failed (retried in-process by the caller)
+        self.restarts = 0
 
-    def prestart(self) -> None:
-        with self._lock:
-            if self._starting or self._closed:
-                return
-            self._starting = True
-
+    def _start_one(self, name: str) -> None:
         def run():
             if self._closed:
                 return
@@ -113,9 +162,21 @@ class H5WriterPool:
                 return
             with self._lock:
                 self._ready += 1
-            self._idle.put(w)
+                self.broken = False
+                closed = self._closed
+            if closed:
+                w.close()
+            else:
+                self._idle.put(w)
+        threading.Thread(target=run, name=name, daemon=True).start()
+
+    def prestart(self) -> None:
+        with self._lock:
+            if self._starting or self._closed:
+                return
+            self._starting = True
         for k in range(self.workers):                 # the interpreters start side by side
-            threading.Thread(target=run, name=f"h5-writer-start-{k}", daemon=True).start()
+            self._start_one(f"h5-writer-start-{k}")
 
     def ready(self) -> bool:
         """True once at least one child answers (before that a caller should not even format passports for it)."""
@@ -129,7 +190,7 @@ class H5WriterPool:
             pass
         with self._lock:
             ready = self._ready
-        if ready == 0 or self.broken:
+        if ready == 0:
             self.prestart()
             return None                               # nobody has started yet: do not wait for an interpreter
         try:
@@ -149,15 +210,19 @@ class H5WriterPool:
         try:
             n = w.write(kwargs, path, np.ascontiguousarray(coords, dtype=np.int32).reshape(-1, 5),
                         np.ascontiguousarray(passports))
-        except (EOFError, BrokenPipeError, OSError, struct.error, pickle.UnpicklingError):
-            self.broken = True
-            with self._lock:
+        except ChildWriteError:
+            self.child_errors += 1
+            self._idle.put(w)                         # the child is healthy; the caller repeats the write in-process, where a real
+            return None                               # error raises with its own traceback (like every other failure mode here)
+        except (EOFError, BrokenPipeError, OSError, ValueError, struct.error, pickle.UnpicklingError):
+            with self._lock:                          # the child died, hung (watchdog) or desynchronised: replace it
                 self._ready -= 1
+                self.restarts += 1
+                n_restart = self.restarts
             w.close()
+            if not self._closed and n_restart <= 4 * self.workers:      # a child that can never start must not respawn forever
+                self._start_one(f"h5-writer-restart-{n_restart}")
             return None
-        except Exception:
-            self._idle.put(w)                         # the child reported a write error: it is still healthy
-            raise
         self.jobs += 1
         self._idle.put(w)
         return n
@@ -197,8 +262,13 @@ def shared_pool(create: bool = True):
 
 def _serve() -> None:
     from .storage import H5PatchWriter
-    stdin, stdout = sys.stdin.buffer, sys.stdout.buffer
-    sys.stdout = sys.stderr                          # nothing but protocol frames may reach the pipe
+    # nothing but protocol frames may reach the pipe: the protocol gets a private duplicate of fd 1, and fd 1 itself -- which
+    # C libraries (libhdf5's error stack, a stray printf) write to behind Python's back -- is pointed at stderr
+    stdin = sys.stdin.buffer
+    sys.stdout.flush()
+    stdout = os.fdopen(os.dup(1), "wb")
+    os.dup2(2, 1)
+    sys.stdout = sys.stderr
     try:                                             # load libhdf5 BEFORE saying hello: the first job would otherwise pay for it
         import tempfile
         with tempfile.TemporaryDirectory() as tmp:

@@ -59,7 +59,7 @@ int main(int argc, char** argv) {
     char name[128];
     int cus = 0;
     size_t hbm = 0;
-    if (ap_abi_version() != 19) { fprintf(stderr, "ABI %d, header is 19\n", ap_abi_version()); return 1; }
+    if (ap_abi_version() != AP_ABI_VERSION) { fprintf(stderr, "ABI %d, header is %d\n", ap_abi_version(), AP_ABI_VERSION); return 1; }
     CHECK(ap_device_info(0, name, (int)sizeof(name), &cus, &hbm));
     fprintf(stderr, "device 0: %s, %d CUs, %.0f GB\n", name, cus, (double)hbm / 1e9);
 
@@ -98,7 +98,7 @@ int main(int argc, char** argv) {
         double sum = 0.0;
         int b;
         char key[96];
-        memset(&cfg, 0, sizeof(cfg));
+        CHECK(ap_vit_config_init(&cfg, sizeof(cfg)));
         cfg.image_size = 224; cfg.patch_size = 16; cfg.dim = dim; cfg.depth = depth; cfg.heads = 12; cfg.mlp_dim = mlp;
         cfg.ln_eps = 1e-6f; cfg.compute_dtype = AP_F16; cfg.pool = AP_POOL_CLS; cfg.pool_ln_eps = 1e-5f;
         CHECK(ap_vit_create(&cfg, &m));

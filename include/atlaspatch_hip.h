@@ -38,7 +38,8 @@ extern "C" {
 typedef void* ap_stream_t;
 
 /* ---- library ---------------------------------------------------------------------- */
-int ap_abi_version(void);                 /* bumps when a signature changes */
+#define AP_ABI_VERSION 20                 /* what THIS header declares; compare with ap_abi_version() before any other call */
+int ap_abi_version(void);                 /* bumps when a signature or a struct layout changes */
 const char* ap_last_error(void);          /* thread-local text of the last failure */
 int ap_device_info(int device, char* name, int name_cap, int* cu_count, size_t* hbm_bytes);
 
@@ -169,7 +170,19 @@ int ap_tile_content_counts(const uint8_t* tiles, int n, int h, int w, int black_
  * blocks (packed-QKV MHA, erf-GELU MLP, optional LayerScale), final LN, CLS token. */
 typedef struct ap_vit ap_vit;
 
+/* ABI v20: the structure is growth-safe.  Its first member is its own size as the CALLER compiled it; new fields are only
+ * ever appended and all-zero always means "the behaviour before the field existed".  ap_vit_create reads exactly
+ * struct_size bytes and accepts only sizes this structure has had in some ABI version:
+ *   struct_size == ap_sizeof_vit_config()            the caller and the library agree;
+ *   an earlier ABI's size (>= AP_VIT_CONFIG_SIZE_V20)  an older caller: the fields it does not know are taken as zero;
+ *   struct_size > ap_sizeof_vit_config()               a newer caller on an older library: AP_ERR_UNSUPPORTED, unread;
+ *   anything else                                      AP_ERR_INVALID, unread -- in particular a binding written for ABI <= 19,
+ *                                                      whose structure had no size member and started with image_size
+ *                                                      (224, 448, 518: never a size of this structure).
+ * Fill the structure through ap_vit_config_init (C: `ap_vit_config_init(&cfg, sizeof cfg)`; ctypes:
+ * `lib.ap_vit_config_init(byref(cfg), sizeof(cfg))`) and a binding can never hand over an uninitialised tail. */
 typedef struct ap_vit_config {
+    uint32_t struct_size; /* sizeof(ap_vit_config) as the caller sees it; written by ap_vit_config_init */
     int image_size;      /* 224 */
     int patch_size;      /* 16 */
     int dim;             /* 768 / 1024 */
@@ -217,6 +230,11 @@ typedef struct ap_vit_config {
                             rope.cos | rope.sin f32 [patches, head_dim] (the host builds them as the HF module does);
                             head_dim must be the true head width */
 } ap_vit_config;
+#define AP_VIT_CONFIG_SIZE_V20 92u   /* struct_size + the 22 fields of ABI v19: the smallest size ap_vit_create accepts */
+size_t ap_sizeof_vit_config(void);   /* sizeof(ap_vit_config) inside the library */
+/* Zero-fills sizeof_caller bytes at cfg and records sizeof_caller in cfg->struct_size.  AP_ERR_INVALID when cfg is NULL,
+ * sizeof_caller < AP_VIT_CONFIG_SIZE_V20 or not a multiple of 4. */
+int ap_vit_config_init(ap_vit_config* cfg, size_t sizeof_caller);
 #define AP_ACT_GELU 0
 #define AP_ACT_QUICK_GELU 1
 #define AP_MLP_GELU 0
@@ -225,6 +243,7 @@ typedef struct ap_vit_config {
 #define AP_POOL_ATTN 1
 #define AP_POOL_CLS_MEAN 2
 
+/* Validates cfg->struct_size as described above, then every field; *out is written only on success. */
 int ap_vit_create(const ap_vit_config* cfg, ap_vit** out);
 void ap_vit_destroy(ap_vit* m);
 
@@ -239,7 +258,13 @@ void ap_vit_destroy(ap_vit* m);
  *   attn_pool.ln_k.weight|bias [dim]   attn_pool.kv.weight [2P, dim] (rows k_proj; v_proj)   attn_pool.kv.bias [2P]
  *   attn_pool.q [P]  (the projected query q_proj(ln_q(query)) + bias: input independent, computed by the host)
  *   attn_pool.out.weight [P, P] | .bias [P]   attn_pool.ln_out.weight|bias [P]
- * Synchronous (copies before returning). */
+ * Synchronous (copies before returning).
+ * Every upload that a derived buffer depends on UN-FINALISES the object -- forwards return AP_ERR_STATE until
+ * ap_vit_finalize succeeds again:
+ *   cls_token, reg_tokens, pos_embed   (since ABI v17; before it a class-token upload took effect at once) the prefix rows
+ *                                      "class / register token + its position row" are built by ap_vit_finalize;
+ *   pos_embed, blocks.*                f16 / bf16: the folded weights / the T copy of pos_embed are stale (see ap_vit_finalize).
+ * patch_embed.*, norm.*, pre_norm.*, rope.*, head_proj.weight and attn_pool.* take effect immediately. */
 int ap_vit_set_param(ap_vit* m, const char* name, const float* host, size_t count);
 /* n parameters in one call (same semantics as n ap_vit_set_param calls, in order; stops at the first error) */
 int ap_vit_set_params(ap_vit* m, const char* const* names, const float* const* host, const size_t* counts, int n);

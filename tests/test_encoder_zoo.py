@@ -153,6 +153,14 @@ def test_oracle_matches_hf_dinov3_with_the_rotary_embedding(gated):
     tok = vit_oracle.vit_tokens_canonical(sd, x, heads=2, depth=2, eps=1e-5)
     assert _rel(tok.numpy(), out.last_hidden_state.numpy()) <= 2e-6
     assert _rel(tok[:, 0].numpy(), out.pooler_output.numpy()) <= 2e-6
+    # the published facebook/dinov3-* model.safetensors carry `layer.<i>.` where the in-memory module says `model.layer.<i>.`
+    # (transformers renames on load); a checkpoint read raw from disk must be recognised and give the same canonical tensors
+    disk = {(k[len("model."):] if k.startswith("model.layer.") else k): v for k, v in model.state_dict().items()}
+    assert any(k.startswith("layer.0.") for k in disk) and not any(k.startswith("model.") for k in disk)
+    from atlaspatch_amd.encoders.vit import _detect_source
+    assert _detect_source(disk) == "hf_dinov3"
+    sd_disk = canonical_state_dict(disk, depth=2, layer_scale=True, grid=4, heads=2)
+    assert sd_disk.keys() == sd.keys() and all(torch.equal(sd_disk[k], sd[k]) for k in sd)
 
 
 def test_mlp_padding_leaves_the_function_unchanged():

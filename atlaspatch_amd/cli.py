@@ -84,6 +84,11 @@ _FEATURE = [
     click.option("--feature-plugin", "feature_plugins", type=click.Path(exists=True), multiple=True,
                  help="Path(s) to Python modules that register custom feature extractors via "
                       "register_feature_extractors(registry, device, dtype, num_workers)."),
+    # MI355X addition (not a reference option): under torch.distributed.run, slides are sharded one per rank and this adds the
+    # ONE collective of the path -- an RCCL all-gather-v of the per-slide feature matrices -> <out>/features_all/<extractor>.npy
+    click.option("--gather-features/--no-gather-features", "gather_features", default=None,
+                 help="Multi-GPU runs only: reassemble the rank-sharded feature matrices on rank 0 with one RCCL all-gather "
+                      "(<out>/features_all/<extractor>.npy + index.json). Default: the ATLASPATCH_GATHER_FEATURES environment variable."),
 ]
 
 
@@ -101,7 +106,7 @@ def _pick_segmenter(app_cfg: AppConfig):
 def _run_pipeline(*, wsi_path, output, patch_size, step_size, target_mag, device, tissue_thresh, white_thresh,
                   black_thresh, seg_batch_size, write_batch, patch_workers, max_open_slides, fast_mode, save_images,
                   visualize_grids, visualize_mask, visualize_contours, recursive, mpp_csv, skip_existing, verbose,
-                  feature_cfg=None, registry=None):
+                  feature_cfg=None, registry=None, gather_features=None):
     logging.getLogger().setLevel(logging.DEBUG if verbose else logging.WARNING)
     seg_yaml = Path(__file__).resolve().parent / "configs" / "sam2.1_hiera_t.yaml"
     app_cfg = AppConfig(
@@ -119,6 +124,9 @@ def _run_pipeline(*, wsi_path, output, patch_size, step_size, target_mag, device
         visualization=VisualizationConfig(), features=feature_cfg, device=device.lower()).validated()
 
     rank, world, local_rank = env_rank_world()
+    if gather_features is None:
+        gather_features = bool(os.environ.get("ATLASPATCH_GATHER_FEATURES"))
+    gather_features = bool(gather_features) and world > 1
     if world > 1 and torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
     segmenter = _pick_segmenter(app_cfg)
@@ -130,7 +138,8 @@ def _run_pipeline(*, wsi_path, output, patch_size, step_size, target_mag, device
                               show_progress=not verbose, rank=rank, world_size=world)
     service = None
     if app_cfg.features is not None:
-        service = PatchFeatureEmbeddingService(app_cfg.extraction, app_cfg.output, app_cfg.features, registry=registry)
+        service = PatchFeatureEmbeddingService(app_cfg.extraction, app_cfg.output, app_cfg.features, registry=registry,
+                                               keep_feature_blocks=gather_features)
         service.prefetch_extractor()         # the first encoder is built on a side thread while phase 1 runs
     try:
         with stage("phase1_segment_and_coords"):
@@ -147,7 +156,7 @@ def _run_pipeline(*, wsi_path, output, patch_size, step_size, target_mag, device
                 failures.extend(service.embed_all(results, wsi_loader=loader, progress=bar))
         finally:
             bar.close()
-        if world > 1 and os.environ.get("ATLASPATCH_GATHER_FEATURES"):
+        if gather_features:
             # MI355X addition (north star): one RCCL all-gather-v reassembles the rank-sharded feature matrices
             from .orchestration.dispatch import gather_run_features, init_process_group
             dev = torch.device("cuda", local_rank) if torch.cuda.is_available() else None
@@ -195,7 +204,7 @@ segment_and_get_coords = cli.command(name="segment-and-get-coords",
 
 
 def _process(*, feature_device, feature_extractors, feature_batch_size, feature_num_workers, feature_precision,
-             feature_plugins, **kw):
+             feature_plugins, gather_features=None, **kw):
     feat_device = (feature_device or kw["device"]).lower()
     torch_device = torch.device(feat_device)
     dtype = resolve_feature_dtype(torch_device, feature_precision.lower())
@@ -207,7 +216,7 @@ def _process(*, feature_device, feature_extractors, feature_batch_size, feature_
     feature_cfg = FeatureExtractionConfig(extractors=names, batch_size=feature_batch_size, device=feat_device,
                                           num_workers=feature_num_workers, precision=feature_precision.lower(),
                                           plugins=[Path(p) for p in feature_plugins])
-    results, failures = _run_pipeline(feature_cfg=feature_cfg, registry=registry, **kw)
+    results, failures = _run_pipeline(feature_cfg=feature_cfg, registry=registry, gather_features=gather_features, **kw)
     _echo_results(results, failures, kw["verbose"], feature_cfg)
 
 

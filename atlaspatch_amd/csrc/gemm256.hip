@@ -108,6 +108,27 @@ struct Cursor {
     uint32_t xo[2], yo[2]; // per-lane byte offsets of the two 64-row rounds of this stream's X / Y unit
 };
 
+// The 16-byte output-row stores.  NT = non-temporal hint: measured (round 5, twin A/B on the ViT-B shapes, 2048 tiles) -2 ... -3 %
+// on the plain-store epilogues (qkv: its 3.6 MB of output per 32-tile wave of an XCD is read next by another kernel, from
+// HBM either way, and without the hint it evicts the weight and activation panels the XCD is re-reading), +-0.5 % on fc1 /
+// proj / fc2, which keep the default policy.  sc1 (write through, drop the line) measured the same as nt on qkv and slightly
+// worse elsewhere.  The s_nop: a store of more than 8 bytes followed by a write of its data registers needs wait states
+// that the compiler inserts for its own stores only (without it the 140-case bit-equality check fails).
+#if defined(AP_EXP_STORE_SC1)
+#define AP_STORE_ASM "global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1"
+#else
+#define AP_STORE_ASM "global_store_dwordx4 %0, %1, off nt\n\ts_nop 1"
+#endif
+template <bool NT> __device__ __forceinline__ void out_store16(void* p, u32x4 v) {
+#if defined(AP_EXP_STORE_PLAIN)
+    *(u32x4*)p = v;
+#else
+    if constexpr (NT) asm volatile(AP_STORE_ASM ::"v"(p), "v"(v) : "memory");
+    else *(u32x4*)p = v;
+#endif
+}
+#define AP_OUT_STORE(PTR, V) out_store16<kStoreNT>((PTR), (V))
+
 template <typename T, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) char smem[kLdsBytes];
@@ -116,6 +137,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
     constexpr bool kSwiglu = EPI == EPI_NORM_SWIGLU;       // x1 | x2 in the wave's two n blocks -> 32 gated output columns
     constexpr bool kPatch = EPI == EPI_PATCH_STREAM;
     constexpr bool kRes = EPI == EPI_RESID_STATS || kPatch;
+#if defined(AP_EXP_STORE_ALL)
+    constexpr bool kStoreNT = true;
+#else
+    constexpr bool kStoreNT = !kRes && EPI != EPI_BIAS_RESID;       // every epilogue whose 16-bit output another kernel reads next
+#endif
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -314,10 +340,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
 #define AP_NOHOIST()
 #endif
 
+    // (the loop of rounds 2-4: still what EPI_PATCH_STREAM runs -- its epilogue keeps more registers live across the K loop and
+    //  the pipelined form below would spill 5-11 of them -- and, with -DAP_G256_OLD_LOOP, every instantiation, for A/B)
     // wait = false only for the first K-tile after an epilogue: everything staged before the epilogue
     // was drained there (vmcnt(0)), so its four phases need no counted wait and the epilogue's own
     // stores keep draining under them.
-    auto ktile = [&](auto bufc, const bool wait) {
+    [[maybe_unused]] auto ktile = [&](auto bufc, const bool wait) {
         constexpr int BUF = decltype(bufc)::value;
         const char* buf = smem + BUF * kBufBytes;
         // ---------------- phase 0: (X0, Y0), stage Y1 of the next K-tile
@@ -376,7 +404,116 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
         AP_MMA(acc[0][2], fb0[3], fa[0][3]); AP_MMA(acc[0][3], fb0[3], fa[1][3]);
     };
 
+#ifdef AP_G256_OLD_LOOP
+    constexpr bool kOldLoop = true;
+#else
+    constexpr bool kOldLoop = kPatch;
+#endif
+    // Software-pipelined fragment reads (round 5; -DAP_G256_OLD_LOOP selects the loop of rounds 2-4 for A/B): the reads of a phase are issued BETWEEN the MFMAs of the phase before it, each as soon
+    // as the last MFMA that uses its destination register has been issued (program order pinned with sched_barrier), so every
+    // phase opens with MFMAs whose operands arrived long ago instead of with all eight waves' ds_read burst and the
+    // latency of its first reply.  Nothing is read earlier than one barrier after the wait that retired its staging (same
+    // argument as above: Y1 of this K-tile behind this K-tile's phase-0 barrier, X1 behind its phase-1 barrier, X0 / Y0 of the
+    // NEXT K-tile behind its phase-3 barrier), and units are re-staged no earlier than before.  FIRST: the K-tile that opens a
+    // tile reads its phase-0 fragments up front (the fragment registers are the epilogue's scratch between tiles);
+    // PREFETCH = false: the K-tile that closes a tile reads nothing ahead.
+#define AP_SB() __builtin_amdgcn_sched_barrier(0)
+    // Measured on top of this form and dropped (round 5, profiles/r05b_gemm_twin_ab.txt): barriers only in front of phases 1 and 3
+    // (-1 ... +0.5 %: with the operands already in registers the barriers cost nothing -- the twin's no-barrier ablation is
+    // SLOWER than the product), and the two waves of a SIMD issuing a phase's LDS-DMA two MFMA pairs apart (+1 ... +3 %).
+#define AP_SYNC_EVEN() AP_PHASE_SYNC()
+#define AP_SYNC_1() AP_PHASE_SYNC()
+#define AP_SYNC_3() AP_PHASE_SYNC()
+#define AP_STAGE_EARLY(...) { __VA_ARGS__; }
+#define AP_STAGE_LATE(...)
+#ifndef AP_G256_NO_ADDR2
+    // fragment addresses of both K-tile buffers in registers (the second buffer starts past ds_read's 16-bit offset field:
+    // without these every read of it is preceded by a v_add / v_or in the MFMA stream)
+    int pa1[4], pb1[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { pa1[kk] = pa[kk] + kBufBytes; pb1[kk] = pb[kk] + kBufBytes; }
+#define AP_PA(B, kk) ((B) ? pa1[kk] : pa[kk])
+#define AP_PB(B, kk) ((B) ? pb1[kk] : pb[kk])
+#define AP_FRAG(B, UNIT_OFF, P) (*(const Frag*)(smem + (UNIT_OFF) + (P)))
+#else
+#define AP_PA(B, kk) ((B) * kBufBytes + pa[kk])
+#define AP_PB(B, kk) ((B) * kBufBytes + pb[kk])
+#define AP_FRAG(B, UNIT_OFF, P) (*(const Frag*)(smem + (UNIT_OFF) + (P)))
+#endif
+    [[maybe_unused]] auto ktile_p = [&](auto bufc, auto firstc, auto prefc, const bool wait) {
+        constexpr int BUF = decltype(bufc)::value, NBUF = BUF ^ 1;
+        constexpr bool FIRST = decltype(firstc)::value, PREFETCH = decltype(prefc)::value;
+        // ---------------- phase 0: (X0, Y0), stage Y1 of the next K-tile; read Y1 of this one
+        if constexpr (FIRST) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                fb0[kk] = AP_FRAG(BUF, U_Y0 * kUnitBytes, AP_PB(BUF, kk));
+                fa[0][kk] = AP_FRAG(BUF, U_X0 * kUnitBytes, AP_PA(BUF, kk));
+                fa[1][kk] = AP_FRAG(BUF, U_X0 * kUnitBytes + 32 * kRowBytes, AP_PA(BUF, kk));
+            }
+        }
+        AP_SYNC_EVEN();
+        AP_MMA(acc[0][0], fb0[0], fa[0][0]); AP_MMA(acc[0][1], fb0[0], fa[1][0]);
+        AP_STAGE_EARLY(stage(cb, false, NBUF, U_Y1));
+        AP_SB();
+        fb1[0] = AP_FRAG(BUF, U_Y1 * kUnitBytes, AP_PB(BUF, 0));
+        fb1[1] = AP_FRAG(BUF, U_Y1 * kUnitBytes, AP_PB(BUF, 1));
+        AP_SB();
+        AP_MMA(acc[0][0], fb0[1], fa[0][1]); AP_MMA(acc[0][1], fb0[1], fa[1][1]);
+        AP_SB();
+        fb1[2] = AP_FRAG(BUF, U_Y1 * kUnitBytes, AP_PB(BUF, 2));
+        fb1[3] = AP_FRAG(BUF, U_Y1 * kUnitBytes, AP_PB(BUF, 3));
+        AP_SB();
+        AP_MMA(acc[0][0], fb0[2], fa[0][2]); AP_MMA(acc[0][1], fb0[2], fa[1][2]);
+        AP_STAGE_LATE(stage(cb, false, NBUF, U_Y1));
+        AP_MMA(acc[0][0], fb0[3], fa[0][3]); AP_MMA(acc[0][1], fb0[3], fa[1][3]);
+        // ---------------- phase 1: (X0, Y1), stage X1 of the next K-tile; read X1 of this one into fa as its registers free up
+        AP_SYNC_1();
+        AP_MMA(acc[1][0], fb1[0], fa[0][0]); AP_MMA(acc[1][1], fb1[0], fa[1][0]);
+        AP_STAGE_EARLY(stage(cb, true, NBUF, U_X1); advance(cb, 1));
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            AP_SB();
+            fa[0][kk] = AP_FRAG(BUF, U_X1 * kUnitBytes, AP_PA(BUF, kk));
+            fa[1][kk] = AP_FRAG(BUF, U_X1 * kUnitBytes + 32 * kRowBytes, AP_PA(BUF, kk));
+            AP_SB();
+            if (kk < 3) { AP_MMA(acc[1][0], fb1[kk + 1], fa[0][kk + 1]); AP_MMA(acc[1][1], fb1[kk + 1], fa[1][kk + 1]); }
+            if (kk == 1) { AP_STAGE_LATE(stage(cb, true, NBUF, U_X1); advance(cb, 1)); }
+        }
+        // ---------------- phase 2: (X1, Y1), stage X0 of the K-tile after next
+        AP_SYNC_EVEN();
+        AP_MMA(acc[1][2], fb1[0], fa[0][0]); AP_MMA(acc[1][3], fb1[0], fa[1][0]);
+        AP_STAGE_EARLY(stage(ca, true, BUF, U_X0));
+        AP_SB();
+        AP_MMA(acc[1][2], fb1[1], fa[0][1]); AP_MMA(acc[1][3], fb1[1], fa[1][1]);
+        AP_MMA(acc[1][2], fb1[2], fa[0][2]); AP_MMA(acc[1][3], fb1[2], fa[1][2]);
+        AP_STAGE_LATE(stage(ca, true, BUF, U_X0));
+        AP_MMA(acc[1][2], fb1[3], fa[0][3]); AP_MMA(acc[1][3], fb1[3], fa[1][3]);
+        // ---------------- phase 3: (X1, Y0), stage Y0 likewise; read X0 / Y0 of the NEXT K-tile (other buffer)
+        AP_SYNC_3();
+        AP_MMA(acc[0][2], fb0[0], fa[0][0]); AP_MMA(acc[0][3], fb0[0], fa[1][0]);
+        AP_STAGE_EARLY(stage(ca, false, BUF, U_Y0); advance(ca, 0));
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if constexpr (PREFETCH) {
+                AP_SB();
+                fb0[kk] = AP_FRAG(NBUF, U_Y0 * kUnitBytes, AP_PB(NBUF, kk));
+                fa[0][kk] = AP_FRAG(NBUF, U_X0 * kUnitBytes, AP_PA(NBUF, kk));
+                fa[1][kk] = AP_FRAG(NBUF, U_X0 * kUnitBytes + 32 * kRowBytes, AP_PA(NBUF, kk));
+                AP_SB();
+            }
+            if (kk < 3) { AP_MMA(acc[0][2], fb0[kk + 1], fa[0][kk + 1]); AP_MMA(acc[0][3], fb0[kk + 1], fa[1][kk + 1]); }
+            if (kk == 1) { AP_STAGE_LATE(stage(ca, false, BUF, U_Y0); advance(ca, 0)); }
+        }
+    };
+
     char* scr = smem + kScratchOff + wave * 4096;
+    // Measured and dropped (round 5, profiles/r05_gemm_experiments.txt): EPI_RESID_STATS reads its 128 x 64 window of the stream
+    // (128 KiB per workgroup) when the tile's K loop is over -- the "drain" of proj / fc2 is 4.2-4.7 us per tile against
+    // 1.3-1.5 us for the NORM epilogues.  Touching every line of the window four K-tiles early (two LDS-DMA loads per wave into
+    // the idle epilogue scratch, so that the epilogue's loads hit the L2) made proj 11 % and fc2 1.6 % SLOWER: the window is
+    // already served from the XCD's L2 / the Infinity Cache (the previous kernel wrote it), and the extra loads sit in
+    // the same queue as the operand stream.
 #ifdef AP_G256_DIAG
     auto stamp = [&](int ti, int k) {
         if (g.trace && ti < g.trace_tiles && threadIdx.x == 0)
@@ -393,15 +530,26 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
     for (int ti = 0; ti < tw.count; ++ti) {
         stamp(ti, 0);
         stamp_clk(ti, 5);
-        for (int kt = 0; kt < nk; kt += 2) {
+        if constexpr (!kOldLoop) {
+            using B0 = std::integral_constant<int, 0>; using B1 = std::integral_constant<int, 1>;
+            using Y = std::true_type; using N = std::false_type;
+            ktile_p(B0{}, Y{}, Y{}, ti == 0);
+            for (int kt = 2; kt < nk; kt += 2) {
+                ktile_p(B1{}, N{}, Y{}, true);
+                ktile_p(B0{}, N{}, Y{}, true);
+            }
+            ktile_p(B1{}, N{}, N{}, true);
+        } else {
+            for (int kt = 0; kt < nk; kt += 2) {
 #ifdef AP_G256_DIAG
-            // fine timeline (twin only): start of every K-tile pair, in a second [workgroups, tiles, 8] block of the buffer
-            if (g.trace && ti < g.trace_tiles && threadIdx.x == 0 && (kt >> 1) < 8)
-                g.trace[((size_t)(gridDim.x + blockIdx.x) * g.trace_tiles + ti) * 8 + (kt >> 1)] =
-                    (long long)__builtin_amdgcn_s_memrealtime();
+                // fine timeline (twin only): start of every K-tile pair, in a second [workgroups, tiles, 8] block of the buffer
+                if (g.trace && ti < g.trace_tiles && threadIdx.x == 0 && (kt >> 1) < 8)
+                    g.trace[((size_t)(gridDim.x + blockIdx.x) * g.trace_tiles + ti) * 8 + (kt >> 1)] =
+                        (long long)__builtin_amdgcn_s_memrealtime();
 #endif
-            ktile(std::integral_constant<int, 0>{}, ti == 0 || kt != 0);
-            ktile(std::integral_constant<int, 1>{}, true);
+                ktile(std::integral_constant<int, 0>{}, ti == 0 || kt != 0);
+                ktile(std::integral_constant<int, 1>{}, true);
+            }
         }
         // ---------------- epilogue
         stamp_clk(ti, 6);
@@ -648,7 +796,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
                             *(f32x2*)(g.partial + (orow * (g.N >> 6) + (n0 >> 6)) * 2) = sq;
                         }
                     }
-                    if (m < g.M) *(u32x4*)((T*)g.out + orow * g.ldo + n0 + rc * 8) = v;
+                    if (m < g.M) AP_OUT_STORE((T*)g.out + orow * g.ldo + n0 + rc * 8, v);
                 }
             }
         }

@@ -64,7 +64,8 @@ def _to_patch_size(tiles: torch.Tensor, ps: int) -> torch.Tensor:
 class PatchFeatureEmbeddingService(FeatureEmbeddingService):
     def __init__(self, extraction_cfg: ExtractionConfig, output_cfg: OutputConfig,
                  feature_cfg: FeatureExtractionConfig,
-                 registry: Optional[PatchFeatureExtractorRegistry] = None) -> None:
+                 registry: Optional[PatchFeatureExtractorRegistry] = None, *,
+                 keep_feature_blocks: Optional[bool] = None) -> None:
         self.cfg = extraction_cfg.validated()
         self.output_cfg = output_cfg.validated()
         self.feature_cfg = feature_cfg.validated()
@@ -85,9 +86,9 @@ class PatchFeatureEmbeddingService(FeatureEmbeddingService):
         self._seen: dict[Path, tuple[int | None, set[str]]] = {}
         self._ring = None
         # (h5 path, extractor) -> float32 [N, D] computed in this run; kept only when the rank-sharded gather will use
-        # them (ATLASPATCH_GATHER_FEATURES), so that the all-gather does not read the matrices back from disk
+        # them (--gather-features / ATLASPATCH_GATHER_FEATURES), so that the all-gather does not read the matrices back from disk
         self.feature_blocks: dict = {}
-        self._keep_blocks = bool(os.environ.get("ATLASPATCH_GATHER_FEATURES"))
+        self._keep_blocks = bool(os.environ.get("ATLASPATCH_GATHER_FEATURES")) if keep_feature_blocks is None else bool(keep_feature_blocks)
         # embed_all pipelines slides: slide k's feature matrix lands in one of two grow-only pinned buffers and is written to
         # its H5 by a writer thread while slide k + 1 embeds into the other; the first encoder can be built on a side thread
         # while phase 1 (segmentation + coordinates) still runs (prefetch_extractor)

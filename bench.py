@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- patches/sec embedded (256x256 tiles, ViT-B/16) on N MI355X.
 
-Workload (BASELINE.json configs[1]): `process` on one synthetic 40 000 x 40 000 slide, ViT-B/16,
-one slide per rank.  Tiles are the slide's own tissue tiles (coords from the device coordinate
+Workload: `process` on one synthetic 100 000 x 100 000 slide per rank, ViT-B/16 -- the slide BASELINE.json's north star
+quotes its target on, at EVERY N, so the driver's 1 -> 8 curve is one workload string (configs[3] per rank; configs[1]'s
+40 000^2 slide: `--slide 40000` -- the step is the same 2048 HBM-resident tiles, only the tile pool and the coordinate
+block differ; its end-to-end rate is `rates.e2e_cli_40k`).  Tiles are the slide's own tissue tiles (coords from the device coordinate
 path, pixels rendered into HBM by ap_synth_tiles) -- resident in HBM before the timed region.
 A "step" = one pass of the hot path over one device batch of tiles:
     uint8 HWC tiles -> K1 normalise/crop/patch-rows -> ViT-B/16 (12 blocks) -> float32 [B, 768].
@@ -125,8 +127,8 @@ def parse_args():
                     help="tiles per step (device batch; default 2048, conch_v1 256 = its registered maximum)")
     ap.add_argument("--precision", default="float16", choices=["float16", "bfloat16", "float32"])
     ap.add_argument("--slide", type=int, default=None,
-                    help="synthetic slide side in pixels (default: 40000 = BASELINE config 2 at N = 1, "
-                         "100000 = config 4 for N > 1)")
+                    help="synthetic slide side in pixels (default: 100000 at every N = the north star's slide, BASELINE configs 3 / 4; "
+                         "40000 = config 2's slide)")
     ap.add_argument("--encoder", default="vit_b_16", choices=sorted(ENCODERS),
                     help="registered encoder of the forward (vit_b_16 = configs 2 / 4, uni_v1 = config 3, conch_v1 = config 5; "
                          "vit_b_32 / vit_l_32 / vit_h_14 / uni_v2 = the rest of those encoder files; dinov2_* / phikon_* = the "
@@ -652,7 +654,7 @@ def main():
         respawn_under_torchrun(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.slide is None:
-        args.slide = 40000 if world == 1 else 100000
+        args.slide = 100000                 # one workload string for N = 1, 2, 4, 8 (round 4 spliced 40 000 / 100 000)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():

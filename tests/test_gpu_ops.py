@@ -674,7 +674,7 @@ def test_vit_create_rejects_configurations_the_kernels_cannot_run():
                 attn_scale=0.0, pre_norm=0, act=0, proj_dim=0, rope=0)
 
     def create(**kw):
-        cfg = _lib.VitConfig(*[{**base, **kw}[name] for name, _ in _lib.VitConfig._fields_])
+        cfg = _lib.VitConfig(*[{**base, **kw}[name] for name, _ in _lib.VitConfig._fields_ if name != "struct_size"])
         h = C.c_void_p()
         rc = lib.ap_vit_create(C.byref(cfg), C.byref(h))
         if rc == 0:

@@ -41,13 +41,17 @@
 // Roofline: MFMA (4 * T * T * 64 flop per head; padded to 32-query x 64-key tiles);
 // HBM traffic = q, k, v read once + o written once.
 #include "ap_common.h"
+#include <cstdlib>
 
 namespace ap {
 namespace {
 
 constexpr int kKV = 64;                 // keys per tile
 constexpr int kNW = 8;                  // waves per workgroup
-constexpr int kNB = 4;                  // K/V ring buffers (prefetch distance kNB - 1)
+#ifndef AP_ATTN_NB
+#define AP_ATTN_NB 4
+#endif
+constexpr int kNB = AP_ATTN_NB;         // K/V ring buffers (prefetch distance kNB - 1); >= 3 (the epilogue stages through two idle ones)
 
 template <typename T> struct FMma;
 template <> struct FMma<f16> {
@@ -107,7 +111,7 @@ __device__ __forceinline__ float half_swap_sum(float v) {
 }
 
 template <typename T, int HD>
-__global__ __launch_bounds__(kNW * 64, HD == 64 ? 4 : 2)
+__global__ __launch_bounds__(kNW * 64, HD == 64 ? (kNB == 3 ? 6 : 4) : 2)
 void attention_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int tokens, int heads, int parts, int units,
                             float scale) {
     constexpr int kHD = HD;
@@ -380,6 +384,7 @@ void attention_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int 
         }
     }
 }
+
 
 }  // namespace
 

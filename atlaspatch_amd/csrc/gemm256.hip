@@ -527,9 +527,53 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
     auto stamp = [](int, int) {};
     auto stamp_clk = [](int, int) {};
 #endif
+#ifndef AP_G256_NO_LDSOPS
+    // NORM epilogues (round 5; -DAP_G256_NO_LDSOPS restores the loads + drain of rounds 2-4: qkv 4.5 %, fc1 3.2 % slower): this tile's row statistics (128 rows x 8 B), bias and column sums (64 floats each) are brought into the wave's
+    // idle epilogue scratch by three LDS-DMA loads at the START of the tile's K loop (older than every staging load that the
+    // loop's counted waits leave in flight, so they have landed long before the epilogue), and the epilogue reads them with
+    // ds_read instead of opening with 20 global loads and a full drain.  The drain (the first K-tile after an epilogue runs
+    // without counted waits, so everything staged must be back before the epilogue's stores go out) moves in front of the
+    // tile's FIRST store, behind the first 32-row block's arithmetic.  A tile that holds the last row of an odd M keeps the
+    // loads (the 16-byte row-statistics pieces cover row pairs).
+    constexpr bool kLdsOps = kNorm;
+    const uint32_t scr_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + kScratchOff + wave * 4096;
+    auto tile_uses_lds_ops = [&](int m0_tile) { return !((g.M & 1) && m0_tile + kBM > g.M); };
+    [[maybe_unused]] auto stage_ops = [&](int ti) {
+        int tr, tc;
+        tw.rc(tw.first + ti * tw.stride, tr, tc);
+        if (!tile_uses_lds_ops(tr * kBM)) return;
+        const int m0 = tr * kBM + wr * 128, n0 = tc * kBN + wc * 64;
+        int p = m0 + 2 * lane;
+        p = p + 1 < g.M ? p : g.M - 2;
+        p = p < 0 ? 0 : p;
+        const uint32_t off_rs = (uint32_t)p * 8u, off_b = (uint32_t)(n0 + lane) * 4u;
+        uint32_t keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %3\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, %6\n\t"
+            "s_mov_b32 m0, %4\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dword %2, %7\n\t"
+            "s_mov_b32 m0, %5\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dword %2, %8\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(off_rs), "v"(off_b), "s"(scr_lds), "s"(scr_lds + 1024), "s"(scr_lds + 1280), "s"(g.rowstats), "s"(g.bias), "s"(g.colsum)
+            : "memory");
+    };
+    if constexpr (kLdsOps) stage_ops(0);
+#else
+    constexpr bool kLdsOps = false;
+#endif
     for (int ti = 0; ti < tw.count; ++ti) {
         stamp(ti, 0);
         stamp_clk(ti, 5);
+#ifndef AP_G256_NO_LDSOPS
+        if constexpr (kLdsOps) { if (ti > 0) stage_ops(ti); }
+#endif
         if constexpr (!kOldLoop) {
             using B0 = std::integral_constant<int, 0>; using B1 = std::integral_constant<int, 1>;
             using Y = std::true_type; using N = std::false_type;
@@ -571,7 +615,25 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
         // no register of a load can be copied before the wait (an inline-asm load with a separate inline-asm wait lets the
         // register allocator place such copies in between: seen as a run-to-run race).  vmcnt(0) = 0x0F70 on gfx9
         // (expcnt / lgkmcnt fields left at their maxima).  Only loads are outstanding here.
-        if constexpr (kNorm) {
+        bool drain_late = false;
+#ifndef AP_G256_NO_LDSOPS
+        if constexpr (kLdsOps) drain_late = tile_uses_lds_ops(tr * kBM);
+#endif
+        if (kLdsOps && drain_late) {
+#ifndef AP_G256_NO_LDSOPS
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    nbias[nb][g4] = *(const f32x4*)(scr + 1024 + (nb * 32 + g4 * 8 + hi * 4) * 4);
+                    ncs[nb][g4] = *(const f32x4*)(scr + 1280 + (nb * 32 + g4 * 8 + hi * 4) * 4);
+                }
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) rst[mb] = *(const f32x2*)(scr + (mb * 32 + l31) * 8);
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        } else if constexpr (kNorm) {
             // THIS tile's bias, column sums and row statistics
             __builtin_amdgcn_sched_barrier(0);
             const float* bp = bias_ptr(ti, hi);
@@ -734,6 +796,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
                     const f32x2_t b = swiglu2(f32x2_t{y[0][2], y[0][3]}, f32x2_t{y[1][2], y[1][3]});
                     *(u32x2*)(scr + l31 * 64 + ((g4 ^ (l31 & 3)) << 4) + hi * 8) = pack4<T>(f32x4{a[0], a[1], b[0], b[1]});
                 }
+                if (mb == 0 && drain_late) AP_VMCNT(0);        // (the drain that used to open the epilogue)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int row = i * 16 + (lane_e >> 2), ch = lane_e & 3;
@@ -774,6 +837,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
                         if constexpr (kRes) *(u32x2*)(scr + l31 * 128 + (((nb * 4 + g4) ^ (l31 & 7)) << 4) + hi * 8) = pk[nb][mb][g4];
                         else *(u32x2*)(scr + l31 * 128 + (((nb * 4 + g4) ^ (l31 & 7)) << 4) + hi * 8) = pack4<T>(v);
                     }
+                if (mb == 0 && drain_late) AP_VMCNT(0);        // (the drain that used to open the epilogue)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int row = i * 8 + rrow;

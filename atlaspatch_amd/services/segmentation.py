@@ -7,7 +7,10 @@ weights (``AtlasAnalyticsLab/AtlasPatch:model.pth``) are not available offline; 
   the thumbnail grid (SURVEY.md 8d "synthetic masks"); lets ``process`` run end to end.
 * ``SAM2SegmentationService`` -- the reference's constructor and thumbnail preparation
   (``get_thumbnail_at_power(1.25)`` + ``PIL.thumbnail(1024)``) around ``sam2_hip.Sam2HipPredictor``: the Hiera-T
-  image path on the HIP float32 operator set (weights needed; parity unpinned, see oracle/sam2_oracle.py).
+  image path on the HIP float32 operator set (weights needed).  The architecture is pinned against an independent
+  implementation -- transformers' ``Sam2Model`` on seeded weights through ``services/sam2_keys.py`` (oracle 2.8e-7, device
+  <= 1e-4 / 2e-4, tests/test_sam2_hf_pin.py); what stays unpinned is the facebook-side ``sam2`` package itself and the real
+  checkpoint ``AtlasAnalyticsLab/AtlasPatch:model.pth``, neither of which exists offline.
   Any other segmenter plugs in through ``SegmentationService``.
 """
 from __future__ import annotations

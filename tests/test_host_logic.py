@@ -534,6 +534,22 @@ def test_detect_tissue_command_writes_mask_overlays(tmp_path):
     assert res.exit_code == 0 and "Created 2 mask overlay(s), failures: 0" in res.output
     assert sorted(p.name for p in (out / "visualization").iterdir()) == ["a_mask.png", "a_mask_bw.png", "b_mask.png", "b_mask_bw.png"]
 
+def test_process_exposes_the_feature_gather_as_a_flag():
+    """The one collective of the multi-GPU path is a CLI flag (MI355X addition, next to the ATLASPATCH_GATHER_FEATURES
+    environment variable), named in `process --help`; `segment-and-get-coords` does not carry it; with one rank it is a no-op
+    that needs no process group."""
+    import inspect
+    from click.testing import CliRunner
+    from atlaspatch_amd import cli as cli_mod
+    res = CliRunner().invoke(cli_mod.cli, ["process", "--help"])
+    assert res.exit_code == 0 and "--gather-features / --no-gather-features" in res.output
+    res = CliRunner().invoke(cli_mod.cli, ["segment-and-get-coords", "--help"])
+    assert res.exit_code == 0 and "--gather-features" not in res.output
+    assert "gather_features" in inspect.signature(cli_mod._run_pipeline).parameters
+    from atlaspatch_amd.services.feature_embedding import PatchFeatureEmbeddingService
+    assert "keep_feature_blocks" in inspect.signature(PatchFeatureEmbeddingService.__init__).parameters
+
+
 def test_h5_file_equals_the_file_the_references_writer_makes_with_real_h5py(tmp_path, golden_dir):
     """G5b: tests/golden/reference_real.h5 was written by the reference's own H5PatchWriter (write_coords + append_features,
     unmodified) under the REAL h5py of the image's conda interpreter (gen_golden_h5_real.py).  The build's writer, given the

@@ -721,6 +721,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
 #pragma unroll
             for (int j = 8; j < 16; ++j) res_ld(j);
             __builtin_amdgcn_sched_barrier(0);
+            // (measured, round 5: leaving the waits for these loads to the compiler -- counted vmcnt(15 .. 12) in front of the first
+            //  32-row block, full drains once its stores are in flight -- changes nothing: proj / fc2 +0.1 %.  The 4-5 us this
+            //  drain takes per tile are the window's 128 KiB per workgroup at a CU's share of the memory system, not one latency.)
             __builtin_amdgcn_s_waitcnt(0x0F70);
             __builtin_amdgcn_sched_barrier(0);
         } else {

@@ -58,8 +58,10 @@ class Sam2HipPredictor:
         self.input_size = 1024
         self.plan, self.stage_ends = block_plan()
         self._graph = None
+        self._flop = None                    # set to 0.0 by count_flop(): _gemm / _attention then add their multiply-adds
         self._batch_graphs: dict = {}
         self.fused_attention = os.environ.get("ATLASPATCH_SAM2_UNFUSED_ATTENTION") in (None, "", "0")
+        self.wide_gemm = os.environ.get("ATLASPATCH_SAM2_NO_WIDE_GEMM") in (None, "", "0")      # A/B switch of _gemm's kernel choice
         self._static_img = self._static_mask = None
         self._resamplers: dict = {}
         f = lambda t: t.detach().to(torch.float32).contiguous()
@@ -148,6 +150,19 @@ class Sam2HipPredictor:
               batch=1, sa=0, sw=0, so=0, sr=0, w_kn=False, alpha=1.0, stack=1):
         m = a.shape[0] if m is None else m
         out = self._buf(m, n) if out is None else out
+        if self._flop is not None:
+            self._flop += 2.0 * batch * m * n * k
+        # Wide row-wise layers go to the encoder's float32 GEMM (ap_gemm, 128 x 128 tiles, the same v_mfma_f32_32x32x2_f32
+        # arithmetic, erf GELU): with >= 512 tiles per image it fills the chip better than ap_sgemm's plan (round 5,
+        # tools/sgemm_vs_gemm_probe.py: 0.69-0.83 x the time on the five shapes this selects, 1.0-2.7 x on the ones it does not).
+        # The choice looks at ONE image's rows, never at the batch: a row's result does not depend on what it is stacked with.
+        if (self.wide_gemm and batch == 1 and not w_kn and alpha == 1.0 and resid is None and bias is not None and act in (0, 1)
+                and n % 128 == 0 and k % 32 == 0 and k <= 768 and -(-(m // stack) // 128) * (n // 128) >= 512
+                and (lda is None or lda == k) and (ldw is None or ldw == k) and (ldo is None or ldo == n)
+                and a.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0):
+            _lib.check(self.lib.ap_gemm(_lib.AP_F32, act, a.data_ptr(), k, w.data_ptr(), k, m, n, k, bias.data_ptr(), None,
+                                        out.data_ptr(), n, 128, 0, self._stream()), "ap_gemm")
+            return out
         if stack > 1:
             # `stack` images through one row-wise layer: planned like a single image (ap_sgemm_stacked), so a row's result
             # does not depend on the batch size
@@ -175,6 +190,8 @@ class Sam2HipPredictor:
         """q [nb*tq, ldq], k / v [nb*tk, ld*] with head h at column h*d  ->  [nb*tq, heads*d]."""
         out = self._buf(nb * tq, heads * d)
         scale = 1.0 / math.sqrt(d)
+        if self._flop is not None:
+            self._flop += 4.0 * nb * heads * tq * tk * d
         if (self.fused_attention and d in (32, 64, 96) and nb <= 65535 and ldq % 4 == 0 and ldk % 4 == 0
                 and q.data_ptr() % 16 == 0 and k.data_ptr() % 16 == 0):
             # one fused kernel for all windows and heads: the [nb, heads, tq, tk] score matrix never reaches memory
@@ -350,6 +367,20 @@ class Sam2HipPredictor:
         h = self._gemm(h, w["hyper1.w"], 256, 256, bias=w["hyper1.b"], act=2)
         h = self._gemm(h, w["hyper2.w"], 32, 256, bias=w["hyper2.b"])                    # [1, 32]
         return self._gemm(up, h, 1, 32).view(256, 256)                                   # logits[p] = sum_c up[p][c] * h[c]
+
+    @torch.inference_mode()
+    def count_flop(self) -> float:
+        """Multiply-add work of ONE forward (2 * M * N * K per GEMM, 4 * tq * tk * d per attention head), counted by running the
+        chain once eagerly on a blank thumbnail: what bench.py prices against the exact-f32 MFMA peak."""
+        img = torch.zeros((self.input_size, self.input_size, 3), dtype=torch.uint8, device=self.device)
+        self._flop = 0.0
+        try:
+            with torch.cuda.device(self.device):
+                self.mask_logits(*self.image_features(img))
+                torch.cuda.synchronize(self.device)
+            return float(self._flop)
+        finally:
+            self._flop = None
 
     # ------------------------------------------------------------------ reference-facing API
     def _forward_mask(self, img: torch.Tensor) -> torch.Tensor:

@@ -579,6 +579,7 @@ def secondary_rates(device, ex, tiles, B):
     from atlaspatch_amd.services.segmentation import random_sam2_state_dict
     pred = Sam2HipPredictor(random_sam2_state_dict(0), device=str(device))
     img = np.random.default_rng(0).integers(0, 256, (1024, 1024, 3), dtype=np.uint8)
+    sam2_flop = pred.count_flop()
     pred.predict_image(img)                                   # captures the graph
     torch.cuda.synchronize(device)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -606,6 +607,12 @@ def secondary_rates(device, ex, tiles, B):
     rates["sam2_segmentation"] = {"ms_per_slide_device": round(ev0.elapsed_time(ev1) / 10, 3), "ms_per_slide_host_to_host": round(host_ms, 3),
                                   "ms_per_slide_device_seg_batch_4": round(eb0.elapsed_time(eb1) / 20, 3),
                                   "slides_per_s": round(1e3 / host_ms, 1),
+                                  "gflop_per_slide": round(sam2_flop / 1e9, 1),
+                                  "TFLOPs": round(sam2_flop / (ev0.elapsed_time(ev1) / 10 * 1e-3) / 1e12, 1),
+                                  "TFLOPs_seg_batch_4": round(sam2_flop / (eb0.elapsed_time(eb1) / 20 * 1e-3) / 1e12, 1),
+                                  "peak_TFLOPs": MFMA_PEAK["f32"] / 1e12,
+                                  "frac": round(sam2_flop / (ev0.elapsed_time(ev1) / 10 * 1e-3) / MFMA_PEAK["f32"], 4),
+                                  "frac_seg_batch_4": round(sam2_flop / (eb0.elapsed_time(eb1) / 20 * 1e-3) / MFMA_PEAK["f32"], 4),
                                   "what": "SAM2.1 Hiera-T image encoder + box-prompted mask decoder on one 1024x1024 thumbnail "
                                           "(services/segmentation.py:120-140), exact-f32 MFMA GEMMs, ~350 launches captured in one "
                                           "hipGraph; host-to-host includes the PIL resize to 1024x1024, H2D and the mask D2H"}
@@ -966,6 +973,14 @@ def main():
     if not args.no_extras and world == 1 and args.encoder == "vit_b_16":
         line["rates"] = {"kernel_only": {"patches_per_s": round(value, 1), "what": "= value"}}
         line["rates"].update(secondary_rates(device, ex, tiles, B))
+        seg = line["rates"].get("sam2_segmentation")
+        if seg:
+            # config 1's hot kernel chain priced like `roofline`: the forward's multiply-add work over its replay time against
+            # the exact-f32 MFMA peak (the reference runs SAM2 in float32: services/segmentation.py:120-180 has no autocast)
+            line["sam2"] = {"bound": "mfma", "dtype": "f32", "gflop_per_slide": seg["gflop_per_slide"], "ms_per_slide": seg["ms_per_slide_device"],
+                            "ms_per_slide_seg_batch_4": seg["ms_per_slide_device_seg_batch_4"], "achieved": seg["TFLOPs"],
+                            "achieved_seg_batch_4": seg["TFLOPs_seg_batch_4"], "peak": seg["peak_TFLOPs"], "unit": "TFLOP/s",
+                            "frac": seg["frac"], "frac_seg_batch_4": seg["frac_seg_batch_4"]}
     # every arithmetic mode next to its error vs the CPU fp32 path: `value` is the reference CLI's default precision (f16,
     # cli.py:175-181), the north star's 1e-3 is met by the modes marked so
     errs = (line.get("cpu_baseline") or {}).get("rel_err_by_mode") or {}

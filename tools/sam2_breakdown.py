@@ -24,6 +24,13 @@ class Timed:
             if name == "ap_sgemm":
                 key = f"sgemm b{a[7]} M{a[8]} N{a[9]} K{a[10]} {'NN' if a[6] else 'NT'} act{a[13]}{' +res' if a[14] else ''}"
                 flop = 2.0 * a[7] * a[8] * a[9] * a[10]
+            elif name == "ap_sattention_f32":
+                nb, heads, tq, tk, d = a[6], a[7], a[8], a[9], a[10]
+                key = f"sattention nb{nb} heads{heads} tq{tq} tk{tk} d{d}"
+                flop = 4.0 * nb * heads * tq * tk * d
+            elif name == "ap_gemm":
+                key = f"gemm128(f32) M{a[6]} N{a[7]} K{a[8]} epi{a[1]}"
+                flop = 2.0 * a[6] * a[7] * a[8]
             else:
                 key, flop = name, 0.0
             events.append((key, flop, e0, e1)); return r

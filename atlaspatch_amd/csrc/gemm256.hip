@@ -18,8 +18,8 @@
 //    after it was read and lets a plain double buffer run ~4 phases (a whole K-tile) of prefetch:
 //        phase 0: read X0,Y0   stage Y1 of K-tile v+1      phase 2: read X1   stage X0 of v+2
 //        phase 1: read Y1      stage X1 of K-tile v+1      phase 3: -         stage Y0 of v+2
-//    A phase is  [ds_read fragments | s_waitcnt vmcnt(6)] s_barrier [8 MFMAs with the phase's unit
-//    staged between them: 2 x global_load_lds_dwordx4 per lane].  vmcnt(6) = "everything staged four
+//    A phase is  s_waitcnt vmcnt(6); s_barrier; [8 MFMAs with the phase's unit staged between them: 2 x
+//    global_load_lds_dwordx4 per lane -- and, since round 5, the NEXT phase's fragment reads].  vmcnt(6) = "everything staged four
 //    phases ago has landed"; data is read no earlier than one phase after the wait that retires it
 //    and a unit is restaged no earlier than one barrier after its reading phase (raw s_barrier,
 //    never vmcnt(0) in the loop).  Loads retire in issue order among themselves, which is all the counted
@@ -42,7 +42,11 @@
 //    is the raw 16-bit residual stream; NORM applies the row statistics and the rank-one mean correction per element
 //    (accumulators start from zero there), RESID_STATS / PATCH_STREAM add the accumulator to the stream window (or to the
 //    position-embedding row) after the transposition, 16 bytes per lane, and emit per-row partial sums for the next
-//    statistics.  Their operands are fetched with plain loads + __builtin_amdgcn_s_waitcnt before the epilogue body.
+//    statistics.  RESID_STATS / PATCH_STREAM fetch their operands (bias, the 128 x 64 stream window) with plain loads +
+//    __builtin_amdgcn_s_waitcnt before the epilogue body; the NORM epilogues' operands arrive in the wave's idle scratch by
+//    LDS-DMA during the tile's K loop and the drain sits in front of the tile's first store (round 5, see kLdsOps below).
+//  * round 5: the fragment reads of a phase are issued between the MFMAs of the phase BEFORE it (ktile_p below); 16-bit
+//    plain-store epilogues write their rows with the non-temporal hint (out_store16).
 //  * XCD-aware tile order: block b runs on XCD b % 8; each XCD owns a contiguous range of tile ids
 //    (n fastest), its 32 workgroups take consecutive ids, so concurrently running tiles share
 //    activation panels and weight panels in that XCD's L2.

@@ -20,8 +20,8 @@
 //        phase 1: read Y1      stage X1 of K-tile v+1      phase 3: -         stage Y0 of v+2
 //    A phase is  s_waitcnt vmcnt(6); s_barrier; [8 MFMAs with the phase's unit staged between them: 2 x
 //    global_load_lds_dwordx4 per lane -- and, since round 5, the NEXT phase's fragment reads].  vmcnt(6) = "everything staged four
-//    phases ago has landed"; data is read no earlier than one phase after the wait that retires it
-//    and a unit is restaged no earlier than one barrier after its reading phase (raw s_barrier,
+//    phases ago has landed"; data is read no earlier than behind the barrier that follows the wait that retires it
+//    (round 2-4's loop: one phase later) and a unit is restaged no earlier than one barrier after its reading phase (raw s_barrier,
 //    never vmcnt(0) in the loop).  Loads retire in issue order among themselves, which is all the counted
 //    wait relies on; vmcnt also counts the epilogue's global stores, and a store may retire before OR after a
 //    load issued around it: older stores still in the queue only make vmcnt(6) stricter (safe), but nothing may

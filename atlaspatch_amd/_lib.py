@@ -93,6 +93,7 @@ SIGNATURES = {
     "ap_stream_init": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ap_rowstats_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "ap_gemm_trace": (C.c_int, [C.c_void_p, C.c_int]),
+    "ap_split_f16_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "ap_layernorm": (C.c_int, [C.c_int, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                C.c_float, C.c_void_p, C.c_void_p]),
     "ap_attention": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -170,15 +171,30 @@ def load():
         except Exception:  # pragma: no cover - torch is optional for symbol checks
             pass
         lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        # the ABI question first, on the two symbols it needs: a stale library must be refused with "rebuild", not fail
+        # on the first symbol it lacks
+        rebuild = "Rebuild the library (`make -C atlaspatch_amd/csrc`)."
+        try:
+            lib.ap_abi_version.restype, lib.ap_abi_version.argtypes = SIGNATURES["ap_abi_version"]
+            got = lib.ap_abi_version()
+        except AttributeError as exc:
+            raise HipLibraryError(f"{path} does not export ap_abi_version: not a build of include/atlaspatch_hip.h. {rebuild}") from exc
+        size = None
+        if hasattr(lib, "ap_sizeof_vit_config"):
+            lib.ap_sizeof_vit_config.restype, lib.ap_sizeof_vit_config.argtypes = SIGNATURES["ap_sizeof_vit_config"]
+            size = lib.ap_sizeof_vit_config()
+        if got != ABI_VERSION or size != C.sizeof(VitConfig):
+            raise HipLibraryError(
+                f"{path} reports ABI {got} with a {size}-byte ap_vit_config; this binding is written "
+                f"for ABI {ABI_VERSION} / {C.sizeof(VitConfig)} bytes (include/atlaspatch_hip.h). {rebuild}")
         for name, (res, args) in SIGNATURES.items():
-            fn = getattr(lib, name)
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as exc:
+                raise HipLibraryError(f"{path} (ABI {got}) does not export {name}, which include/atlaspatch_hip.h declares: "
+                                      f"the library is older than this binding. {rebuild}") from exc
             fn.restype = res
             fn.argtypes = args
-        got = lib.ap_abi_version()
-        if got != ABI_VERSION or lib.ap_sizeof_vit_config() != C.sizeof(VitConfig):
-            raise HipLibraryError(
-                f"{path} reports ABI {got} with a {lib.ap_sizeof_vit_config()}-byte ap_vit_config; this binding is written "
-                f"for ABI {ABI_VERSION} / {C.sizeof(VitConfig)} bytes (include/atlaspatch_hip.h). Rebuild the library.")
         _lib = lib
         return _lib
 

@@ -144,6 +144,9 @@ struct GemmArgs {
     // (accumulator, bias included) in cls_branch[img][n], f32 [M / cls_tokens, N]; cls_tokens = 0: off.  M < 2^24.
     float* cls_branch;
     int cls_tokens;
+    // float32 buffers with split-f16 products (gemm.hip, 128 x 128 kernel): W points at the [hi 32 | lo 32] f16 rows that
+    // launch_split_f16_weights made of the f32 matrix (same row stride in bytes, ldw still counts f32 elements)
+    int split;
 };
 void set_gemm_trace(long long* buf, int tiles_per_wg);
 
@@ -232,6 +235,8 @@ int launch_swiglu(int dtype, const void* x, int rows, int h, void* out, hipStrea
 // prefix[j][:] = tokens[j][:] (+ pos[j][:] when pos != nullptr), f32
 int launch_prefix_build(const float* cls, const float* reg, int reg_rows, const float* pos, int dim, float* prefix, hipStream_t stream);
 int launch_convert(int dtype, const float* src, void* dst, size_t count, hipStream_t stream);
+// f32 [count] -> per 32 values [hi 32 | lo 32] f16 (count % 32 == 0; the same number of bytes): GemmArgs::split's weight rows
+int launch_split_f16_weights(const float* src, void* dst, size_t count, hipStream_t stream);
 // [n,3,S,S] (f32 or T) -> patch rows T [n*g*g, ld]
 int launch_chw_to_patchrows(int x_dtype, int dtype, const void* x, int n, int S, int ps, void* dst,
                             int ld, hipStream_t stream);

@@ -166,7 +166,16 @@ int ap_gemm(int dtype, int epilogue, const void* A, int lda, const void* W, int 
     ap::GemmArgs g{};
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K;
     g.bias = bias; g.gamma = gamma; g.out = out; g.ldo = ldo;
+    if (impl == 129) {                       // float32 buffers, split-f16 products: W = the rows ap_split_f16_weights made
+        AP_REQUIRE(dtype == AP_F32, "ap_gemm: impl 129 (split-f16 products) takes float32 buffers");
+        g.split = 1;
+        impl = 128;
+    }
     return ap::launch_gemm_impl(dtype, epilogue, g, impl, variant, (hipStream_t)stream);
+}
+
+int ap_split_f16_weights(const float* w32, void* out, size_t count, ap_stream_t stream) {
+    return ap::launch_split_f16_weights(w32, out, count, (hipStream_t)stream);
 }
 
 int ap_gemm_fused(int dtype, int epilogue, const void* A, int lda, const void* W, int ldw, int M, int N, int K,

@@ -604,6 +604,20 @@ __global__ void convert_kernel(const float* __restrict__ src, T* __restrict__ ds
     for (; i < count; i += step) dst[i] = from_f32<T>(src[i]);
 }
 
+// f32 [count] (count % 32 == 0: rows of a K padded to 64) -> per 32 values 32 f16 hi followed by 32 f16 lo, hi = f16(w),
+// lo = f16((w - hi) * 2^11): the weight rows of the split-f16 GEMM (gemm.hip), same bytes as the f32 row
+__global__ void split_f16_kernel(const float* __restrict__ src, f16* __restrict__ dst, size_t count) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; i < count; i += step) {
+        const float w = src[i];
+        const f16 h = (f16)w;
+        const size_t base = (i >> 5) * 64 + (i & 31);
+        dst[base] = h;
+        dst[base + 32] = (f16)((w - (float)h) * 2048.0f);
+    }
+}
+
 // [n, 3, S, S] -> rows [(img*g + py)*g + px][c*ps*ps + ky*ps + kx]; one thread per 4 kx
 template <typename TI, typename TO>
 __global__ void chw_to_patchrows_kernel(const TI* __restrict__ x, int n, int S, int ps,
@@ -912,6 +926,15 @@ int launch_convert(int dtype, const float* src, void* dst, size_t count, hipStre
         case AP_F32: AP_HIP_CHECK(hipMemcpyAsync(dst, src, count * 4, hipMemcpyDeviceToDevice, stream)); return AP_OK;
         default: set_error("convert: unknown dtype %d", dtype); return AP_ERR_INVALID;
     }
+    AP_HIP_CHECK(hipGetLastError());
+    return AP_OK;
+}
+
+int launch_split_f16_weights(const float* src, void* dst, size_t count, hipStream_t stream) {
+    AP_REQUIRE(src && dst && count % 32 == 0 && (const void*)src != dst, "split_f16_weights: count %zu must be a multiple of 32, out of place", count);
+    if (count == 0) return AP_OK;
+    const int blocks = (int)((count + 255) / 256 < 4096 ? (count + 255) / 256 : 4096);
+    split_f16_kernel<<<blocks, 256, 0, stream>>>(src, (f16*)dst, count);
     AP_HIP_CHECK(hipGetLastError());
     return AP_OK;
 }

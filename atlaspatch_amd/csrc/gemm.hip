@@ -16,6 +16,15 @@
 //    permuted (lanes 0-31 take k 0..15 of the tile, lanes 32-63 take k 16..31) so a lane
 //    reads its 16 floats as four 16-byte loads.  Any permutation of k is exact as long
 //    as both operands use the same one.
+//  * split-f16 mode (SPLIT, float32 buffers): the float32-ACCURATE fast path.  x = hi + lo * 2^-11 with hi = f16(x),
+//    lo = f16((x - hi) * 2^11) carries 22 of f32's 24 mantissa bits (and keeps lo a NORMAL f16 for every x whose hi is
+//    normal: no reliance on subnormal operands); a product keeps its three leading terms
+//        w a  ~=  w_hi a_hi  +  2^-11 (w_hi a_lo + w_lo a_hi)
+//    as three v_mfma_f32_32x32x16_f16 passes into TWO f32 accumulators (the 2^-11 terms are summed apart and folded
+//    in once, after the K loop).  Weights are split once (ap_vit_finalize / ap_split_f16_weights) into rows of
+//    [hi 32 | lo 32] f16 per 32 k -- the same 128 bytes per 32 k as the f32 row, so the staging plan is unchanged;
+//    activations stay f32 in HBM and LDS and are split in registers after the fragment read.  24 MFMAs of 16 k per
+//    32-deep K-tile and wave against 32 x 4 of the exact f32 instruction: 2.7x the arithmetic rate at ~2^-22 per product.
 //  * XCD-aware tile order: block b runs on XCD b % 8; logical tile ids are remapped so
 //    each XCD owns a contiguous run of tiles (all n-tiles of an m-panel share one L2).
 //
@@ -122,13 +131,27 @@ template <> __device__ __forceinline__ u32x2 pack4t<bf16>(f32x4 v) {
 }
 template <> __device__ __forceinline__ u32x2 pack4t<float>(f32x4) { return u32x2{0, 0}; }
 
+// 8 f32 -> hi (f16, round to nearest) and lo = f16((x - hi) * 2^11): x = hi + lo * 2^-11 to ~2^-22 |x|
+// (~3.7 VALU per value as hipcc compiles it; measured: a kernel with the split removed altogether is 10 % faster, with
+// v_fma_mix_f32 for x - hi the same -- the loop is bound by its staging barrier, not by these, profiles/r06a_split_f16.txt)
+__device__ __forceinline__ void split8(f32x4 x0, f32x4 x1, f16x8& hi8, f16x8& lo8) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f16 h0 = (f16)x0[j], h1 = (f16)x1[j];
+        hi8[j] = h0; hi8[4 + j] = h1;
+        lo8[j] = (f16)((x0[j] - (float)h0) * 2048.0f);
+        lo8[4 + j] = (f16)((x1[j] - (float)h1) * 2048.0f);
+    }
+}
+
 __device__ __forceinline__ void dma16(const char* gsrc, char* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <typename T, int EPI>
+template <typename T, int EPI, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
+    static_assert(!SPLIT || sizeof(T) == 4, "the split-f16 product runs on float32 buffers");
     __shared__ __attribute__((aligned(16))) char smem[2 * kBufBytes];   // 64 KiB
 
     const int lane = threadIdx.x & 63;
@@ -179,6 +202,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
                 for (int e = 0; e < 4; ++e) acc[nt][mt][g4 * 4 + e] = kNormInit ? 0.0f : b4[e];
         }
 
+    f32x16 accl[SPLIT ? 2 : 1][SPLIT ? 2 : 1];                      // split-f16: the 2^-11 terms
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) accl[nt][mt][e] = 0.0f;
+    }
+
     const int xr = (l31 >> 1) & 7;                                  // row-dependent chunk xor
     const int rowW = (wave_n * 64 + l31) * kRowBytes;               // + nt * 32 rows
     const int rowA = kTileBytes + (wave_m * 64 + l31) * kRowBytes;  // + mt * 32 rows
@@ -206,6 +239,30 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
                 acc[1][0] = Mma<T>::run(w1, a0, acc[1][0]);
                 acc[1][1] = Mma<T>::run(w1, a1, acc[1][1]);
             }
+        } else if constexpr (SPLIT) {
+            // split-f16: W row = [hi 32 | lo 32] f16, A row = 32 f32.  MFMA step s covers k = 16 s .. 16 s + 15, the lane's
+            // eight k = 16 s + 8 hi ..: W chunks 2 s + hi (hi half) and 4 + 2 s + hi (lo half), A chunks 4 s + 2 hi, + 1
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int cw = ((2 * s + hi) ^ xr) << 4, cl = ((4 + 2 * s + hi) ^ xr) << 4;
+                const int ca0 = ((4 * s + 2 * hi) ^ xr) << 4, ca1 = ((4 * s + 2 * hi + 1) ^ xr) << 4;
+                f16x8 wh[2], wl[2], ah[2], al[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    wh[t] = *(const f16x8*)(buf + rowW + t * 32 * kRowBytes + cw);
+                    wl[t] = *(const f16x8*)(buf + rowW + t * 32 * kRowBytes + cl);
+                    split8(*(const f32x4*)(buf + rowA + t * 32 * kRowBytes + ca0),
+                           *(const f32x4*)(buf + rowA + t * 32 * kRowBytes + ca1), ah[t], al[t]);
+                }
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[nt], ah[mt], acc[nt][mt], 0, 0, 0);
+                        accl[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[nt], al[mt], accl[nt][mt], 0, 0, 0);
+                        accl[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[nt], ah[mt], accl[nt][mt], 0, 0, 0);
+                    }
+            }
         } else {
             // f32: lane's 16 k-values = chunks 4*hi .. 4*hi+3 of its row (permuted k, see header)
 #pragma unroll
@@ -226,6 +283,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+    }
+
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[nt][mt][e] = __builtin_fmaf(accl[nt][mt][e], 1.0f / 2048.0f, acc[nt][mt][e]);
     }
 
     // ---- epilogue: lane owns m = .. + l31 and, per (nt, g4), n = .. + 8*g4 + 4*hi + {0..3}
@@ -415,6 +481,22 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     }
 }
 
+// float32 buffers, split-f16 products (GemmArgs::split; W = the [hi | lo] rows of launch_split_f16_weights)
+int launch_split(int epilogue, const GemmArgs& a, hipStream_t stream) {
+    const int tiles = ((a.M + kTile - 1) / kTile) * (a.N / kTile);
+    dim3 grid(tiles), block(256);
+    switch (epilogue) {
+        case EPI_BIAS_STORE: gemm_kernel<float, EPI_BIAS_STORE, true><<<grid, block, 0, stream>>>(a); break;
+        case EPI_BIAS_GELU: gemm_kernel<float, EPI_BIAS_GELU, true><<<grid, block, 0, stream>>>(a); break;
+        case EPI_BIAS_RESID: gemm_kernel<float, EPI_BIAS_RESID, true><<<grid, block, 0, stream>>>(a); break;
+        case EPI_PATCH_EMBED: gemm_kernel<float, EPI_PATCH_EMBED, true><<<grid, block, 0, stream>>>(a); break;
+        case EPI_BIAS_QGELU: gemm_kernel<float, EPI_BIAS_QGELU, true><<<grid, block, 0, stream>>>(a); break;
+        default: set_error("gemm: epilogue %d has no split-f16 form", epilogue); return AP_ERR_INVALID;
+    }
+    AP_HIP_CHECK(hipGetLastError());
+    return AP_OK;
+}
+
 template <typename T>
 int launch_typed(int epilogue, const GemmArgs& a, hipStream_t stream) {
     const int tiles = ((a.M + kTile - 1) / kTile) * (a.N / kTile);
@@ -446,6 +528,7 @@ int launch_gemm(int dtype, int epilogue, const GemmArgs& a, hipStream_t stream) 
 int launch_gemm_impl(int dtype, int epilogue, const GemmArgs& a, int impl, int variant, hipStream_t stream) {
     AP_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem %d x %d x %d", a.M, a.N, a.K);
     AP_REQUIRE(impl == 0 || impl == 128 || impl == 256 || impl == 257, "gemm: unknown implementation %d", impl);
+    AP_REQUIRE(!a.split || (dtype == AP_F32 && (impl == 0 || impl == 128)), "gemm: split-f16 products: float32 buffers, 128 x 128 kernel");
     if (impl == 257) {
 #ifdef AP_WITH_TWIN
         return launch_gemm256_alt(dtype, epilogue, a, variant, stream);
@@ -480,6 +563,10 @@ int launch_gemm_impl(int dtype, int epilogue, const GemmArgs& a, int impl, int v
     AP_REQUIRE(a.lda >= a.K && a.ldw >= a.K, "gemm: leading dimensions smaller than K");
     AP_REQUIRE(((size_t)a.lda * dtype_size(dtype)) % 16 == 0 && ((size_t)a.ldw * dtype_size(dtype)) % 16 == 0,
                "gemm: row strides must be 16-byte multiples");
+    if (a.split) {
+        AP_REQUIRE(dtype == AP_F32, "gemm: the split-f16 product runs on float32 buffers");
+        return launch_split(epilogue, a, stream);
+    }
     switch (dtype) {
         case AP_F16: return launch_typed<f16>(epilogue, a, stream);
         case AP_BF16: return launch_typed<bf16>(epilogue, a, stream);

@@ -26,6 +26,7 @@ struct Param {
     bool matrix = false;
     void* dev = nullptr;   // f32 vector or T matrix
     float* dev32 = nullptr; // matrices, 16-bit compute types: the f32 upload [rows, ld], kept until ap_vit_finalize has folded it
+    void* split = nullptr; // float32 compute type, matrices: the [hi 32 | lo 32] f16 rows of the split-f16 GEMM (AP_VIT_OPT_SPLIT_F16)
     bool set = false;
 };
 
@@ -72,6 +73,7 @@ struct ap_vit {
     // options (ap_vit_set_option; the defaults come from the environment once, at creation)
     bool full_last_block = false, two_half_overlap = false, f32_stream = false;
     bool exact_cls = true;      // fused dataflow: the class rows' residual stream is also kept in f32 (blocks_fused)
+    bool split_f16 = false;     // float32 compute type: GEMMs as three f16 MFMA passes on hi / lo halves (gemm.hip) instead of f32 MFMA
     std::vector<ap::FusedBlock> fused;      // filled by ap_vit_finalize for f16 / bf16
     std::vector<void*> fused_allocs;
     void* pos16 = nullptr;                  // position embedding in the compute type (fused patch embedding), in fused_allocs
@@ -131,6 +133,10 @@ const Param* find(const ap_vit* m, const std::string& name) {
     return it == m->params.end() ? nullptr : &it->second;
 }
 
+// weight operand of a GEMM on the float32 path: the f32 matrix, or its split rows when AP_VIT_OPT_SPLIT_F16 is on
+inline bool use_split(const ap_vit* m) { return m->split_f16 && m->cfg.compute_dtype == AP_F32; }
+inline const void* wsel(const ap_vit* m, const Param* p) { return use_split(m) ? p->split : p->dev; }
+
 struct Workspace {
     float* tok; void* xn; void* qkv; void* att; void* hid; void* hid2; void* delta; void* delta2;
     void* x16; float* rowstats; float* partial;      // fused-LayerNorm path: T stream [M, D], f32 [M, 2], f32 [M, D / 64, 2]
@@ -187,7 +193,7 @@ int patch_embed(ap_vit* m, int n, const Workspace& w, hipStream_t stream) {
     {
         const Param* wpe = m->pe_w;
         ap::GemmArgs g{};
-        g.A = w.hid; g.lda = m->kpe; g.W = wpe->dev; g.ldw = wpe->ld;
+        g.A = w.hid; g.lda = m->kpe; g.W = wsel(m, wpe); g.split = use_split(m); g.ldw = wpe->ld;
         g.M = n * m->patches; g.N = D; g.K = m->kpe;
         g.bias = m->pe_b;
         g.pos = m->pos;
@@ -251,7 +257,7 @@ int blocks_f32_stream(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipS
             char* a_cls = (char*)w.att + (size_t)n * DA * es;             // T [n, DA]
             {
                 ap::GemmArgs g{};                                          // k | v for all rows
-                g.A = w.xn; g.lda = D; g.W = (const char*)wq->dev + (size_t)DA * wq->ld * es; g.ldw = wq->ld;
+                g.A = w.xn; g.lda = D; g.W = (const char*)wsel(m, wq) + (size_t)DA * wq->ld * es; g.split = use_split(m); g.ldw = wq->ld;
                 g.M = M; g.N = 2 * DA; g.K = D; g.bias = bp.qkv_b + DA;
                 g.out = (char*)w.qkv + (size_t)DA * es; g.ldo = 3 * DA;
                 ScopedTimer t(m, AP_PROF_GEMM_QKV, stream);
@@ -263,7 +269,7 @@ int blocks_f32_stream(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipS
             ScopedTimer t(m, AP_PROF_CLS_TAIL, stream);
             {
                 ap::GemmArgs g{};                                          // q for the CLS rows
-                g.A = w.xn; g.lda = (int)cls_stride; g.W = wq->dev; g.ldw = wq->ld;
+                g.A = w.xn; g.lda = (int)cls_stride; g.W = wsel(m, wq); g.split = use_split(m); g.ldw = wq->ld;
                 g.M = n; g.N = DA; g.K = D; g.bias = bp.qkv_b; g.out = q_cls; g.ldo = DA;
                 if ((rc = ap::launch_gemm_impl(dt, ap::EPI_BIAS_STORE, g, 128, 0, stream)) != AP_OK) return rc;
             }
@@ -271,7 +277,7 @@ int blocks_f32_stream(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipS
                                                m->hd, m->attn_scale, stream)) != AP_OK) return rc;
             {
                 ap::GemmArgs g{};
-                g.A = a_cls; g.lda = DA; g.W = bp.proj->dev; g.ldw = bp.proj->ld;
+                g.A = a_cls; g.lda = DA; g.W = wsel(m, bp.proj); g.split = use_split(m); g.ldw = bp.proj->ld;
                 g.M = n; g.N = D; g.K = DA; g.bias = bp.proj_b; g.out = w.delta2; g.ldo = D;
                 if ((rc = ap::launch_gemm_impl(dt, ap::EPI_BIAS_STORE, g, 128, 0, stream)) != AP_OK) return rc;
             }
@@ -281,14 +287,14 @@ int blocks_f32_stream(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipS
                 return rc;
             {
                 ap::GemmArgs g{};
-                g.A = w.xn; g.lda = D; g.W = bp.fc1->dev; g.ldw = bp.fc1->ld;
+                g.A = w.xn; g.lda = D; g.W = wsel(m, bp.fc1); g.split = use_split(m); g.ldw = bp.fc1->ld;
                 g.M = n; g.N = F1; g.K = D; g.bias = bp.fc1_b; g.out = w.hid; g.ldo = F1;
                 if ((rc = ap::launch_gemm_impl(dt, swiglu ? ap::EPI_BIAS_STORE : (c.act == AP_ACT_QUICK_GELU ? ap::EPI_BIAS_QGELU : ap::EPI_BIAS_GELU), g, 128, 0, stream)) != AP_OK) return rc;
                 if (swiglu && (rc = ap::launch_swiglu(dt, w.hid, n, H, w.hid2, stream)) != AP_OK) return rc;
             }
             {
                 ap::GemmArgs g{};
-                g.A = w.hid2; g.lda = H; g.W = bp.fc2->dev; g.ldw = bp.fc2->ld;
+                g.A = w.hid2; g.lda = H; g.W = wsel(m, bp.fc2); g.split = use_split(m); g.ldw = bp.fc2->ld;
                 g.M = n; g.N = D; g.K = H; g.bias = bp.fc2_b; g.out = w.delta; g.ldo = D;
                 if ((rc = ap::launch_gemm_impl(dt, ap::EPI_BIAS_STORE, g, 128, 0, stream)) != AP_OK) return rc;
             }
@@ -299,7 +305,7 @@ int blocks_f32_stream(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipS
         }
         {
             ap::GemmArgs g{};
-            g.A = w.xn; g.lda = D; g.W = bp.qkv->dev; g.ldw = bp.qkv->ld;
+            g.A = w.xn; g.lda = D; g.W = wsel(m, bp.qkv); g.split = use_split(m); g.ldw = bp.qkv->ld;
             g.M = M; g.N = 3 * DA; g.K = D; g.bias = bp.qkv_b; g.out = w.qkv; g.ldo = 3 * DA;
             ScopedTimer t(m, AP_PROF_GEMM_QKV, stream);
             if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_STORE, g, stream)) != AP_OK) return rc;
@@ -311,7 +317,7 @@ int blocks_f32_stream(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipS
                                          stream)) != AP_OK) return rc; }
         {
             ap::GemmArgs g{};
-            g.A = w.att; g.lda = DA; g.W = bp.proj->dev; g.ldw = bp.proj->ld;
+            g.A = w.att; g.lda = DA; g.W = wsel(m, bp.proj); g.split = use_split(m); g.ldw = bp.proj->ld;
             g.M = M; g.N = D; g.K = DA; g.bias = bp.proj_b;
             g.out = w.delta2; g.ldo = D;
             ScopedTimer t(m, AP_PROF_GEMM_PROJ, stream);
@@ -323,7 +329,7 @@ int blocks_f32_stream(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipS
                                               bp.ln2_b, c.ln_eps, w.xn, stream)) != AP_OK) return rc; }
         {
             ap::GemmArgs g{};
-            g.A = w.xn; g.lda = D; g.W = bp.fc1->dev; g.ldw = bp.fc1->ld;
+            g.A = w.xn; g.lda = D; g.W = wsel(m, bp.fc1); g.split = use_split(m); g.ldw = bp.fc1->ld;
             g.M = M; g.N = F1; g.K = D; g.bias = bp.fc1_b; g.out = w.hid; g.ldo = F1;
             ScopedTimer t(m, AP_PROF_GEMM_FC1, stream);
             if ((rc = ap::launch_gemm(dt, swiglu ? ap::EPI_BIAS_STORE : (c.act == AP_ACT_QUICK_GELU ? ap::EPI_BIAS_QGELU : ap::EPI_BIAS_GELU), g, stream)) != AP_OK) return rc;
@@ -331,7 +337,7 @@ int blocks_f32_stream(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipS
         }
         {
             ap::GemmArgs g{};
-            g.A = w.hid2; g.lda = H; g.W = bp.fc2->dev; g.ldw = bp.fc2->ld;
+            g.A = w.hid2; g.lda = H; g.W = wsel(m, bp.fc2); g.split = use_split(m); g.ldw = bp.fc2->ld;
             g.M = M; g.N = D; g.K = H; g.bias = bp.fc2_b;
             g.out = w.delta; g.ldo = D;
             ScopedTimer t(m, AP_PROF_GEMM_FC2, stream);
@@ -521,7 +527,7 @@ int run_blocks(ap_vit* m, int n, const Workspace& w, float* out, hipStream_t str
         if ((rc = ap::launch_add_layernorm(dt, dt, w.tok, st.tok_stride, pending, st.pending_stride, pending_ls, n, D, m->norm_w,
                                            m->norm_b, c.ln_eps, w.xn, stream)) != AP_OK) return rc;
         ap::GemmArgs g{};
-        g.A = w.xn; g.lda = D; g.W = m->head_proj->dev; g.ldw = m->head_proj->ld; g.M = n; g.N = P; g.K = D;
+        g.A = w.xn; g.lda = D; g.W = wsel(m, m->head_proj); g.split = use_split(m); g.ldw = m->head_proj->ld; g.M = n; g.N = P; g.K = D;
         g.bias = m->zero_bias; g.out = dt == AP_F32 ? (void*)out : w.att; g.ldo = P;
         if ((rc = ap::launch_gemm_impl(dt, ap::EPI_BIAS_STORE, g, 128, 0, stream)) != AP_OK) return rc;
         return dt == AP_F32 ? AP_OK : ap::launch_stream_to_f32(dt, w.att, P, n, P, out, stream);
@@ -569,6 +575,22 @@ int run_blocks(ap_vit* m, int n, const Workspace& w, float* out, hipStream_t str
         if ((rc = ap::launch_gemm(dt, ap::EPI_BIAS_RESID, g, stream)) != AP_OK) return rc;    // 0 + (acc + bias), f32
     }
     return ap::launch_layernorm(AP_F32, o32, P, n, P, pp.ln_out_w, pp.ln_out_b, c.pool_ln_eps, out, stream);
+}
+
+// AP_VIT_OPT_SPLIT_F16: every matrix of a float32 encoder also as [hi 32 | lo 32] f16 rows (same bytes again: ViT-B 0.34 GB)
+int refresh_split(Param& p, hipStream_t stream) {
+    return ap::launch_split_f16_weights((const float*)p.dev, p.split, (size_t)p.rows * p.ld, stream);
+}
+int build_split(ap_vit* m) {
+    for (auto& kv : m->params) {
+        Param& p = kv.second;
+        if (!p.matrix || p.split) continue;
+        AP_HIP_CHECK(hipMalloc(&p.split, (size_t)p.rows * p.ld * sizeof(float)));
+        int rc = refresh_split(p, nullptr);
+        if (rc != AP_OK) return rc;
+    }
+    AP_HIP_CHECK(hipDeviceSynchronize());
+    return AP_OK;
 }
 
 int check_forward_args(const ap_vit* m, int n, const void* in, const float* out, const void* ws,
@@ -670,6 +692,7 @@ int ap_vit_create(const ap_vit_config* cfg, ap_vit** out) {
     m->two_half_overlap = getenv("AP_VIT_OVERLAP") != nullptr;
     m->f32_stream = getenv("AP_VIT_F32_STREAM") != nullptr;
     m->exact_cls = getenv("AP_VIT_NO_EXACT_CLS") == nullptr;
+    m->split_f16 = c.compute_dtype == AP_F32 && getenv("AP_VIT_EXACT_F32") == nullptr;      // float32: split-f16 products unless asked otherwise
     int rc = AP_OK;
     auto add = [&](const std::string& name, int rows, int cols, bool matrix) {
         if (rc == AP_OK) rc = alloc_param(m, name, rows, cols, matrix);
@@ -710,6 +733,7 @@ int ap_vit_create(const ap_vit_config* cfg, ap_vit** out) {
         add("attn_pool.out.weight", P, P, true); add("attn_pool.out.bias", 1, P, false);
         add("attn_pool.ln_out.weight", 1, P, false); add("attn_pool.ln_out.bias", 1, P, false);
     }
+    if (rc == AP_OK && m->split_f16) rc = build_split(m);
     if (rc != AP_OK) { ap_vit_destroy(m); return rc; }
     *out = m;
     return AP_OK;
@@ -720,6 +744,7 @@ void ap_vit_destroy(ap_vit* m) {
     for (auto& kv : m->params) {
         if (kv.second.dev) (void)hipFree(kv.second.dev);
         if (kv.second.dev32) (void)hipFree(kv.second.dev32);
+        if (kv.second.split) (void)hipFree(kv.second.split);
     }
     for (void* p : m->fused_allocs) (void)hipFree(p);
     if (m->prefix_dev) (void)hipFree(m->prefix_dev);
@@ -746,6 +771,7 @@ int ap_vit_set_param(ap_vit* m, const char* name, const float* host, size_t coun
         AP_HIP_CHECK(hipMemcpy2D(tmp, (size_t)p.ld * sizeof(float), host, (size_t)p.cols * sizeof(float),
                                  (size_t)p.cols * sizeof(float), p.rows, hipMemcpyHostToDevice));
         int rc = ap::launch_convert(m->cfg.compute_dtype, tmp, p.dev, (size_t)p.rows * p.ld, nullptr);
+        if (rc == AP_OK && p.split) rc = refresh_split(p, nullptr);
         if (rc != AP_OK) { (void)hipFree(tmp); return rc; }
         AP_HIP_CHECK(hipDeviceSynchronize());
         if (p.dev32) { (void)hipFree(p.dev32); p.dev32 = nullptr; }
@@ -813,7 +839,8 @@ int ap_vit_set_params(ap_vit* m, const char* const* names, const float* const* h
                                       (size_t)p.cols * sizeof(float), p.rows, hipMemcpyHostToDevice, stream), "hipMemcpy2DAsync")) {
                 (void)hipFree(tmp); break;
             }
-            const int crc = ap::launch_convert(m->cfg.compute_dtype, tmp, p.dev, padded, stream);
+            int crc = ap::launch_convert(m->cfg.compute_dtype, tmp, p.dev, padded, stream);
+            if (crc == AP_OK && p.split) crc = refresh_split(p, stream);
             if (crc != AP_OK) { rc = crc; (void)hipFree(tmp); break; }
             if (p.dev32) { (void)hipFree(p.dev32); p.dev32 = nullptr; }     // (hipFree waits for the device: a re-upload is rare)
             const bool is_block = strncmp(names[i], "blocks.", 7) == 0;
@@ -950,6 +977,11 @@ int ap_vit_set_option(ap_vit* m, int option, int value) {
     else if (option == AP_VIT_OPT_TWO_HALF_OVERLAP) m->two_half_overlap = value != 0;
     else if (option == AP_VIT_OPT_F32_STREAM) m->f32_stream = value != 0;
     else if (option == AP_VIT_OPT_EXACT_CLS) m->exact_cls = value != 0;
+    else if (option == AP_VIT_OPT_SPLIT_F16) {
+        AP_REQUIRE(value == 0 || m->cfg.compute_dtype == AP_F32, "vit_set_option: AP_VIT_OPT_SPLIT_F16 is a mode of the float32 compute type");
+        if (value != 0) { const int rc = build_split(m); if (rc != AP_OK) return rc; }
+        m->split_f16 = value != 0;
+    }
     else { ap::set_error("vit_set_option: unknown option %d", option); return AP_ERR_INVALID; }
     return AP_OK;
 }

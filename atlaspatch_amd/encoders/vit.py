@@ -691,7 +691,7 @@ class HipViT:
                                                    _lib.current_stream_ptr(self.device)), "ap_vit_forward_chw")
         return out
 
-    OPTIONS = {"full_last_block": 0, "two_half_overlap": 1, "f32_stream": 2, "exact_cls": 3}
+    OPTIONS = {"full_last_block": 0, "two_half_overlap": 1, "f32_stream": 2, "exact_cls": 3, "split_f16": 4}
 
     def set_option(self, name: str, on: bool) -> None:
         """``full_last_block``: the last block for every token instead of the CLS row only; ``two_half_overlap``: a
@@ -699,7 +699,9 @@ class HipViT:
         (f16 / bf16): float32 residual stream with standalone add+LayerNorm launches instead of the fused-LayerNorm
         dataflow (slower).  ``exact_cls`` (default ON; f16 / bf16 fused dataflow with a class-token pooling): the class rows'
         residual stream is additionally carried in float32, which removes most of the 16-bit stream's error from the features
-        (ViT-B/16 float16: 1.26e-3 -> 8.0e-4 against the CPU fp32 path, 1.5 % of the step); off = the plain 16-bit stream."""
+        (ViT-B/16 float16: 1.26e-3 -> 8.0e-4 against the CPU fp32 path, 1.5 % of the step); off = the plain 16-bit stream.
+        ``split_f16`` (float32 only): the GEMMs' inner products as three f16 MFMA passes on hi / lo halves with f32
+        accumulation instead of the exact f32 MFMA -- every buffer, LayerNorm, softmax and the stream stay float32."""
         value = int(on) if not isinstance(on, bool) else (1 if on else 0)
         _lib.check(self.lib.ap_vit_set_option(self._handle, self.OPTIONS[name], value), "ap_vit_set_option")
 

@@ -557,21 +557,36 @@ def secondary_rates(device, ex, tiles, B):
         rates["e2e_cli_100k_jpeg_store"] = jpeg_store_rate(device, tmp)
         # ---- (3c) tiles served by (stub) OpenSlide through the native batched hook
         rates["e2e_openslide_stub_100k"] = openslide_stub_rate(device, ex, tmp)
-    # ---- (4) float32 mode (the 1e-3 parity mode): value + fc1 roofline fraction against the f32 MFMA peak
-    Bf = 512
+    # ---- (4) float32 mode (`--feature-precision float32`; the mode that meets 1e-3 on EVERY element): split-f16 products (the
+    #      default: float32 buffers / LayerNorm / softmax / stream, GEMM products as three f16 MFMA passes on hi / lo halves) and the
+    #      exact f32 MFMA chain (option split_f16 off).  fc1 priced against the peak of the instruction it runs on: the split form
+    #      executes 3 x 2 M N K f16 flop per launch (dense f16 peak), the exact form 2 M N K on v_mfma_f32_32x32x2_f32
+    Bf = 1024
     ex32 = build_hip_vit_extractor(name="vit_b_16", arch="vit_b_16", device=device, dtype=torch.float32,
                                    random_init_seed=0, max_batch=Bf)
-    ex32.forward_device(tiles[:Bf], torch.empty((Bf, 768), dtype=torch.float32, device=device))
-    ex32.vit.profile(True)
-    v32 = _timed_forward(ex32, tiles[:Bf], 4, warm=0)
-    prof = ex32.vit.profile_read()
-    ex32.vit.profile(False)
-    ms, cnt = prof["gemm_fc1"]
-    tf = 2.0 * Bf * 197 * 3072 * 768 / ((ms / max(1, cnt)) * 1e-3) / 1e12 if cnt else 0.0
-    rates["float32_mode"] = {"patches_per_s": round(v32, 1), "device_batch": Bf,
-                             "fc1_TFLOPs": round(tf, 1), "fc1_peak_TFLOPs": MFMA_PEAK["f32"] / 1e12,
-                             "fc1_frac": round(tf / (MFMA_PEAK["f32"] / 1e12), 4),
-                             "what": "exact-f32 MFMA (v_mfma_f32_32x32x2_f32) ViT-B/16, tiles resident in HBM"}
+    out32 = torch.empty((Bf, 768), dtype=torch.float32, device=device)
+
+    def f32_rate(split):
+        ex32.vit.set_option("split_f16", split)
+        ex32.forward_device(tiles[:Bf], out32)
+        ex32.vit.profile(True)
+        v = _timed_forward(ex32, tiles[:Bf], 4, warm=0)
+        prof = ex32.vit.profile_read()
+        ex32.vit.profile(False)
+        ms, cnt = prof["gemm_fc1"]
+        eff = 2.0 * Bf * 197 * 3072 * 768 / ((ms / max(1, cnt)) * 1e-3) / 1e12 if cnt else 0.0
+        peak = (MFMA_PEAK["f16"] if split else MFMA_PEAK["f32"]) / 1e12
+        executed = eff * (3 if split else 1)
+        return {"patches_per_s": round(v, 1), "device_batch": Bf, "fc1_ms_per_launch": round(ms / max(1, cnt), 4),
+                "fc1_TFLOPs": round(eff, 1), "fc1_executed_TFLOPs": round(executed, 1), "fc1_peak_TFLOPs": peak,
+                "fc1_frac": round(executed / peak, 4),
+                "ms_by_kind": {k: round(t / 4, 3) for k, (t, _) in prof.items()}}
+
+    rates["float32_mode"] = dict(f32_rate(True), what="ViT-B/16 float32, split-f16 products (AP_VIT_OPT_SPLIT_F16, the default of the "
+                                 "float32 compute type): x = hi + 2^-11 lo, w a ~= w_hi a_hi + 2^-11 (w_hi a_lo + w_lo a_hi), three "
+                                 "v_mfma_f32_32x32x16_f16 passes, f32 accumulation; tiles resident in HBM")
+    rates["float32_exact_mode"] = dict(f32_rate(False), what="the same with the exact f32 MFMA chain (v_mfma_f32_32x32x2_f32)")
+    ex32.vit.set_option("split_f16", True)
     ex32.cleanup()
     # ---- (4b) SAM2 Hiera-T tissue segmentation of one 1024 x 1024 thumbnail (config 1's hot path; random weights: the
     #      checkpoint is not available offline), float32 MFMA operator set replayed as a hipGraph
@@ -962,7 +977,14 @@ def main():
             ex32 = build_hip_vit_extractor(name=args.encoder, arch=args.encoder, device=device, dtype=torch.float32,
                                            random_init_seed=0, max_batch=min(B, 256), resize=TRANSFORM_RESIZE[args.encoder],
                                            expect_size=None, mean=enc.get("mean"), std=enc.get("std"))
-            errs["float32_mode"] = relf(ex32.extract_batch(patches, batch_size=32))
+            elemf = lambda got: float((np.abs(got.astype(np.float64) - out_cpu) / (np.abs(out_cpu) + 0.05 * np.abs(out_cpu).max())).max())
+            got32 = ex32.extract_batch(patches, batch_size=32)
+            errs["float32_mode"] = relf(got32)
+            errs["float32_mode_elementwise_max"] = elemf(got32)
+            ex32.vit.set_option("split_f16", False)
+            got32 = ex32.extract_batch(patches, batch_size=32)
+            errs["float32_exact_mode"] = relf(got32)
+            errs["float32_exact_mode_elementwise_max"] = elemf(got32)
             ex32.cleanup()
         line["cpu_baseline"]["rel_err_by_mode"] = errs
         cpu_coords, cpu_coords_s = cpu_coords_baseline(args.slide, args.slide_seed + rank)
@@ -992,9 +1014,12 @@ def main():
     if plain16 is not None:
         modes["plain_16bit_stream_" + short] = {"patches_per_s": plain16["patches_per_s"],
                                                 "rel_err_vs_cpu_fp32": errs.get("plain_16bit_stream_" + short)}
-    f32m = (line.get("rates") or {}).get("float32_mode")
-    if f32m:
-        modes["float32_mode"] = {"patches_per_s": f32m["patches_per_s"], "rel_err_vs_cpu_fp32": errs.get("float32_mode")}
+    for key in ("float32_mode", "float32_exact_mode"):
+        f32m = (line.get("rates") or {}).get(key)
+        if f32m:
+            modes[key] = {"patches_per_s": f32m["patches_per_s"], "rel_err_vs_cpu_fp32": errs.get(key),
+                          "elementwise_max_vs_cpu_fp32": errs.get(key + "_elementwise_max"),
+                          "meets_1e-3_elementwise": (errs.get(key + "_elementwise_max") is not None and errs[key + "_elementwise_max"] <= 1e-3)}
     for m in modes.values():
         m["meets_1e-3"] = (m["rel_err_vs_cpu_fp32"] is not None and m["rel_err_vs_cpu_fp32"] <= 1e-3) if m["rel_err_vs_cpu_fp32"] is not None else None
     line["parity_modes"] = modes

@@ -289,11 +289,24 @@ int ap_vit_finalize(ap_vit* m);
  *                                 fc2 launch an n-row GEMM adds the unrounded branch of the class rows to it, and the
  *                                 stream's class row becomes its rounding.  The features are the class row of the stream and
  *                                 nearly all of the 16-bit stream's error in them is that row's own 2 x depth roundings:
- *                                 ViT-B/16 float16 1.26e-3 -> 7.7e-4 against the CPU fp32 path, for < 1 % of the step */
+ *                                 ViT-B/16 float16 1.26e-3 -> 7.7e-4 against the CPU fp32 path, for < 1 % of the step
+ *   AP_VIT_OPT_SPLIT_F16          (additive to ABI v20; float32 compute type only; default ON, environment AP_VIT_EXACT_F32 turns the default
+ *                                 off) the float32-ACCURATE
+ *                                 fast mode behind `--feature-precision float32` (cli.py:175-181, models/patch/base.py:95-106):
+ *                                 every buffer, LayerNorm, softmax and the residual stream stay float32; only the GEMMs' inner
+ *                                 products change from the exact f32 MFMA to three f16 MFMA passes on hi / lo halves
+ *                                 (x = hi + 2^-11 lo, 22 of 24 mantissa bits; w a ~= w_hi a_hi + 2^-11 (w_hi a_lo + w_lo a_hi), f32
+ *                                 accumulation).  The weights are split once, when the option is switched on (a second copy of the
+ *                                 matrices, kept up to date by ap_vit_set_param).  Measured on ViT-B/16, depth 12, against the CPU fp32
+ *                                 path: 1.1e-6 norm-wise / 1.4e-5 element-wise maximum (the exact chain: 2.0e-6 / 3.4e-5 -- its 768- to
+ *                                 3072-long sequential f32 sums round more often than the MFMA's 16-wide ones) at 1.8x the rate.
+ *                                 GEMM operands must stay inside f16's range (|x| < 65504; LayerNorm / attention / GELU outputs and
+ *                                 weights do).  Off = the exact f32 MFMA chain (v_mfma_f32_32x32x2_f32) */
 #define AP_VIT_OPT_FULL_LAST_BLOCK 0
 #define AP_VIT_OPT_TWO_HALF_OVERLAP 1
 #define AP_VIT_OPT_F32_STREAM 2
 #define AP_VIT_OPT_EXACT_CLS 3
+#define AP_VIT_OPT_SPLIT_F16 4
 int ap_vit_set_option(ap_vit* m, int option, int value);
 
 size_t ap_vit_workspace_bytes(const ap_vit* m, int n);
@@ -350,6 +363,13 @@ int ap_vit_forward_chw(ap_vit* m, const void* x, int x_dtype, int n,
 int ap_gemm(int dtype, int epilogue, const void* A, int lda, const void* W, int ldw,
             int M, int N, int K, const float* bias, const float* gamma, void* out, int ldo,
             int impl, int variant, ap_stream_t stream);
+/* The float32-accurate fast product (what AP_VIT_OPT_SPLIT_F16 runs; added to ABI v20 without a layout change).
+ * ap_split_f16_weights: w32 f32 [count] (count % 32 == 0: whole rows of a K that is a multiple of 32) -> out, the same
+ * number of BYTES: per 32 consecutive values 32 f16 `hi` followed by 32 f16 `lo`, hi = f16(w), lo = f16((w - hi) * 2^11).
+ * ap_gemm(AP_F32, ..., impl = 129) then takes such rows as W (ldw still in f32 elements), float32 A / bias / out, and
+ * computes  sum_k  w_hi a_hi + 2^-11 (w_hi a_lo + w_lo a_hi)  with a split in registers, f32 accumulation: ~2^-22 per
+ * product against the exact f32 chain of impl 128, at 2-3x its rate.  K % 32 == 0, N % 128 == 0. */
+int ap_split_f16_weights(const float* w32, void* out, size_t count, ap_stream_t stream);
 
 /* ---- fused-LayerNorm operators (what ap_vit_forward_* chains for f16 / bf16 unless AP_VIT_OPT_F32_STREAM is set) ----
  * The pre-LN block of the reference's encoders (nn.LayerNorm -> nn.Linear, models/patch/vit.py / uni.py / conch.py via

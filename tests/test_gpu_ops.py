@@ -237,6 +237,81 @@ def test_gemm_f32_exact_mfma(env):
     assert (out - ref).abs().max().item() <= 2e-5
 
 
+def _split_rows(env, W):
+    _lib, lib, dev, stream = env
+    out = torch.empty_like(W)
+    _lib.check(lib.ap_split_f16_weights(W.data_ptr(), out.data_ptr(), W.numel(), stream), "ap_split_f16_weights")
+    torch.cuda.synchronize()
+    return out
+
+
+def test_split_f16_weight_rows_are_hi_then_scaled_lo_per_32(env):
+    """ap_split_f16_weights: per 32 consecutive float32 values 32 float16 `hi` = f16(w) followed by 32 float16
+    `lo` = f16((w - hi) * 2^11); hi + lo * 2^-11 reproduces w to 2^-22 |w| (and exactly below f16's subnormal range)."""
+    _lib, lib, dev, stream = env
+    g = torch.Generator(device=dev).manual_seed(5)
+    W = torch.randn((96, 128), device=dev, generator=g) * torch.exp2(torch.randint(-20, 4, (96, 128), device=dev, generator=g).float())
+    W[0, :4] = torch.tensor([0.0, -0.0, 1.0, 65504.0], device=dev)
+    got = _split_rows(env, W).cpu().view(torch.float16).reshape(-1, 2, 32)
+    w = W.cpu().reshape(-1, 32)
+    hi = w.to(torch.float16)
+    lo = ((w - hi.float()) * 2048.0).to(torch.float16)
+    assert torch.equal(got[:, 0].view(torch.int16), hi.view(torch.int16))
+    assert torch.equal(got[:, 1].view(torch.int16), lo.view(torch.int16))
+    back = hi.double() + lo.double() / 2048.0
+    assert ((back - w.double()).abs() <= w.double().abs() * 2.0 ** -21 + 2.0 ** -36).all()
+    with pytest.raises(_lib.HipLibraryError):
+        _lib.check(lib.ap_split_f16_weights(W.data_ptr(), W.data_ptr(), 48, stream))        # not whole groups of 32 / in place
+
+
+@pytest.mark.parametrize("epi", ["bias", "gelu", "resid"])
+@pytest.mark.parametrize("case", [((777, 384, 160), 1.0, 0.2), ((3941, 2304, 768), 1.0, 0.03), ((1182, 768, 3072), 0.02, 0.02),
+                                  ((1, 128, 64), 1.0, 0.1), ((1000, 768, 768), 1.0, 1e-5), ((1000, 768, 768), 300.0, 0.03),
+                                  ((2000, 1024, 1024), None, 0.03)])
+def test_gemm_split_f16_products_are_float32_accurate(env, epi, case):
+    """ap_gemm impl 129 (what AP_VIT_OPT_SPLIT_F16 runs): float32 buffers, every product as
+    w_hi a_hi + 2^-11 (w_hi a_lo + w_lo a_hi) on the f16 MFMA with f32 accumulation.  Against a float64 matmul of the same
+    float32 operands it must be as accurate as the exact f32 MFMA chain (impl 128) -- norm-wise <= 1e-6 and no worse than
+    1.25x the exact chain's own error -- on ragged M, large activations and operands whose magnitudes span 18 binades;
+    a matrix whose weights ALL sit below f16's normal range (1e-5: hi and lo are subnormal, 2^-24 / 2^-35 absolute) keeps
+    2^-19 relative (bound 4e-6) -- no checkpoint has one; bit-repeatable."""
+    _lib, lib, dev, stream = env
+    (M, N, K), ascale, wscale = case
+    g = torch.Generator(device=dev).manual_seed(M + N + K)
+    A = torch.randn((M, K), device=dev, generator=g)
+    A = A * ascale if ascale is not None else A * torch.exp2(torch.randint(-12, 6, (M, K), device=dev, generator=g).float())
+    W = torch.randn((N, K), device=dev, generator=g) * wscale
+    bias = torch.randn(N, device=dev, generator=g) * 0.1 * wscale * max(1.0, ascale or 1.0) * K ** 0.5
+    gamma = torch.rand(N, device=dev, generator=g) + 0.5 if epi == "resid" else None
+    resid = torch.randn((M, N), device=dev, generator=g) * wscale * (ascale or 1.0) if epi == "resid" else None
+    C = A.double() @ W.double().t() + bias.double()
+    ref = torch.nn.functional.gelu(C) if epi == "gelu" else (resid.double() + C * gamma.double() if epi == "resid" else C)
+    Ws = _split_rows(env, W)
+    err = {}
+    for tag, impl, w in (("exact", 128, W), ("split", 129, Ws), ("split again", 129, Ws)):
+        out = resid.clone() if epi == "resid" else torch.full((M, N), float("nan"), device=dev)
+        _lib.check(lib.ap_gemm(_lib.AP_F32, EPI[epi], A.data_ptr(), K, w.data_ptr(), K, M, N, K, bias.data_ptr(),
+                               gamma.data_ptr() if gamma is not None else None, out.data_ptr(), N, impl, 0, stream), "ap_gemm")
+        torch.cuda.synchronize()
+        err[tag] = float((out.double() - ref).norm() / ref.norm())
+        if tag == "split":
+            first = out
+    assert torch.equal(first, out)
+    print(f"SPLIT_F16 gemm {epi} {case}: exact {err['exact']:.2e} split {err['split']:.2e}")
+    if wscale < 6e-5:
+        assert err["split"] <= 4e-6, err
+    else:
+        assert err["split"] <= 1e-6 and err["split"] <= 1.25 * err["exact"] + 1e-8, err
+
+
+def test_gemm_split_f16_refuses_other_types(env):
+    _lib, lib, dev, stream = env
+    A = torch.zeros((128, 64), device=dev, dtype=torch.float16)
+    b = torch.zeros(128, device=dev)
+    with pytest.raises(_lib.HipLibraryError, match="float32"):
+        _lib.check(lib.ap_gemm(_lib.AP_F16, 0, A.data_ptr(), 64, A.data_ptr(), 64, 128, 128, 64, b.data_ptr(), None, A.data_ptr(), 128, 129, 0, stream))
+
+
 def test_gemm_repeatable(env):
     """Race screen: the same launch five times must be bit-identical (counted-vmcnt LDS-DMA pipeline)."""
     _lib, lib, dev, stream = env

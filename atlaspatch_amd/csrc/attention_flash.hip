@@ -41,17 +41,16 @@
 // Roofline: MFMA (4 * T * T * 64 flop per head; padded to 32-query x 64-key tiles);
 // HBM traffic = q, k, v read once + o written once.
 #include "ap_common.h"
-#include <cstdlib>
 
 namespace ap {
 namespace {
 
 constexpr int kKV = 64;                 // keys per tile
-constexpr int kNW = 8;                  // waves per workgroup
-#ifndef AP_ATTN_NB
-#define AP_ATTN_NB 4
-#endif
-constexpr int kNB = AP_ATTN_NB;         // K/V ring buffers (prefetch distance kNB - 1); >= 3 (the epilogue stages through two idle ones)
+constexpr int kNW = 8;                  // waves per workgroup (round 6: five-, six- and seven-wave workgroups, with a three-buffer
+                                        //   ring so that three are resident, measured slower at 197 / 257 / 261 / 265 / 300 / 320 / 785
+                                        //   tokens: profiles/r06c_attention.txt -- the eighth wave's share of the staging is worth more
+                                        //   than its slot)
+constexpr int kNB = 4;                  // K/V ring buffers (prefetch distance kNB - 1); >= 3 (the epilogue stages through two idle ones)
 
 template <typename T> struct FMma;
 template <> struct FMma<f16> {
@@ -82,10 +81,12 @@ __device__ __forceinline__ void dma16(const char* base, uint32_t off, uint32_t l
         : "memory");
 }
 
-template <int OFF> __device__ __forceinline__ u32x2 tr_read(uint32_t lds_addr) {       // immediate offset: no address VALU
-    u32x2 v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF) : "memory");
-    return v;
+// gfx950 transpose load (ds_read_b64_tr_b16) through the builtin: hipcc folds the constant offset into the instruction, counts
+// it in lgkmcnt itself and is free to issue it early (round 6; the inline-asm form of rounds 2-5 had to be waited for on the spot)
+template <int OFF> __device__ __forceinline__ u32x2 tr_read(const char* lds_ptr) {
+    typedef short s4v __attribute__((__vector_size__(4 * sizeof(short))));
+    const s4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(lds_ptr + OFF));
+    return __builtin_bit_cast(u32x2, v);
 }
 template <int V> struct IntC { static constexpr int value = V; };
 
@@ -110,8 +111,28 @@ __device__ __forceinline__ float half_swap_sum(float v) {
     return lo + hi;
 }
 
+// row sums of P from the ROUNDED operand values (what the P V product multiplies): sum of 8 packed values into f32
+template <typename T> __device__ __forceinline__ float psum8(float acc, typename FMma<T>::Frag pf);
+template <> __device__ __forceinline__ float psum8<f16>(float acc, f16x8 pf) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const u32x4 w = __builtin_bit_cast(u32x4, pf);
+    const h2 one = {(_Float16)1.0f, (_Float16)1.0f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t wk = w[k];
+        acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, wk), one, acc, false);      // v_dot2_f32_f16: exact products, f32 sum
+    }
+    return acc;
+}
+template <> __device__ __forceinline__ float psum8<bf16>(float acc, bf16x8 pf) {
+    const u32x4 w = __builtin_bit_cast(u32x4, pf);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc += __builtin_bit_cast(float, w[k] << 16) + __builtin_bit_cast(float, w[k] & 0xffff0000u);
+    return acc;
+}
+
 template <typename T, int HD>
-__global__ __launch_bounds__(kNW * 64, HD == 64 ? (kNB == 3 ? 6 : 4) : 2)
+__global__ __launch_bounds__(kNW * 64, HD == 64 ? 4 : 2)
 void attention_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int tokens, int heads, int parts, int units,
                             float scale) {
     constexpr int kHD = HD;
@@ -219,7 +240,6 @@ void attention_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int 
         const int chunk = (it * 4 + (vcol >> 4)) ^ ((HD == 64 ? (vrow >> 1) & 1 : (HD == 96 ? 0 : vrow & 3)) << 2);
         va[it] = (uint32_t)(kTileBytes + vrow * RB + (chunk << 4) + (vcol & 15));
     }
-    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
     const float c = scale * 1.4426950408889634f;                         // log2(e) * softmax scale
     float m_run = -INFINITY, l_run = 0.f;
@@ -236,36 +256,42 @@ void attention_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int 
     // by 2^kDefer (exact in f32 accumulation, well inside the f16 / bf16 range as an MFMA operand).
     constexpr float kDefer = 8.0f;
 
-    auto tile = [&](const char* buf, uint32_t bufa, int j, bool full) {
+    // One key tile.  NS = 16-key steps that hold valid keys: 4 = the whole tile, 2 = its first 32-key block only (the second
+    // lies wholly past the end: keys 224..255 at 197 tokens), 1 = its first 16 keys only (the last tile of 197 / 257 / 261 / 265
+    // / 785 tokens holds 5 / 1 / 5 / 9 / 17 keys): S^T is still one 32-key MFMA block, but max / exp / sum / cvt run on the lane's
+    // first 8 scores and one P V step is issued instead of two.
+    auto tile = [&](const char* buf, int j, auto NSc, auto LASTc) {
+        constexpr int NS = decltype(NSc)::value;
+        constexpr bool kLast = decltype(LASTc)::value != 0;              // only the last tile can hold keys past the end
+        constexpr int NKB = NS == 4 ? 2 : 1;                              // 32-key blocks of S^T
+        constexpr int NR = NS == 1 ? 8 : 16;                              // scores per lane and block that can be valid
         // ---------------- S^T = K Q^T  (32 queries x 64 keys); first MFMA of a block takes C = 0
-        f32x16 st[2];
+        f32x16 st[NKB];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            if (kb == 1 && !full) break;
+        for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
             for (int kk = 0; kk < NKK; ++kk) {
                 const Frag kf = *(const Frag*)(buf + kb * 32 * RB + ka[kk]);
                 st[kb] = FMma<T>::run(kf, qf[kk], kk == 0 ? zero16 : st[kb]);
             }
         }
-        if ((j + 1) * kKV > tokens) {                                     // mask keys past the end
+        if (kLast && (j + 1) * kKV > tokens) {                            // mask keys past the end
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                if (kb == 1 && !full) break;
+            for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
+                for (int r = 0; r < NR; ++r) {
                     const int key = j * kKV + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                     if (key >= tokens) st[kb][r] = -INFINITY;
                 }
             }
         }
-        // ---------------- online softmax
-        float mx = st[0][0];
+        // ---------------- online softmax (row maximum three values per instruction: v_max3_f32)
+        float mx = fmaxf(st[0][0], st[0][1]);
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[0][r]);
-        if (full) {
+        for (int r = 2; r < NR; r += 2) mx = fmaxf(fmaxf(mx, st[0][r]), st[0][r + 1]);
+        if constexpr (NKB == 2) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[1][r]);
+            for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, st[1][r]), st[1][r + 1]);
         }
         mx = half_swap_max(mx);
         if (__any((mx - m_run) * c > kDefer)) {
@@ -280,44 +306,32 @@ void attention_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int 
                     for (int e = 0; e < 16; ++e) ot[it][e] *= alpha;
             }
         }
-        // exponent arguments and row sums two scores per instruction (v_pk_fma_f32 / v_pk_add_f32): the kernel is
-        // bound by the number of instructions its waves issue, not by any one pipe
+        // exponent arguments two scores per instruction (v_pk_fma_f32)
         const f32x2_t c2 = {c, c}, nmb2 = {-m_run * c, -m_run * c};
-        f32x2_t ps2 = {0.f, 0.f};
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            if (kb == 1 && !full) break;
+        for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
+            for (int r = 0; r < NR; r += 2) {
                 const f32x2_t a = __builtin_elementwise_fma(f32x2_t{st[kb][r], st[kb][r + 1]}, c2, nmb2);
-                const f32x2_t p = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
-                ps2 += p;
-                st[kb][r] = p[0];
-                st[kb][r + 1] = p[1];
+                st[kb][r] = __builtin_amdgcn_exp2f(a[0]);
+                st[kb][r + 1] = __builtin_amdgcn_exp2f(a[1]);
             }
         }
-        l_run += ps2[0] + ps2[1];
 
-        // ---------------- O^T += V^T P^T
+        // ---------------- O^T += V^T P^T; the row sums are taken from the ROUNDED P (psum8: the very values the product
+        // multiplies -- out = sum p~ v / sum p~ is a convex combination of the v rows whatever the rounding of p~ did)
         auto pv_step = [&](auto SP) {                                     // one 16-key step
             constexpr int sp = decltype(SP)::value;
             Frag pf;
 #pragma unroll
             for (int e = 0; e < 8; ++e) pf[e] = (T)st[sp >> 1][(sp & 1) * 8 + e];
+            l_run = psum8<T>(l_run, pf);
             u32x2 va_[NIT], vb_[NIT];
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                va_[it] = tr_read<sp * 16 * RB>(bufa + va[it]);
-                vb_[it] = tr_read<sp * 16 * RB + 8 * RB>(bufa + va[it]);
+                va_[it] = tr_read<sp * 16 * RB>(buf + va[it]);
+                vb_[it] = tr_read<sp * 16 * RB + 8 * RB>(buf + va[it]);
             }
-            // the loads' destinations count as written only from here on (hipcc does not track asm loads)
-            if constexpr (NIT == 2)
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(va_[0]), "+v"(vb_[0]), "+v"(va_[1]), "+v"(vb_[1]) :: "memory");
-            else if constexpr (NIT == 3)
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(va_[0]), "+v"(vb_[0]), "+v"(va_[1]), "+v"(vb_[1]), "+v"(va_[2]), "+v"(vb_[2]) :: "memory");
-            else
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(va_[0]), "+v"(vb_[0]), "+v"(va_[1]), "+v"(vb_[1]), "+v"(va_[2]), "+v"(vb_[2]),
-                             "+v"(va_[NIT - 1]), "+v"(vb_[NIT - 1]) :: "memory");
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const u32x4 f = {va_[it][0], va_[it][1], vb_[it][0], vb_[it][1]};
@@ -325,14 +339,15 @@ void attention_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int 
             }
         };
         pv_step(IntC<0>{});
-        pv_step(IntC<1>{});
-        if (full) {
+        if constexpr (NS >= 2) pv_step(IntC<1>{});
+        if constexpr (NS == 4) {
             pv_step(IntC<2>{});
             pv_step(IntC<3>{});
         }
     };
 
-    for (int j = 0; j < nkv; ++j) {
+    // every tile but the last is whole; the last one runs the variant its valid keys need (peeled: one tile body inside the loop)
+    auto step = [&](int j, auto NSc, auto LASTc) {
         // tile j has landed when at most the 2 loads of each younger staged tile (j + 1, j + 2) are still in flight
         const int ahead = nkv - 1 - j < kNB - 2 ? nkv - 1 - j : kNB - 2;
         if (ahead == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -342,11 +357,15 @@ void attention_flash_kernel(const T* __restrict__ qkv, T* __restrict__ out, int 
         // ONE barrier per tile: tile j + 3 goes into the buffer of tile j - 1, which every wave has left by now
         if (j + kNB - 1 < nkv) stage(j + kNB - 1);
         const char* buf = smem + (j % kNB) * 2 * kTileBytes;
-        const uint32_t bufa = lds_base + (j % kNB) * 2 * kTileBytes;
-
-        // A wave without queries (8th wave at T = 197) only stages and keeps the barriers; a tile whose
-        // second 32-key block lies wholly past the end (keys 224..255 at T = 197) runs as a half tile.
-        if (active) tile(buf, bufa, j, j * kKV + 32 < tokens);
+        // A wave without queries (8th wave at T = 197) only stages and keeps the barriers.
+        if (active) tile(buf, j, NSc, LASTc);
+    };
+    for (int j = 0; j < nkv - 1; ++j) step(j, IntC<4>{}, IntC<0>{});
+    {
+        const int left = tokens - (nkv - 1) * kKV;                        // valid keys of the last tile (1 .. 64)
+        if (left > 32) step(nkv - 1, IntC<4>{}, IntC<1>{});
+        else if (left > 16) step(nkv - 1, IntC<2>{}, IntC<1>{});
+        else step(nkv - 1, IntC<1>{}, IntC<1>{});
     }
 
     const float inv = 1.0f / half_swap_sum(l_run);

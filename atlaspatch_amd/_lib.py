@@ -94,6 +94,10 @@ SIGNATURES = {
     "ap_rowstats_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "ap_gemm_trace": (C.c_int, [C.c_void_p, C.c_int]),
     "ap_split_f16_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ap_gemm_split_f16": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                    C.c_void_p, C.c_int, C.c_void_p]),
+    "ap_gemm_split_f16_windows": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                            C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ap_layernorm": (C.c_int, [C.c_int, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                C.c_float, C.c_void_p, C.c_void_p]),
     "ap_attention": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -105,6 +109,8 @@ SIGNATURES = {
     "ap_softmax_rows": (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]),
     "ap_sattention_f32": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_long, C.c_void_p]),
+    "ap_sattention_split_f16": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_long, C.c_void_p]),
     "ap_sam2_patchify": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p,
                                    C.c_void_p]),
     "ap_window_partition": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -147,6 +147,12 @@ struct GemmArgs {
     // float32 buffers with split-f16 products (gemm.hip, 128 x 128 kernel): W points at the [hi 32 | lo 32] f16 rows that
     // launch_split_f16_weights made of the f32 matrix (same row stride in bytes, ldw still counts f32 elements)
     int split;
+    const float* resid; int ldr;   // split form, EPI_BIAS_STORE / EPI_BIAS_GELU: out = act(acc + bias) + resid[m][n] (f32 [M, ldr], may alias nothing)
+    // split form, windowed layers of the SAM2 trunk (hieradet.py window_partition / window_unpartition folded into the GEMM):
+    // win_mode 1: A is [B * H * W, lda] in image order and row m of the product is the window-order row (padding rows read
+    // zero_row, f32 [>= K] zeros); win_mode 2: out / resid are in image order, window-order row m is scattered, padding rows dropped
+    int win_mode, win_ws, win_H, win_W, win_nwy, win_nwx;
+    const float* zero_row;
 };
 void set_gemm_trace(long long* buf, int tiles_per_wg);
 
@@ -244,7 +250,7 @@ int launch_chw_to_patchrows(int x_dtype, int dtype, const void* x, int n, int S,
 // fused float32 attention of the SAM2 trunk's image-wide blocks (sam2_attention.hip)
 bool sattention_supports(int heads, int tq, int tk, int d, long ldq, long ldk, long ldv, long ldo);
 int launch_sattention(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv, int batch, int heads, int tq,
-                      int tk, int d, float scale, float* out, long ldo, hipStream_t stream);
+                      int tk, int d, float scale, float* out, long ldo, hipStream_t stream, bool exact);
 
 // content statistics (content.hip): counts [n, 2] = (#gray < black_thresh, #(S < sat_thresh && V >= value_thresh))
 int tile_content_counts(const uint8_t* tiles, int n, int h, int w, int black_thresh, int sat_thresh,

@@ -178,6 +178,50 @@ int ap_split_f16_weights(const float* w32, void* out, size_t count, ap_stream_t 
     return ap::launch_split_f16_weights(w32, out, count, (hipStream_t)stream);
 }
 
+static int gemm_split_f16(const float* A, int lda, const void* w_split, int M, int N, int K, const float* bias, int act,
+                          const float* resid, int ldr, float* out, int ldo, int win_mode, int b, int h, int w, int ws, ap_stream_t stream) {
+    AP_REQUIRE(A && w_split && out, "ap_gemm_split_f16: null pointer");
+    AP_REQUIRE(act == 0 || act == 1, "ap_gemm_split_f16: act %d (0 none, 1 GELU)", act);
+    AP_REQUIRE(M > 0 && N > 0 && N % 32 == 0 && K > 0 && K % 32 == 0, "ap_gemm_split_f16: %d x %d x %d (N and K multiples of 32)", M, N, K);
+    AP_REQUIRE(lda >= K && lda % 4 == 0 && ldo >= N && ldo % 4 == 0 && (!resid || (ldr >= N && ldr % 4 == 0)), "ap_gemm_split_f16: strides");
+    AP_REQUIRE(((uintptr_t)A | (uintptr_t)w_split | (uintptr_t)out | (uintptr_t)resid | (uintptr_t)bias) % 16 == 0, "ap_gemm_split_f16: 16-byte aligned pointers");
+    ap::GemmArgs g{};
+    g.A = A; g.lda = lda; g.W = w_split; g.ldw = K; g.M = M; g.N = N; g.K = K;
+    g.bias = bias; g.out = out; g.ldo = ldo; g.resid = resid; g.ldr = ldr; g.split = 1;
+    if (win_mode != 0) {
+        AP_REQUIRE((win_mode == 1 || win_mode == 2) && b > 0 && h > 0 && w > 0 && ws > 0, "ap_gemm_split_f16_windows: mode %d, %d x %d x %d, window %d", win_mode, b, h, w, ws);
+        g.win_mode = win_mode; g.win_ws = ws; g.win_H = h; g.win_W = w; g.win_nwy = (h + ws - 1) / ws; g.win_nwx = (w + ws - 1) / ws;
+        AP_REQUIRE((long)b * g.win_nwy * g.win_nwx * ws * ws == (long)M, "ap_gemm_split_f16_windows: M = %d is not %d images x %d x %d windows of %d x %d", M, b,
+                   g.win_nwy, g.win_nwx, ws, ws);
+        if (win_mode == 1) {
+            // padding rows of the gathered operand: one row of zeros per device, allocated on first use (outside any stream capture: the
+            // predictor's warm-up forward comes first)
+            constexpr int kZeroFloats = 16384;
+            static float* zero_rows[64] = {};
+            int dev = 0;
+            AP_HIP_CHECK(hipGetDevice(&dev));
+            AP_REQUIRE(dev >= 0 && dev < 64 && K <= kZeroFloats, "ap_gemm_split_f16_windows: device %d / K %d", dev, K);
+            if (!zero_rows[dev]) {
+                AP_HIP_CHECK(hipMalloc((void**)&zero_rows[dev], kZeroFloats * sizeof(float)));
+                AP_HIP_CHECK(hipMemsetAsync(zero_rows[dev], 0, kZeroFloats * sizeof(float), (hipStream_t)stream));   // ordered before this launch
+            }
+            g.zero_row = zero_rows[dev];
+        }
+    }
+    return ap::launch_gemm_impl(AP_F32, act == 1 ? ap::EPI_BIAS_GELU : ap::EPI_BIAS_STORE, g, 128, 0, (hipStream_t)stream);
+}
+
+int ap_gemm_split_f16(const float* A, int lda, const void* w_split, int M, int N, int K, const float* bias, int act,
+                      const float* resid, int ldr, float* out, int ldo, ap_stream_t stream) {
+    return gemm_split_f16(A, lda, w_split, M, N, K, bias, act, resid, ldr, out, ldo, 0, 0, 0, 0, 0, stream);
+}
+
+int ap_gemm_split_f16_windows(const float* A, int lda, const void* w_split, int M, int N, int K, const float* bias, int act,
+                              const float* resid, int ldr, float* out, int ldo, int win_mode, int b, int h, int w, int ws,
+                              ap_stream_t stream) {
+    return gemm_split_f16(A, lda, w_split, M, N, K, bias, act, resid, ldr, out, ldo, win_mode, b, h, w, ws, stream);
+}
+
 int ap_gemm_fused(int dtype, int epilogue, const void* A, int lda, const void* W, int ldw, int M, int N, int K,
                   const float* bias, const float* colsum, const float* rowstats, float* partial, void* out, int ldo,
                   int impl, ap_stream_t stream) {

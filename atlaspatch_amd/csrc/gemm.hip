@@ -144,6 +144,15 @@ __device__ __forceinline__ void split8(f32x4 x0, f32x4 x1, f16x8& hi8, f16x8& lo
     }
 }
 
+// window-order row -> image-order row of a [B, H, W] token grid cut into ws x ws windows (zero-padded at the right / bottom
+// edge: hieradet.py window_partition), or -1 for a padding row.  ap_window_partition's layout.
+__device__ __forceinline__ int window_row(int m, int ws, int H, int W, int nwy, int nwx) {
+    const int t = ws * ws, w = m / t, r = m - w * t, iy = r / ws, ix = r - iy * ws;
+    const int per = nwy * nwx, b = w / per, wi = w - b * per, wy = wi / nwx, wx = wi - wy * nwx;
+    const int y = wy * ws + iy, x = wx * ws + ix;
+    return (y < H && x < W) ? (b * H + y) * W + x : -1;
+}
+
 __device__ __forceinline__ void dma16(const char* gsrc, char* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
@@ -163,7 +172,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     const int nblk = gridDim.x, b = blockIdx.x;
     const int q8 = nblk >> 3, r8 = nblk & 7, xcd = b & 7, idx = b >> 3;
     const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-    const int tiles_n = g.N / kTile;
+    // (split-f16 form only: N may be any multiple of 32 -- weight rows past N are staged from the last row and never stored)
+    const int tiles_n = SPLIT ? (g.N + kTile - 1) / kTile : g.N / kTile;
     const int m0 = (lid / tiles_n) * kTile, n0 = (lid % tiles_n) * kTile;
 
     // ---- staging plan: wave-instruction s of this wave fills tile rows [8*(4*wave+s), +8)
@@ -175,8 +185,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
         int am = m0 + row;
         am = am < g.M ? am : g.M - 1;
-        srcW[s] = (const char*)g.W + ((size_t)(n0 + row) * g.ldw) * sizeof(T) + chunk * 16;
+        int wn = n0 + row;
+        if constexpr (SPLIT) wn = wn < g.N ? wn : g.N - 1;
+        srcW[s] = (const char*)g.W + ((size_t)wn * g.ldw) * sizeof(T) + chunk * 16;
         srcA[s] = (const char*)g.A + ((size_t)am * g.lda) * sizeof(T) + chunk * 16;
+        if constexpr (SPLIT) {
+            if (g.win_mode == 1) {             // A is in image order: gather the window-order row, padding rows from the zero row
+                const int r = window_row(am, g.win_ws, g.win_H, g.win_W, g.win_nwy, g.win_nwx);
+                srcA[s] = (r >= 0 ? (const char*)g.A + ((size_t)r * g.lda) * sizeof(T) : (const char*)g.zero_row) + chunk * 16;
+            }
+        }
     }
     auto stage = [&](int buf, int kt) {
         char* base = smem + buf * kBufBytes + wave * 4096;
@@ -194,7 +212,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-            const f32x4 b4 = *(const f32x4*)(g.bias + n0 + wave_n * 64 + nt * 32 + g4 * 8 + hi * 4);
+            const int nb = n0 + wave_n * 64 + nt * 32 + g4 * 8 + hi * 4;
+            const f32x4 b4 = !SPLIT || (nb < g.N && g.bias) ? *(const f32x4*)(g.bias + nb) : f32x4{0.f, 0.f, 0.f, 0.f};
             constexpr bool kNormInit = EPI == EPI_NORM_STORE || EPI == EPI_NORM_GELU || EPI == EPI_NORM_SWIGLU || EPI == EPI_NORM_QGELU;   // (these start from zero)
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
@@ -427,15 +446,36 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
         } else {
             orow = (size_t)m * (size_t)g.ldo;
         }
+        int rrow = m;                          // row of the separate residual
+        if constexpr (SPLIT) {
+            if (g.win_mode == 2) {             // out / resid are in image order: scatter the window-order row, drop padding rows
+                rrow = window_row(m, g.win_ws, g.win_H, g.win_W, g.win_nwy, g.win_nwx);
+                if (rrow < 0) continue;
+                orow = (size_t)rrow * (size_t)g.ldo;
+            }
+        }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int n = n0 + wave_n * 64 + nt * 32 + g4 * 8 + hi * 4;
+                if constexpr (SPLIT) { if (n >= g.N) continue; }
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[nt][mt][g4 * 4 + e];
-                if constexpr (EPI == EPI_BIAS_STORE) {
+                if constexpr (SPLIT && (EPI == EPI_BIAS_STORE || EPI == EPI_BIAS_GELU)) {
+                    // separate residual (the SAM2 trunk's x = shortcut + f(x)): added AFTER the activation, GemmArgs::resid
+                    if constexpr (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                    }
+                    if (g.resid) {
+                        const f32x4 r = *(const f32x4*)(g.resid + (size_t)rrow * (size_t)g.ldr + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += r[e];
+                    }
+                    *(f32x4*)((float*)g.out + orow + n) = v;
+                } else if constexpr (EPI == EPI_BIAS_STORE) {
                     if (g.gamma) {
                         const f32x4 ga = *(const f32x4*)(g.gamma + n);
 #pragma unroll
@@ -483,7 +523,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 
 // float32 buffers, split-f16 products (GemmArgs::split; W = the [hi | lo] rows of launch_split_f16_weights)
 int launch_split(int epilogue, const GemmArgs& a, hipStream_t stream) {
-    const int tiles = ((a.M + kTile - 1) / kTile) * (a.N / kTile);
+    const int tiles = ((a.M + kTile - 1) / kTile) * ((a.N + kTile - 1) / kTile);
     dim3 grid(tiles), block(256);
     switch (epilogue) {
         case EPI_BIAS_STORE: gemm_kernel<float, EPI_BIAS_STORE, true><<<grid, block, 0, stream>>>(a); break;
@@ -558,7 +598,9 @@ int launch_gemm_impl(int dtype, int epilogue, const GemmArgs& a, int impl, int v
     if (impl == 256 || (impl == 0 && a.M >= 256 && !few_tiles && gemm256_supports(dtype, epilogue, a)))
         return launch_gemm256(dtype, epilogue, a, variant, stream);
     const int kt = kRowBytes / (int)dtype_size(dtype);
-    AP_REQUIRE(a.N % kTile == 0, "gemm: N=%d must be a multiple of %d", a.N, kTile);
+    AP_REQUIRE(a.split ? a.N % 32 == 0 : a.N % kTile == 0, "gemm: N=%d must be a multiple of %d", a.N, a.split ? 32 : kTile);
+    AP_REQUIRE(a.resid == nullptr || (a.split && (epilogue == EPI_BIAS_STORE || epilogue == EPI_BIAS_GELU) && a.ldr >= a.N && a.ldr % 4 == 0),
+               "gemm: a separate residual is an option of the split-f16 form's bias / GELU epilogues");
     AP_REQUIRE(a.K % kt == 0, "gemm: K=%d must be a multiple of %d for this dtype", a.K, kt);
     AP_REQUIRE(a.lda >= a.K && a.ldw >= a.K, "gemm: leading dimensions smaller than K");
     AP_REQUIRE(((size_t)a.lda * dtype_size(dtype)) % 16 == 0 && ((size_t)a.ldw * dtype_size(dtype)) % 16 == 0,

@@ -22,7 +22,14 @@
 //     O^T = V^T P^T takes exactly those registers as its B operand (k slot of step s = accumulator s), so P never moves.
 // Softmax in the log2 domain (scale * log2(e) folded into the exponent), float32 throughout.
 //
-// Roofline: f32 MFMA, 4 * tq * tk * d flop per head.
+// Split-f16 form (SPLIT, round 6; the default -- ap_sattention_f32's `exact` argument selects the chain above): every operand
+// x = hi + lo with hi = f16(x), lo = f16(x - hi) (22 of 24 mantissa bits; the f16 MFMA takes subnormal operands exactly --
+// tools/isa_probes/mfma_f16_denorm.hip -- so a small lo only loses absolute precision below 2^-25) and both products as
+//     a b ~= a_hi b_hi + a_hi b_lo + a_lo b_hi        three v_mfma_f32_32x32x16_f16 into the SAME f32 accumulator
+// 36 MFMAs of 32 cycles per 32-key tile at d = 96 instead of 96 of 64 cycles; the split costs ~3 VALU per value.  Same
+// loads, same fragment assignment (a lane's eight k slots of a 16-deep step are two of its 16-byte vectors), same softmax.
+//
+// Roofline: f32 MFMA, 4 * tq * tk * d flop per head (split form: three times that on the f16 MFMA).
 #include "ap_common.h"
 
 namespace ap {
@@ -39,6 +46,22 @@ __device__ __forceinline__ float sa_partner_sum(float v) {
     return a + b;
 }
 
+// 8 f32 -> f16 hi and f16 lo = f16(x - hi), unscaled
+__device__ __forceinline__ void sa_split8(f32x4 x0, f32x4 x1, f16x8& hi8, f16x8& lo8) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f16 h0 = (f16)x0[j], h1 = (f16)x1[j];
+        hi8[j] = h0; hi8[4 + j] = h1;
+        lo8[j] = (f16)(x0[j] - (float)h0);
+        lo8[4 + j] = (f16)(x1[j] - (float)h1);
+    }
+}
+__device__ __forceinline__ f32x16 sa_mma3(f16x8 ah, f16x8 al, f16x8 bh, f16x8 bl, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);          // the small terms first
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
+}
+
 struct SAttnArgs {
     const float *q, *k, *v;
     float* out;
@@ -48,7 +71,7 @@ struct SAttnArgs {
 };
 
 // DB = d / 32 (1..3)
-template <int DB>
+template <int DB, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void sattention_kernel(SAttnArgs a) {
     constexpr int D = DB * 32;
     constexpr int KJ = D / 8;                       // 16-byte K / Q vectors per lane
@@ -111,13 +134,22 @@ __global__ __launch_bounds__(256, 2) void sattention_kernel(SAttnArgs a) {
         f32x16 st;
 #pragma unroll
         for (int e = 0; e < 16; ++e) st[e] = 0.f;
+        if constexpr (SPLIT) {
 #pragma unroll
-        for (int j = 0; j < KJ; ++j)
-            {
+            for (int j = 0; j < KJ; j += 2) {                     // one 16-deep step = the lane's vectors j, j + 1 on both operands
+                f16x8 kh, kl, qh, ql;
+                sa_split8(kf[j], kf[j + 1], kh, kl);
+                sa_split8(*(const f32x4*)&qs[l31][8 * j + 4 * hi], *(const f32x4*)&qs[l31][8 * j + 8 + 4 * hi], qh, ql);
+                st = sa_mma3(kh, kl, qh, ql, st);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < KJ; ++j) {
                 const f32x4 qv = *(const f32x4*)&qs[l31][8 * j + 4 * hi];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j][e], qv[e], st, 0, 0, 0);
             }
+        }
         if (t + 4 < ntiles) load_k(t + 4);                      // flies under the softmax and the second product
         if (t * 32 + 32 > a.tk) {                               // ragged last tile: keys past the end score -inf
             const int lim = a.tk - t * 32 - 4 * hi;
@@ -145,10 +177,26 @@ __global__ __launch_bounds__(256, 2) void sattention_kernel(SAttnArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) ot[db][e] *= alpha;
         // ---------------- O^T += V^T P^T
+        if constexpr (SPLIT) {
 #pragma unroll
-        for (int s = 0; s < 16; ++s)
+            for (int u = 0; u < 2; ++u) {                         // keys 16 u ..: accumulator / V registers 8 u .. 8 u + 7
+                f16x8 ph, pl;
+                sa_split8(f32x4{st[8 * u], st[8 * u + 1], st[8 * u + 2], st[8 * u + 3]},
+                          f32x4{st[8 * u + 4], st[8 * u + 5], st[8 * u + 6], st[8 * u + 7]}, ph, pl);
 #pragma unroll
-            for (int db = 0; db < DB; ++db) ot[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[db][s], st[s], ot[db], 0, 0, 0);
+                for (int db = 0; db < DB; ++db) {
+                    f16x8 vh, vl;
+                    sa_split8(f32x4{vf[db][8 * u], vf[db][8 * u + 1], vf[db][8 * u + 2], vf[db][8 * u + 3]},
+                              f32x4{vf[db][8 * u + 4], vf[db][8 * u + 5], vf[db][8 * u + 6], vf[db][8 * u + 7]}, vh, vl);
+                    ot[db] = sa_mma3(vh, vl, ph, pl, ot[db]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+#pragma unroll
+                for (int db = 0; db < DB; ++db) ot[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[db][s], st[s], ot[db], 0, 0, 0);
+        }
         if (t + 4 < ntiles) load_v(t + 4);                      // flies under the next tile's first product
     }
     l_run = sa_partner_sum(l_run);
@@ -199,17 +247,25 @@ bool sattention_supports(int heads, int tq, int tk, int d, long ldq, long ldk, l
 }
 
 int launch_sattention(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv, int batch, int heads, int tq,
-                      int tk, int d, float scale, float* out, long ldo, hipStream_t stream) {
+                      int tk, int d, float scale, float* out, long ldo, hipStream_t stream, bool exact) {
     AP_REQUIRE(q && k && v && out && batch > 0 && batch <= 65535, "sattention: bad arguments");
     AP_REQUIRE(sattention_supports(heads, tq, tk, d, ldq, ldk, ldv, ldo),
                "sattention: unsupported shape (d 32 / 64 / 96, row strides multiples of 4 floats)");
     AP_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)out) & 15) == 0, "sattention: q / k / out must be 16-byte aligned");
     SAttnArgs a{q, k, v, out, ldq, ldk, ldv, ldo, tq, tk, scale * 1.4426950408889634f};
     dim3 grid((tq + 31) / 32, heads, batch), block(256);
-    switch (d / 32) {
-        case 1: sattention_kernel<1><<<grid, block, 0, stream>>>(a); break;
-        case 2: sattention_kernel<2><<<grid, block, 0, stream>>>(a); break;
-        default: sattention_kernel<3><<<grid, block, 0, stream>>>(a); break;
+    if (exact) {
+        switch (d / 32) {
+            case 1: sattention_kernel<1, false><<<grid, block, 0, stream>>>(a); break;
+            case 2: sattention_kernel<2, false><<<grid, block, 0, stream>>>(a); break;
+            default: sattention_kernel<3, false><<<grid, block, 0, stream>>>(a); break;
+        }
+    } else {
+        switch (d / 32) {
+            case 1: sattention_kernel<1, true><<<grid, block, 0, stream>>>(a); break;
+            case 2: sattention_kernel<2, true><<<grid, block, 0, stream>>>(a); break;
+            default: sattention_kernel<3, true><<<grid, block, 0, stream>>>(a); break;
+        }
     }
     AP_HIP_CHECK(hipGetLastError());
     return AP_OK;

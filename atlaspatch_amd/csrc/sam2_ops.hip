@@ -529,7 +529,12 @@ int ap_sgemm_stacked(const float* A, long lda, const float* W, long ldw, int sta
 
 int ap_sattention_f32(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv, int batch, int heads, int tq,
                       int tk, int d, float scale, float* out, long ldo, ap_stream_t stream) {
-    return ap::launch_sattention(q, ldq, k, ldk, v, ldv, batch, heads, tq, tk, d, scale, out, ldo, (hipStream_t)stream);
+    return ap::launch_sattention(q, ldq, k, ldk, v, ldv, batch, heads, tq, tk, d, scale, out, ldo, (hipStream_t)stream, /*exact=*/true);
+}
+
+int ap_sattention_split_f16(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv, int batch, int heads, int tq,
+                            int tk, int d, float scale, float* out, long ldo, ap_stream_t stream) {
+    return ap::launch_sattention(q, ldq, k, ldk, v, ldv, batch, heads, tq, tk, d, scale, out, ldo, (hipStream_t)stream, /*exact=*/false);
 }
 
 int ap_softmax_rows(float* x, long ld, int rows, int cols, ap_stream_t stream) {

@@ -62,6 +62,11 @@ class Sam2HipPredictor:
         self._batch_graphs: dict = {}
         self.fused_attention = os.environ.get("ATLASPATCH_SAM2_UNFUSED_ATTENTION") in (None, "", "0")
         self.wide_gemm = os.environ.get("ATLASPATCH_SAM2_NO_WIDE_GEMM") in (None, "", "0")      # A/B switch of _gemm's kernel choice
+        # row-wise layers as split-f16 products (ap_gemm_split_f16: three f16 MFMA passes on hi / lo halves, f32 accumulation;
+        # float32-accurate -- measured closer to float64 than the exact f32 MFMA chain on every layer shape -- at 1.3-3x its
+        # rate); ATLASPATCH_SAM2_EXACT_F32=1 keeps the exact chain everywhere (rounds 2-5's arithmetic)
+        self.split_gemm = os.environ.get("ATLASPATCH_SAM2_EXACT_F32") in (None, "", "0")
+        self._split: dict = {}               # data_ptr of a weight matrix -> its [hi | lo] f16 rows (ap_split_f16_weights)
         self._static_img = self._static_mask = None
         self._resamplers: dict = {}
         f = lambda t: t.detach().to(torch.float32).contiguous()
@@ -119,6 +124,16 @@ class Sam2HipPredictor:
             self.w[f"hyper{k}.w"] = dev(sd[d + f"output_hypernetworks_mlps.0.layers.{k}.weight"])
             self.w[f"hyper{k}.b"] = dev(sd[d + f"output_hypernetworks_mlps.0.layers.{k}.bias"])
 
+        if self.split_gemm:
+            with torch.cuda.device(self.device):
+                for name, t in self.w.items():
+                    if t.dim() == 2 and t.shape[0] % 32 == 0 and t.shape[1] % 32 == 0 and t.data_ptr() % 16 == 0:
+                        out = torch.empty_like(t)
+                        _lib.check(self.lib.ap_split_f16_weights(t.data_ptr(), out.data_ptr(), t.numel(), self._stream()),
+                                   "ap_split_f16_weights")
+                        self._split[t.data_ptr()] = out
+                torch.cuda.synchronize(self.device)
+
     # ------------------------------------------------------------------ constants of the box prompt
     @staticmethod
     def _prompt_constants(sd: dict, size: int = 1024):
@@ -152,14 +167,24 @@ class Sam2HipPredictor:
         out = self._buf(m, n) if out is None else out
         if self._flop is not None:
             self._flop += 2.0 * batch * m * n * k
-        # Wide row-wise layers go to the encoder's float32 GEMM (ap_gemm, 128 x 128 tiles, the same v_mfma_f32_32x32x2_f32
-        # arithmetic, erf GELU): with >= 512 tiles per image it fills the chip better than ap_sgemm's plan (round 5,
-        # tools/sgemm_vs_gemm_probe.py: 0.69-0.83 x the time on the five shapes this selects, 1.0-2.7 x on the ones it does not).
-        # The choice looks at ONE image's rows, never at the batch: a row's result does not depend on what it is stacked with.
-        if (self.wide_gemm and batch == 1 and not w_kn and alpha == 1.0 and resid is None and bias is not None and act in (0, 1)
+        # Row-wise layers with >= 90 tiles of 128 x 128 per image go to the 128 x 128-tile kernel of the encoder path: as split-f16
+        # products (default; tools/sgemm_vs_split_probe.py: 0.33-0.79 x ap_sgemm's time on the shapes this selects, 0.95-1.9 x on
+        # the ones it does not -- profiles/r06d_sgemm_vs_split.txt), or -- ATLASPATCH_SAM2_EXACT_F32=1 -- the five widest on its
+        # exact f32 form (round 5).  The choice looks at ONE image's rows, never at the batch, and neither kernel splits K: a
+        # row's result does not depend on what it is stacked with.
+        plain = batch == 1 and not w_kn and alpha == 1.0 and act in (0, 1) and (lda is None or lda == k) and (ldw is None or ldw == k)
+        tiles = -(-(m // stack) // 128) * -(-n // 128)
+        if (self.wide_gemm and self.split_gemm and plain and tiles >= 90 and n % 32 == 0 and k % 32 == 0 and w.data_ptr() in self._split
+                and a.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0 and (ldo is None or ldo % 4 == 0)
+                and (resid is None or (resid.data_ptr() % 16 == 0 and (ldr is None or ldr % 4 == 0)))):
+            _lib.check(self.lib.ap_gemm_split_f16(a.data_ptr(), k, self._split[w.data_ptr()].data_ptr(), m, n, k,
+                                                  bias.data_ptr() if bias is not None else None, act,
+                                                  resid.data_ptr() if resid is not None else None, ldr if ldr is not None else n,
+                                                  out.data_ptr(), ldo if ldo is not None else n, self._stream()), "ap_gemm_split_f16")
+            return out
+        if (self.wide_gemm and not self.split_gemm and plain and resid is None and bias is not None
                 and n % 128 == 0 and k % 32 == 0 and k <= 768 and -(-(m // stack) // 128) * (n // 128) >= 512
-                and (lda is None or lda == k) and (ldw is None or ldw == k) and (ldo is None or ldo == n)
-                and a.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0):
+                and (ldo is None or ldo == n) and a.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0):
             _lib.check(self.lib.ap_gemm(_lib.AP_F32, act, a.data_ptr(), k, w.data_ptr(), k, m, n, k, bias.data_ptr(), None,
                                         out.data_ptr(), n, 128, 0, self._stream()), "ap_gemm")
             return out
@@ -180,6 +205,24 @@ class Sam2HipPredictor:
                                      out.data_ptr(), ldo if ldo is not None else n, so, self._stream()), "ap_sgemm")
         return out
 
+    def _gemm_windows(self, a, w, n, k, *, mode, B, H, W, window, bias, resid=None):
+        """A windowed block's qkv (mode 1: `a` in image order -> window-order rows) or proj + residual (mode 2: window-order
+        `a` -> image-order rows added to `resid`) with the (un)partition folded into the split-f16 GEMM; None when that kernel
+        does not take the layer (the caller then partitions / un-partitions with the stand-alone passes)."""
+        nwy, nwx = -(-H // window), -(-W // window)
+        m = B * nwy * nwx * window * window
+        tiles = -(-(m // B) // 128) * -(-n // 128)
+        if not (self.wide_gemm and self.split_gemm and tiles >= 90 and n % 32 == 0 and k % 32 == 0 and w.data_ptr() in self._split
+                and a.data_ptr() % 16 == 0):
+            return None
+        out = self._buf(m if mode == 1 else B * H * W, n)
+        if self._flop is not None:
+            self._flop += 2.0 * m * n * k
+        _lib.check(self.lib.ap_gemm_split_f16_windows(a.data_ptr(), k, self._split[w.data_ptr()].data_ptr(), m, n, k, bias.data_ptr(), 0,
+                                                      resid.data_ptr() if resid is not None else None, n, out.data_ptr(), n,
+                                                      mode, B, H, W, window, self._stream()), "ap_gemm_split_f16_windows")
+        return out
+
     def _ln(self, x, rows, dim, w, b, eps, out=None):
         out = self._buf(rows, dim) if out is None else out
         _lib.check(self.lib.ap_layernorm(_lib.AP_F32, x.data_ptr(), dim, rows, dim, w.data_ptr(), b.data_ptr(), C.c_float(eps),
@@ -195,8 +238,9 @@ class Sam2HipPredictor:
         if (self.fused_attention and d in (32, 64, 96) and nb <= 65535 and ldq % 4 == 0 and ldk % 4 == 0
                 and q.data_ptr() % 16 == 0 and k.data_ptr() % 16 == 0):
             # one fused kernel for all windows and heads: the [nb, heads, tq, tk] score matrix never reaches memory
-            _lib.check(self.lib.ap_sattention_f32(q.data_ptr(), ldq, k.data_ptr(), ldk, v.data_ptr(), ldv, nb, heads, tq, tk, d,
-                                                  scale, out.data_ptr(), heads * d, self._stream()), "ap_sattention_f32")
+            fn = self.lib.ap_sattention_split_f16 if self.split_gemm else self.lib.ap_sattention_f32
+            _lib.check(fn(q.data_ptr(), ldq, k.data_ptr(), ldk, v.data_ptr(), ldv, nb, heads, tq, tk, d,
+                          scale, out.data_ptr(), heads * d, self._stream()), "ap_sattention")
             return out
         scores = self._buf(nb * heads, tq, tk)
         if nb == 1:                     # one image-wide attention: the heads are the batch (head h = column offset h * d)
@@ -244,16 +288,22 @@ class Sam2HipPredictor:
                     pooled = self._buf(B * (H // 2) * (W // 2), dout)
                     _lib.check(lib.ap_maxpool2x2(shortcut.data_ptr(), dout, B, H, W, dout, pooled.data_ptr(), st))
                     shortcut = pooled
+            qkv = None
             if window > 0:
                 nwy, nwx = -(-H // window), -(-W // window)
                 nb, hh, ww = B * nwy * nwx, window, window
-                win = self._buf(nb * hh * ww, din)
-                _lib.check(lib.ap_window_partition(xn.data_ptr(), B, H, W, din, window, win.data_ptr(), st))
-                xn = win
+                # the window partition rides on the qkv GEMM's operand addressing where the split-f16 kernel takes the layer
+                qkv = self._gemm_windows(xn, g("attn.qkv.weight"), 3 * dout, din, mode=1, B=B, H=H, W=W, window=window,
+                                         bias=g("attn.qkv.bias"))
+                if qkv is None:
+                    win = self._buf(nb * hh * ww, din)
+                    _lib.check(lib.ap_window_partition(xn.data_ptr(), B, H, W, din, window, win.data_ptr(), st))
+                    xn = win
             else:
                 nb, hh, ww = B, H, W
             t_k = hh * ww
-            qkv = self._gemm(xn, g("attn.qkv.weight"), 3 * dout, din, bias=g("attn.qkv.bias"), stack=B)     # [nb*t_k, 3*dout]
+            if qkv is None:
+                qkv = self._gemm(xn, g("attn.qkv.weight"), 3 * dout, din, bias=g("attn.qkv.bias"), stack=B)     # [nb*t_k, 3*dout]
             d = dout // heads
             q, ldq, t_q = qkv, 3 * dout, t_k
             if qpool:
@@ -269,9 +319,12 @@ class Sam2HipPredictor:
             # x = shortcut + attn: the residual add rides on the projection GEMM's epilogue (image-wide blocks) or on the
             # window un-partition pass (windowed blocks)
             if window > 0:
-                a = self._gemm(a, g("attn.proj.weight"), dout, dout, bias=g("attn.proj.bias"), stack=B)
-                x2 = self._buf(B * H * W, dout)
-                _lib.check(lib.ap_window_unpartition_add(a.data_ptr(), shortcut.data_ptr(), B, H, W, dout, window, x2.data_ptr(), st))
+                x2 = self._gemm_windows(a, g("attn.proj.weight"), dout, dout, mode=2, B=B, H=H, W=W, window=window,
+                                        bias=g("attn.proj.bias"), resid=shortcut)
+                if x2 is None:
+                    a = self._gemm(a, g("attn.proj.weight"), dout, dout, bias=g("attn.proj.bias"), stack=B)
+                    x2 = self._buf(B * H * W, dout)
+                    _lib.check(lib.ap_window_unpartition_add(a.data_ptr(), shortcut.data_ptr(), B, H, W, dout, window, x2.data_ptr(), st))
             else:
                 x2 = self._gemm(a, g("attn.proj.weight"), dout, dout, bias=g("attn.proj.bias"), resid=shortcut, stack=B)
             xn2 = self._ln(x2, B * H * W, dout, g("norm2.weight"), g("norm2.bias"), 1e-6)

@@ -370,6 +370,25 @@ int ap_gemm(int dtype, int epilogue, const void* A, int lda, const void* W, int 
  * computes  sum_k  w_hi a_hi + 2^-11 (w_hi a_lo + w_lo a_hi)  with a split in registers, f32 accumulation: ~2^-22 per
  * product against the exact f32 chain of impl 128, at 2-3x its rate.  K % 32 == 0, N % 128 == 0. */
 int ap_split_f16_weights(const float* w32, void* out, size_t count, ap_stream_t stream);
+/* The same product as a row-wise float32 layer with an optional SEPARATE residual (the SAM2 trunk's Linear / MLP layers,
+ * services/segmentation.py:120-180 runs them in float32):
+ *   out[m][n] = act(sum_k A[m][k] W[n][k] + bias[n]) + resid[m][n]        act: 0 none, 1 GELU (erf)
+ * A f32 [M, lda], w_split = ap_split_f16_weights of the f32 [N, K] matrix, bias f32 [N] or NULL, resid f32 [M, ldr] or NULL,
+ * out f32 [M, ldo].  N % 32 == 0 (any such N: the 128-wide tile's tail is masked), K % 32 == 0, strides multiples of 4,
+ * pointers 16-byte aligned.  A row's result does not depend on M (no split-K): batches stay bit-identical to single calls. */
+int ap_gemm_split_f16(const float* A, int lda, const void* w_split, int M, int N, int K, const float* bias, int act,
+                      const float* resid, int ldr, float* out, int ldo, ap_stream_t stream);
+/* ... with the window (un)partition of the SAM2 trunk's windowed blocks folded in (sam2 hieradet.py window_partition /
+ * window_unpartition as the reference's SAM2ImagePredictor runs them; replaces ap_window_partition / ap_window_unpartition_add
+ * around the qkv / proj layers).  The token grid is b images of h x w tokens, cut into ws x ws windows, zero-padded at the
+ * right / bottom edge; M = b * ceil(h / ws) * ceil(w / ws) * ws * ws window-order rows.
+ *   win_mode 1: A is [b * h * w, lda] in IMAGE order; product row m takes the image row of window-order row m (zeros for a
+ *               padding row); out [M, ldo] in window order (the qkv layer after norm1).
+ *   win_mode 2: A is [M, lda] in window order; out / resid are [b * h * w, ld] in IMAGE order, padding rows are dropped
+ *               (the proj layer + residual add). */
+int ap_gemm_split_f16_windows(const float* A, int lda, const void* w_split, int M, int N, int K, const float* bias, int act,
+                              const float* resid, int ldr, float* out, int ldo, int win_mode, int b, int h, int w, int ws,
+                              ap_stream_t stream);
 
 /* ---- fused-LayerNorm operators (what ap_vit_forward_* chains for f16 / bf16 unless AP_VIT_OPT_F32_STREAM is set) ----
  * The pre-LN block of the reference's encoders (nn.LayerNorm -> nn.Linear, models/patch/vit.py / uni.py / conch.py via
@@ -445,6 +464,11 @@ int ap_softmax_rows(float* x, long ld, int rows, int cols, ap_stream_t stream); 
  * any tq, tk >= 1; row strides multiples of 4 floats, q / k / out 16-byte aligned. */
 int ap_sattention_f32(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv, int batch, int heads,
                       int tq, int tk, int d, float scale, float* out, long ldo, ap_stream_t stream);
+/* The same operator (same arguments, float32 in and out) with both products as split-f16 MFMA passes:
+ * a b ~= a_hi b_hi + a_hi b_lo + a_lo b_hi on v_mfma_f32_32x32x16_f16 with f32 accumulation, hi = f16(x), lo = f16(x - hi)
+ * (float32-accurate: ~2^-22 per product; the softmax stays float32).  2-3x the rate of the exact chain on the image-wide blocks. */
+int ap_sattention_split_f16(const float* q, long ldq, const float* k, long ldk, const float* v, long ldv, int batch, int heads,
+                            int tq, int tk, int d, float scale, float* out, long ldo, ap_stream_t stream);
 /* uint8 [h, w, 3] -> rows [(h/4)*(w/4), 147] of ((x/255) - mean) / std in (c, ky, kx) order: the im2col of
  * Hiera's PatchEmbed conv (7x7, stride 4, pad 3). */
 int ap_sam2_patchify(const uint8_t* image, int h, int w, const float mean[3], const float stdv[3], float* out,

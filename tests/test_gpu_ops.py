@@ -304,6 +304,80 @@ def test_gemm_split_f16_products_are_float32_accurate(env, epi, case):
         assert err["split"] <= 1e-6 and err["split"] <= 1.25 * err["exact"] + 1e-8, err
 
 
+@pytest.mark.parametrize("case", [(65536, 288, 96, 0, False), (4100, 96, 384, 0, True), (4900, 1152, 384, 0, False), (4096, 1536, 384, 1, False),
+                                  (1000, 384, 1536, 0, True), (130, 32, 64, 1, True), (257, 576, 192, 0, False)])
+def test_gemm_split_f16_rowwise_layer_with_separate_residual(env, case):
+    """ap_gemm_split_f16 (the SAM2 trunk's row-wise layers): any N % 32 == 0 (the 128-wide tile's tail masked), optional
+    bias, erf GELU, optional SEPARATE residual added after the activation; float32-accurate against float64 (<= 5e-7
+    norm-wise); columns beyond N and rows beyond M of a padded output buffer stay untouched."""
+    _lib, lib, dev, stream = env
+    M, N, K, act, with_res = case
+    g = torch.Generator(device=dev).manual_seed(M + N + K)
+    A = torch.randn((M, K), device=dev, generator=g)
+    W = torch.randn((N, K), device=dev, generator=g) * K ** -0.5
+    bias = torch.randn(N, device=dev, generator=g) if M % 2 == 0 else None
+    res = torch.randn((M, N + 8), device=dev, generator=g) if with_res else None
+    out = torch.full((M + 3, N + 4), 7.0, device=dev)
+    Ws = _split_rows(env, W)
+    _lib.check(lib.ap_gemm_split_f16(A.data_ptr(), K, Ws.data_ptr(), M, N, K, bias.data_ptr() if bias is not None else None, act,
+                                     res.data_ptr() if with_res else None, N + 8, out.data_ptr(), N + 4, stream), "ap_gemm_split_f16")
+    torch.cuda.synchronize()
+    ref = A.double() @ W.double().t()
+    if bias is not None:
+        ref = ref + bias.double()
+    if act:
+        ref = torch.nn.functional.gelu(ref)
+    if with_res:
+        ref = ref + res[:, :N].double()
+    err = float((out[:M, :N].double() - ref).norm() / ref.norm())
+    assert err <= 5e-7, err
+    assert bool((out[M:] == 7.0).all()) and bool((out[:, N:] == 7.0).all())
+
+
+@pytest.mark.parametrize("geom", [(1, 64, 64, 14), (2, 32, 32, 7), (1, 256, 256, 8), (3, 30, 22, 8)])
+def test_gemm_split_f16_windows_equals_partition_then_gemm(env, geom):
+    """ap_gemm_split_f16_windows: the window partition as operand addressing (mode 1) and the un-partition + residual add
+    as output addressing (mode 2) give the SAME BITS as ap_window_partition -> ap_gemm_split_f16 and ap_gemm_split_f16 ->
+    ap_window_unpartition_add, zero padding at the right / bottom edge included."""
+    _lib, lib, dev, stream = env
+    B, H, W, ws = geom
+    Cin, Cout = 96, 288
+    nwy, nwx = -(-H // ws), -(-W // ws)
+    M = B * nwy * nwx * ws * ws
+    g = torch.Generator(device=dev).manual_seed(B * H + ws)
+    x = torch.randn((B * H * W, Cin), device=dev, generator=g)
+    Wq = torch.randn((Cout, Cin), device=dev, generator=g) * 0.1
+    bq = torch.randn(Cout, device=dev, generator=g)
+    Wqs = _split_rows(env, Wq)
+    # mode 1
+    win = torch.empty((M, Cin), device=dev)
+    _lib.check(lib.ap_window_partition(x.data_ptr(), B, H, W, Cin, ws, win.data_ptr(), stream))
+    want = torch.empty((M, Cout), device=dev); got = torch.full((M, Cout), float("nan"), device=dev)
+    _lib.check(lib.ap_gemm_split_f16(win.data_ptr(), Cin, Wqs.data_ptr(), M, Cout, Cin, bq.data_ptr(), 0, None, 0, want.data_ptr(), Cout, stream))
+    _lib.check(lib.ap_gemm_split_f16_windows(x.data_ptr(), Cin, Wqs.data_ptr(), M, Cout, Cin, bq.data_ptr(), 0, None, 0, got.data_ptr(), Cout,
+                                             1, B, H, W, ws, stream), "ap_gemm_split_f16_windows")
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    # mode 2
+    a = torch.randn((M, Cout), device=dev, generator=g)
+    Wp = torch.randn((Cin, Cout), device=dev, generator=g) * 0.1        # [N = Cin, K = Cout]
+    bp = torch.randn(Cin, device=dev, generator=g)
+    Wps = _split_rows(env, Wp)
+    shortcut = torch.randn((B * H * W, Cin), device=dev, generator=g)
+    tmp = torch.empty((M, Cin), device=dev)
+    _lib.check(lib.ap_gemm_split_f16(a.data_ptr(), Cout, Wps.data_ptr(), M, Cin, Cout, bp.data_ptr(), 0, None, 0, tmp.data_ptr(), Cin, stream))
+    want2 = torch.empty((B * H * W, Cin), device=dev); got2 = torch.full((B * H * W, Cin), float("nan"), device=dev)
+    _lib.check(lib.ap_window_unpartition_add(tmp.data_ptr(), shortcut.data_ptr(), B, H, W, Cin, ws, want2.data_ptr(), stream))
+    _lib.check(lib.ap_gemm_split_f16_windows(a.data_ptr(), Cout, Wps.data_ptr(), M, Cin, Cout, bp.data_ptr(), 0, shortcut.data_ptr(), Cin,
+                                             got2.data_ptr(), Cin, 2, B, H, W, ws, stream), "ap_gemm_split_f16_windows")
+    torch.cuda.synchronize()
+    # (the stand-alone pass adds resid + v, the epilogue v + resid: the same float32 sum)
+    assert torch.equal(got2, want2)
+    with pytest.raises(_lib.HipLibraryError):
+        _lib.check(lib.ap_gemm_split_f16_windows(a.data_ptr(), Cout, Wps.data_ptr(), M + 32, Cin, Cout, bp.data_ptr(), 0, None, 0, got2.data_ptr(), Cin,
+                                                 2, B, H, W, ws, stream))
+
+
 def test_gemm_split_f16_refuses_other_types(env):
     _lib, lib, dev, stream = env
     A = torch.zeros((128, 64), device=dev, dtype=torch.float16)
@@ -574,9 +648,11 @@ def test_sgemm_mfma_vs_torch(env, case):
 @pytest.mark.parametrize("case", [(1, 4, 4096, 4096, 96), (1, 2, 64, 128, 32), (3, 3, 160, 256, 64), (25, 4, 196, 196, 96),
                                   (25, 8, 49, 196, 96), (64, 1, 64, 64, 96), (100, 2, 16, 64, 96), (1, 8, 9, 9, 32),
                                   (7, 2, 4, 16, 96), (2, 1, 33, 1, 64)])
-def test_sattention_f32_vs_torch(env, case):
+@pytest.mark.parametrize("form", ["ap_sattention_f32", "ap_sattention_split_f16"])
+def test_sattention_f32_vs_torch(env, case, form):
     """ap_sattention_f32 (fused exact-f32 MFMA attention of the SAM2 trunk: image-wide blocks and batched windows, ragged
-    query / key counts, key tiles split over four waves and merged) against softmax(q k^T scale) v in float64; repeatable."""
+    query / key counts, key tiles split over four waves and merged) and its split-f16 form (same arguments; both products as
+    three f16 MFMA passes on hi / lo halves) against softmax(q k^T scale) v in float64, the SAME bound; repeatable."""
     import math
     _lib, lib, dev, stream = env
     nb, heads, tq, tk, d = case
@@ -589,8 +665,8 @@ def test_sattention_f32_vs_torch(env, case):
     outs = []
     for _ in range(3):
         o = torch.full((nb * tq, heads * d), float("nan"), device=dev)
-        _lib.check(lib.ap_sattention_f32(q.data_ptr(), ld, k.data_ptr(), ld, v.data_ptr(), ld, nb, heads, tq, tk, d, scale,
-                                         o.data_ptr(), heads * d, stream), "ap_sattention_f32")
+        _lib.check(getattr(lib, form)(q.data_ptr(), ld, k.data_ptr(), ld, v.data_ptr(), ld, nb, heads, tq, tk, d, scale,
+                                      o.data_ptr(), heads * d, stream), form)
         torch.cuda.synchronize()
         outs.append(o)
     assert all(torch.equal(outs[0], o) for o in outs[1:])
@@ -598,7 +674,9 @@ def test_sattention_f32_vs_torch(env, case):
     kh = k.reshape(nb, tk, heads, d).permute(0, 2, 1, 3).double()
     vh = v.reshape(nb, tk, heads, d).permute(0, 2, 1, 3).double()
     ref = (torch.softmax(qh @ kh.transpose(-1, -2) * scale, -1) @ vh).permute(0, 2, 1, 3).reshape(nb * tq, heads * d).float()
-    assert (outs[0] - ref).abs().max().item() <= 2e-5
+    err = (outs[0] - ref).abs().max().item()
+    print(f"SATTENTION {form} {case}: max abs err {err:.2e}")
+    assert err <= 2e-5
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16, torch.float32])

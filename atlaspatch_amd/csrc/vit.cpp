@@ -313,8 +313,15 @@ int blocks_f32_stream(ap_vit* m, int n, const Workspace& w, StreamTail& st, hipS
                                                 stream)) != AP_OK) return rc;
         }
         { ScopedTimer t(m, AP_PROF_ATTENTION, stream);
-          if ((rc = ap::launch_attention(dt, w.qkv, w.att, n, m->tokens, c.heads, m->hd, m->attn_scale,
-                                         stream)) != AP_OK) return rc; }
+          if (use_split(m) && n <= 65535) {
+              // float32, split-f16 products: the fused float32 attention of the SAM2 operator set in its split form (image = window,
+              // q | k | v at column offsets of the packed rows) -- same arithmetic class as the GEMMs around it; 46 -> 27.5 ms of a
+              // 2048-tile ViT-B/16 step against the exact-f32 strip kernel (profiles/r06e_split_f16_attention.txt)
+              const float* qp = (const float*)w.qkv;
+              if ((rc = ap::launch_sattention(qp, 3 * DA, qp + DA, 3 * DA, qp + 2 * DA, 3 * DA, n, c.heads, m->tokens, m->tokens, m->hd,
+                                              m->attn_scale, (float*)w.att, DA, stream, /*exact=*/false)) != AP_OK) return rc;
+          } else if ((rc = ap::launch_attention(dt, w.qkv, w.att, n, m->tokens, c.heads, m->hd, m->attn_scale,
+                                                stream)) != AP_OK) return rc; }
         {
             ap::GemmArgs g{};
             g.A = w.att; g.lda = DA; g.W = wsel(m, bp.proj); g.split = use_split(m); g.ldw = bp.proj->ld;

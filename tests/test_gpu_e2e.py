@@ -501,6 +501,49 @@ def test_segment_and_get_coords_on_a_cmu1_shaped_slide(tmp_path):
     assert (coords[:, 2] == 256).all() and (coords[:, 4] == 0).all()
 
 
+def test_process_40k_slide_vit_b16(tmp_path, monkeypatch):
+    """BASELINE config 2 at full size: `process` on one synthetic 40 000 x 40 000 slide, ViT-B/16 (torchvision layout),
+    float16 (the CLI's default feature precision, cli.py:175-181), 1 x MI355X.  Coordinates equal the oracle's row for row;
+    every feature row is finite; sampled rows are bit-equal to a direct `extract_batch` of the same tiles (the tile source,
+    the device batches of 2048 and the H5 writer add no arithmetic) and within 1e-3 norm-wise of the fp32 CPU oracle.
+    The twin of the config-3 test below."""
+    from click.testing import CliRunner
+    from atlaspatch_amd.cli import cli
+    from atlaspatch_amd.core.wsi.synth_pixels import SynthSpec, analytic_mask, render_region
+    from atlaspatch_amd.encoders import build_default_registry
+    from atlaspatch_amd.encoders.vit import ARCHS, random_canonical_state_dict
+    from atlaspatch_amd.utils.h5 import h5
+    from oracle import coords_oracle, vit_oracle
+    monkeypatch.setenv("ATLASPATCH_RANDOM_INIT", "0")
+    slide, raw = _make_slide(str(tmp_path), "c2.synth", width=40000, height=40000, seed=4040)
+    out = tmp_path / "out"
+    res = CliRunner().invoke(cli, ["process", slide, "-o", str(out), "--patch-size", "256", "--target-mag", "20",
+                                   "--feature-extractors", "vit_b_16", "--feature-precision", "float16"], catch_exceptions=False)
+    assert res.exit_code == 0 and "failures: 0" in res.output, res.output
+    spec = SynthSpec(width=40000, height=40000, seed=4040)
+    want_coords, _ = coords_oracle.coords_from_mask(
+        analytic_mask(spec), level0_wh=(40000, 40000), downsamples=[1.0, 4.0, 16.0], src_mag=20, tgt_mag=20,
+        patch_size=256, step_size=None, tissue_thresh=0.0)
+    with h5.File(out / "patches" / "c2.h5", "r") as f:
+        coords = f["coords"][:]
+        feats = f["features"]["vit_b_16"][:]
+        assert f.attrs["level0_width"] == 40000 and f.attrs["patch_size_level0"] == 256
+    n = coords.shape[0]
+    assert n == want_coords.shape[0] and n > 5000 and np.array_equal(coords, want_coords)
+    assert feats.shape == (n, 768) and feats.dtype == np.float32 and np.isfinite(feats).all()
+    rows = np.unique(np.array([0, 1, 2047, 2048, n // 2, n - 2, n - 1]).clip(0, n - 1))
+    tiles = [render_region(spec, int(coords[r, 0]), int(coords[r, 1]), 256, 256, 0) for r in rows]
+    ex = build_default_registry(device="cuda", dtype=torch.float16).create("vit_b_16")
+    direct = ex.extract_batch(tiles, batch_size=32)
+    ex.cleanup()
+    assert np.array_equal(feats[rows], direct)
+    sd = helpers.canonical_to_hf(random_canonical_state_dict(ARCHS["vit_b_16"], 0), 12)
+    want = vit_oracle.extract_batch(sd, tiles, heads=12)
+    rel = np.linalg.norm(feats[rows] - want) / np.linalg.norm(want)
+    print(f"PARITY config 2 (40 000^2, vit_b_16 float16): {n} rows, sampled rows vs fp32 oracle {rel:.3e}")
+    assert rel <= 1e-3, rel
+
+
 def test_process_100k_slide_through_the_host_ring_uni_v1(tmp_path, monkeypatch):
     """BASELINE config 3 at full size: `process` on the 100 000 x 100 000 synthetic slide with uni_v1 (ViT-L/16 +
     LayerScale, float16), tiles produced on HOST threads (the native renderer standing in for a slide decoder), crossing

@@ -47,23 +47,60 @@ def shard(items: Sequence, rank: int, world_size: int) -> list:
     return list(items[rank::max(1, world_size)])
 
 
-def gather_feature_matrix(local: torch.Tensor, group=None) -> list[torch.Tensor]:
-    """All-gather-v of per-rank [N_i, D] float32 blocks; returns the list ordered by rank."""
+GATHER_ALGORITHMS = ("allgather", "pairs")
+
+
+def gather_algorithm() -> str:
+    """``ATLASPATCH_GATHER_ALGO``: ``allgather`` (default: one padded ``all_gather_into_tensor``, whatever schedule RCCL
+    picks) or ``pairs`` (every rank sends its exact block to every peer, one point-to-point transfer per xGMI link, no
+    padding).  Same result; the first 8-GPU run can A/B them against the ~3 ms / link estimate with one variable."""
+    algo = os.environ.get("ATLASPATCH_GATHER_ALGO", "") or "allgather"
+    if algo not in GATHER_ALGORITHMS:
+        raise ValueError(f"ATLASPATCH_GATHER_ALGO={algo!r}: expected one of {GATHER_ALGORITHMS}")
+    return algo
+
+
+def gather_feature_matrix(local: torch.Tensor, group=None, algorithm: Optional[str] = None) -> list[torch.Tensor]:
+    """All-gather-v of per-rank [N_i, D] float32 blocks; returns the list ordered by rank.  A rank without rows may pass
+    any width (``[0, 0]`` included): the width is the largest any rank reports.  ``algorithm``: see ``gather_algorithm``."""
     import torch.distributed as dist
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return [local]
-    world = dist.get_world_size(group)
+    algorithm = algorithm or gather_algorithm()
+    if algorithm not in GATHER_ALGORITHMS:
+        raise ValueError(f"gather_feature_matrix: algorithm {algorithm!r}, expected one of {GATHER_ALGORITHMS}")
+    world, me = dist.get_world_size(group), dist.get_rank(group)
     device = local.device
-    count = torch.tensor([local.shape[0], local.shape[1] if local.dim() == 2 else 0],
+    count = torch.tensor([local.shape[0], local.shape[1] if local.dim() == 2 and local.shape[0] else 0],
                          dtype=torch.int64, device=device)
     counts = [torch.zeros_like(count) for _ in range(world)]
     dist.all_gather(counts, count, group=group)
     rows = [int(c[0].item()) for c in counts]
-    dim = max(int(c[1].item()) for c in counts)
+    dims = {int(c[1].item()) for c in counts if int(c[0].item())}
+    if len(dims) > 1:
+        raise ValueError(f"gather_feature_matrix: ranks hold blocks of different widths {sorted(dims)}")
+    dim = dims.pop() if dims else (local.shape[1] if local.dim() == 2 else 0)
+    mine = local.to(torch.float32).contiguous() if local.shape[0] else torch.zeros((0, dim), dtype=torch.float32, device=device)
+    if algorithm == "pairs":
+        # all-pairs exchange: rank r's exact [N_r, D] block goes to every peer as one point-to-point transfer; a rank without
+        # rows neither sends nor is waited for.  On xGMI every (sender, receiver) pair has its own link.
+        parts = [mine if r == me else torch.empty((rows[r], dim), dtype=torch.float32, device=device) for r in range(world)]
+        ops = []
+        for off in range(1, world):                  # peer order rotated per rank: no two ranks start on the same target
+            peer = (me + off) % world
+            src = (me - off) % world
+            if rows[me]:
+                ops.append(dist.P2POp(dist.isend, mine, peer if group is None else dist.get_global_rank(group, peer), group))
+            if rows[src]:
+                ops.append(dist.P2POp(dist.irecv, parts[src], src if group is None else dist.get_global_rank(group, src), group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        return parts
     width = max(rows) if rows else 0
     padded = torch.zeros((width, dim), dtype=torch.float32, device=device)
-    if local.shape[0]:
-        padded[: local.shape[0]] = local.to(torch.float32)
+    if rows[me]:
+        padded[: rows[me]] = mine
     out = torch.empty((world * width, dim), dtype=torch.float32, device=device)
     if hasattr(dist, "all_gather_into_tensor") and device.type == "cuda":
         dist.all_gather_into_tensor(out, padded, group=group)

@@ -696,6 +696,11 @@ def main():
             dist.init_process_group(backend="nccl", device_id=device)
         world = dist.get_world_size()             # the ranks the process group actually has
         rank = dist.get_rank()
+    if world != args.gpus:
+        # `value` is "the units all ranks processed / time": a line whose n_gpus disagrees with the ranks that ran would be read as
+        # a scaling point it is not (launch with --nproc-per-node = --gpus, or let bench.py re-spawn itself: `python bench.py --gpus N`)
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {world} rank(s) (WORLD_SIZE={os.environ.get('WORLD_SIZE', 'unset')}); "
+                         f"refusing to print a line for a configuration that did not run")
 
     from atlaspatch_amd.encoders.vit import ARCHS, TRANSFORM_RESIZE, build_hip_vit_extractor
 
@@ -720,12 +725,22 @@ def main():
         ex.forward_device(tiles[s:s + B], dst)    # the transform's Resize (uni_v1 / conch_v1) + K1 + encoder
 
     gathered = None
+    gather_algo = None
     if dist is not None:
+        from atlaspatch_amd.orchestration.dispatch import gather_algorithm, gather_feature_matrix
+        gather_algo = gather_algorithm()          # ATLASPATCH_GATHER_ALGO: "allgather" (default) | "pairs" -- the product's two exchanges
         gathered = torch.empty((world * K * B, ex.embedding_dim), dtype=torch.float32, device=device)
+
+    def reassemble():
+        if gather_algo == "pairs":                # every rank's exact block to every peer, one point-to-point transfer per link
+            return gather_feature_matrix(feats, algorithm="pairs")
+        dist.all_gather_into_tensor(gathered, feats)
+        return gathered
+
     for i in range(W):
         step(i, feats[:B])
     if dist is not None and W > 0:                # warm the collective's channels too (untimed, like the W steps)
-        dist.all_gather_into_tensor(gathered, feats)
+        reassemble()
     torch.cuda.synchronize(device)
     ex.vit.profile(True)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
@@ -744,8 +759,9 @@ def main():
     for i in range(K):
         step(i, feats[i * B:(i + 1) * B])
     ev[1].record()
-    if dist is not None:        # reassemble the feature matrix on every rank (north star): one all-gather
-        dist.all_gather_into_tensor(gathered, feats)
+    assembled = None
+    if dist is not None:        # reassemble the feature matrix on every rank (north star): one all-gather (or the all-pairs exchange)
+        assembled = reassemble()
     ev[2].record()
     torch.cuda.synchronize(device)
     if dist is not None:
@@ -770,7 +786,8 @@ def main():
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
     if args.dump_features and rank == 0:
-        np.save(args.dump_features, (gathered if dist is not None else feats).cpu().numpy())
+        whole = feats if dist is None else (torch.cat(assembled, 0) if isinstance(assembled, list) else assembled)
+        np.save(args.dump_features, whole.cpu().numpy())
 
     # Secondary, untimed-for-`value` measurement: the same K steps with the last block computed for every token
     # (option full_last_block), so the line shows what the CLS-only tail is worth.
@@ -944,7 +961,10 @@ def main():
     if per_rank is not None:
         line["per_rank"] = per_rank
         line["all_gather"] = {"bytes_per_rank": int(K * B * ex.embedding_dim * 4), "ms_max_over_ranks": max(r["all_gather_ms"] for r in per_rank),
-                              "what": "one all_gather_into_tensor of every rank's float32 [K*B, D] block, inside the timed region"}
+                              "algorithm": gather_algo,
+                              "what": ("one all_gather_into_tensor of every rank's float32 [K*B, D] block" if gather_algo != "pairs" else
+                                       "all-pairs batch_isend_irecv of every rank's float32 [K*B, D] block (ATLASPATCH_GATHER_ALGO=pairs)")
+                                      + ", inside the timed region"}
     if not args.no_cpu_baseline and world == 1:          # the CPU leg runs at N = 1 only
         sample = args.cpu_sample if args.cpu_sample else {"vit_b_16": 192, "uni_v1": 64, "conch_v1": 32, "vit_b_32": 256,
                                                           "vit_l_32": 128, "vit_h_14": 4, "uni_v2": 24}[args.encoder]

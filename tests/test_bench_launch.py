@@ -77,6 +77,26 @@ def test_gpus_2_without_a_launcher_runs_two_ranks_and_gathers_both_feature_block
         assert single.shape == (2 * 64, 768) and np.isfinite(single).all() and np.abs(single).max() > 0
         assert np.array_equal(gathered[r * 128:(r + 1) * 128], single), f"rank {r}'s block differs from its single-rank run"
     assert not np.array_equal(gathered[:128], gathered[128:])          # the two ranks embedded different slides
+    # the all-pairs exchange (ATLASPATCH_GATHER_ALGO=pairs) assembles the same matrix
+    os.environ["ATLASPATCH_GATHER_ALGO"] = "pairs"
+    try:
+        pairs = _run(["--gpus", "2", "--dump-features", str(tmp_path / "p.npy")] + common)
+    finally:
+        del os.environ["ATLASPATCH_GATHER_ALGO"]
+    assert pairs["all_gather"]["algorithm"] == "pairs" and both["all_gather"]["algorithm"] == "allgather"
+    assert np.array_equal(np.load(tmp_path / "p.npy"), gathered)
+
+
+@pytest.mark.gpu
+def test_a_line_is_refused_when_the_ranks_that_ran_are_not_the_gpus_asked_for():
+    """`--gpus 8` inside a process group of one rank (a launcher given the wrong --nproc-per-node): bench.py exits with a message
+    instead of printing an n_gpus = 8 line measured on one device."""
+    env = {k: v for k, v in os.environ.items() if k not in ("AP_BENCH_BACKEND", "AP_BENCH_ONE_GPU")}
+    env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--steps", "1", "--warmup", "0", "--batch", "16", "--no-extras",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert res.returncode != 0 and "--gpus 8 but the process group has 1 rank" in res.stderr, res.stderr[-2000:]
+    assert not any(ln.startswith("{") for ln in res.stdout.splitlines())
 
 
 @pytest.mark.gpu

@@ -43,6 +43,56 @@ def test_shard_and_gather_world2(tmp_path):
     assert (tmp_path / "ok0.npy").exists() and (tmp_path / "ok1.npy").exists()
 
 
+def _worker_world4(rank, world, port, tmp):
+    import torch.distributed as dist
+    from atlaspatch_amd.orchestration.dispatch import GATHER_ALGORITHMS, gather_feature_matrix
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rows_of = [0, 1, 3, 58938]                            # an empty rank, two tiny ones, one 100 000^2 slide's rows
+        D = 768
+
+        def block(r):
+            g = torch.Generator().manual_seed(100 + r)
+            return torch.randn((rows_of[r], D), generator=g)
+        # the empty rank reports a DIFFERENT width (a rank whose slides all failed knows no D): [0, 0], and [0, 5]
+        for empty_shape in ((0, 0), (0, 5)):
+            local = block(rank) if rows_of[rank] else torch.zeros(empty_shape)
+            got = {}
+            for algo in GATHER_ALGORITHMS:
+                parts = gather_feature_matrix(local, algorithm=algo)
+                assert [tuple(p.shape) for p in parts] == [(n, D) for n in rows_of], (algo, [p.shape for p in parts])
+                for r, p in enumerate(parts):
+                    assert p.dtype == torch.float32 and torch.equal(p, block(r)), (algo, r)
+                got[algo] = parts
+        # every rank empty: nothing to exchange, widths stay what the caller passed
+        for algo in GATHER_ALGORITHMS:
+            parts = gather_feature_matrix(torch.zeros((0, 16)), algorithm=algo)
+            assert [tuple(p.shape) for p in parts] == [(0, 16)] * world
+        # ranks that disagree on the width of NON-empty blocks are an error on every rank, before any payload moves
+        with pytest.raises(ValueError, match="different widths"):
+            gather_feature_matrix(torch.zeros((2, 4 + rank % 2)))
+        np.save(os.path.join(tmp, f"ok{rank}.npy"), np.array([1]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_world4_real_row_counts_both_algorithms(tmp_path, monkeypatch):
+    """Four ranks holding 0 / 1 / 3 / 58 938 rows of 768 floats (an empty rank that reports another width included): the padded
+    all-gather and the all-pairs point-to-point exchange (ATLASPATCH_GATHER_ALGO) both return every rank's exact block."""
+    from atlaspatch_amd.orchestration import dispatch
+    port = _free_port()
+    mp.spawn(_worker_world4, args=(4, port, str(tmp_path)), nprocs=4, join=True)
+    assert all((tmp_path / f"ok{r}.npy").exists() for r in range(4))
+    monkeypatch.setenv("ATLASPATCH_GATHER_ALGO", "pairs")
+    assert dispatch.gather_algorithm() == "pairs"
+    monkeypatch.setenv("ATLASPATCH_GATHER_ALGO", "ring-of-fire")
+    with pytest.raises(ValueError):
+        dispatch.gather_algorithm()
+    monkeypatch.delenv("ATLASPATCH_GATHER_ALGO")
+    assert dispatch.gather_algorithm() == "allgather"
+
+
 def test_runner_shards_slides_one_per_rank(tmp_path):
     import json
     from pathlib import Path

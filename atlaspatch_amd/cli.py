@@ -125,7 +125,8 @@ def _run_pipeline(*, wsi_path, output, patch_size, step_size, target_mag, device
 
     rank, world, local_rank = env_rank_world()
     if gather_features is None:
-        gather_features = bool(os.environ.get("ATLASPATCH_GATHER_FEATURES"))
+        from .utils.env import env_flag
+        gather_features = env_flag("ATLASPATCH_GATHER_FEATURES")
     gather_features = bool(gather_features) and world > 1
     if world > 1 and torch.cuda.is_available():
         torch.cuda.set_device(local_rank)

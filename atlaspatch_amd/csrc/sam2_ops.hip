@@ -52,7 +52,7 @@ struct SgemmArgs {
 template <int TM, int TN, bool WKN, bool VEC>
 __global__ __launch_bounds__(256) void sgemm_mfma_kernel(SgemmArgs g) {
     // KT-deep K tiles: one barrier per 16 MFMA steps and whole 128-byte lines per operand row.  Measured
-    // (tools/sgemm_probe.py): SAM2's mid-size shapes run at 42 - 49 % of the 157 TF/s f32 MFMA peak with either tile size;
+    // (tools/archive/sgemm_probe.py): SAM2's mid-size shapes run at 42 - 49 % of the 157 TF/s f32 MFMA peak with either tile size;
     // large problems reach 67 % (64 x 64) / 77 % (128 x 128).  Tried without effect on the mid sizes: two accumulators per
     // wave instead of one dependent chain (+-0), 16- vs 32-deep K tiles (+3 %), a 128 x 64 tile (-19 %: occupancy), loads
     // hoisted out of branches (+6 %).  MFMA busy 51 % (PMC) with LDS 29 % busy: what is left is the short K loop itself --

@@ -88,7 +88,8 @@ class PatchFeatureEmbeddingService(FeatureEmbeddingService):
         # (h5 path, extractor) -> float32 [N, D] computed in this run; kept only when the rank-sharded gather will use
         # them (--gather-features / ATLASPATCH_GATHER_FEATURES), so that the all-gather does not read the matrices back from disk
         self.feature_blocks: dict = {}
-        self._keep_blocks = bool(os.environ.get("ATLASPATCH_GATHER_FEATURES")) if keep_feature_blocks is None else bool(keep_feature_blocks)
+        from ..utils.env import env_flag
+        self._keep_blocks = env_flag("ATLASPATCH_GATHER_FEATURES") if keep_feature_blocks is None else bool(keep_feature_blocks)
         # embed_all pipelines slides: slide k's feature matrix lands in one of two grow-only pinned buffers and is written to
         # its H5 by a writer thread while slide k + 1 embeds into the other; the first encoder can be built on a side thread
         # while phase 1 (segmentation + coordinates) still runs (prefetch_extractor)

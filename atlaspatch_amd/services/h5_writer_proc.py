@@ -10,7 +10,8 @@ only -- the passports arrive formatted, so the HIP library is not loaded: 0.3 s 
 = the ``H5PatchWriter`` keyword arguments, the output path, the int32 [N, 5] coords and their S160 passports; the child runs the
 very same ``H5PatchWriter.write_coords_array`` -> identical bytes on disk (tests/test_host_logic.py).  Any failure to start or
 talk to a child makes the caller write in-process instead: a child that does not answer within ``ATLASPATCH_H5_PROC_TIMEOUT``
-seconds (default 60: an NFS stall, a stopped process) is killed by a watchdog, which turns the blocked pipe I/O into an error; a
+seconds (default 60, plus one second per 10 000 rows of the job: an NFS stall, a stopped process) is killed by a watchdog, which
+turns the blocked pipe I/O into an error -- its half-written ``.<name>.tmp.<uuid>`` file is removed and the loss is logged; a
 child that REPORTS a write error stays in the pool and the caller retries the write in-process, where the exception (if it is
 real) surfaces with its own traceback; a dead child is replaced in the background, so one failure does not send the rest of the
 run in-process.
@@ -20,6 +21,8 @@ rows * 20 bytes of coords and rows * 160 bytes of passports; reply: 8-byte lengt
 """
 from __future__ import annotations
 
+import glob
+import logging
 import os
 import pickle
 import queue
@@ -55,11 +58,40 @@ def _recv(stream):
     return pickle.loads(_read_exact(stream, n))
 
 
+log = logging.getLogger("atlaspatch_amd.h5_writer_proc")
+
+
 def _timeout() -> float:
     try:
         return max(1.0, float(os.environ.get("ATLASPATCH_H5_PROC_TIMEOUT", "60")))
     except ValueError:
         return 60.0
+
+
+def _job_timeout(rows: int) -> float:
+    """The per-job limit grows with the job: the base (ATLASPATCH_H5_PROC_TIMEOUT) plus one second per 10 000 rows (1.8 MB), so a
+    large coordinate block on a slow but PROGRESSING file system is not mistaken for a hang."""
+    return _timeout() + rows / 10000.0
+
+
+def _start_timeout() -> float:
+    """The hello of a starting child covers an interpreter start, the numpy / libhdf5 imports and a warm-up write: its own,
+    longer limit (ATLASPATCH_H5_PROC_START_TIMEOUT, default max(60, the job limit)) -- a short job limit must not kill a
+    replacement child on a loaded machine."""
+    try:
+        return max(1.0, float(os.environ.get("ATLASPATCH_H5_PROC_START_TIMEOUT", "") or max(60.0, _timeout())))
+    except ValueError:
+        return max(60.0, _timeout())
+
+
+def _remove_leftovers(path: str) -> None:
+    """A child killed mid-write leaves its ``.<name>.tmp.<uuid>`` (utils/h5.py) next to the target: remove them."""
+    folder, base = os.path.split(os.path.abspath(path))
+    for stale in glob.glob(os.path.join(glob.escape(folder), f".{glob.escape(base)}.tmp.*")):
+        try:
+            os.unlink(stale)
+        except OSError:
+            pass
 
 
 class _Watchdog:
@@ -99,7 +131,7 @@ class _Worker:
         self.proc = subprocess.Popen([sys.executable, "-m", "atlaspatch_amd.services.h5_writer_proc"], stdin=subprocess.PIPE,
                                      stdout=subprocess.PIPE, env=env, close_fds=True)
         try:
-            with _Watchdog(self.proc, _timeout()):
+            with _Watchdog(self.proc, _start_timeout()):
                 hello = _recv(self.proc.stdout)
             if hello.get("ready") is not True:
                 raise RuntimeError(f"h5 writer did not start: {hello}")
@@ -111,7 +143,7 @@ class _Worker:
     def write(self, kwargs: dict, path: str, coords: np.ndarray, passports: np.ndarray) -> int:
         """-> rows written; raises ``ChildWriteError`` when the child reports a failed write (it is still healthy), an I/O error
         when the child is gone or was killed by the watchdog."""
-        with _Watchdog(self.proc, _timeout()):
+        with _Watchdog(self.proc, _job_timeout(int(coords.shape[0]))):
             _send(self.proc.stdin, {"kwargs": kwargs, "path": path, "rows": int(coords.shape[0])}, coords.tobytes())
             self.proc.stdin.write(memoryview(passports).cast("B"))
             self.proc.stdin.flush()
@@ -210,20 +242,26 @@ class H5WriterPool:
         try:
             n = w.write(kwargs, path, np.ascontiguousarray(coords, dtype=np.int32).reshape(-1, 5),
                         np.ascontiguousarray(passports))
-        except ChildWriteError:
-            self.child_errors += 1
+        except ChildWriteError as exc:
+            with self._lock:
+                self.child_errors += 1
+            log.warning("h5 writer child could not write %s (%s); writing it in-process", path, exc)
             self._idle.put(w)                         # the child is healthy; the caller repeats the write in-process, where a real
             return None                               # error raises with its own traceback (like every other failure mode here)
-        except (EOFError, BrokenPipeError, OSError, ValueError, struct.error, pickle.UnpicklingError):
+        except (EOFError, BrokenPipeError, OSError, ValueError, struct.error, pickle.UnpicklingError) as exc:
             with self._lock:                          # the child died, hung (watchdog) or desynchronised: replace it
                 self._ready -= 1
                 self.restarts += 1
                 n_restart = self.restarts
+            log.warning("h5 writer child lost while writing %s (%s: %s); writing it in-process, replacing the child", path,
+                        type(exc).__name__, exc)
             w.close()
+            _remove_leftovers(path)                   # what the killed child had written so far
             if not self._closed and n_restart <= 4 * self.workers:      # a child that can never start must not respawn forever
                 self._start_one(f"h5-writer-restart-{n_restart}")
             return None
-        self.jobs += 1
+        with self._lock:
+            self.jobs += 1
         self._idle.put(w)
         return n
 

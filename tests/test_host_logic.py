@@ -782,6 +782,14 @@ def test_h5_writer_pool_survives_a_hung_and_a_dead_child(tmp_path, monkeypatch):
     assert pool.write(mk().to_kwargs(), str(tmp_path / "hung.h5"), coords, mk().passports_array(coords)) is None
     assert 1.0 < time.time() - t0 < 20 and pool.restarts == 1
     assert victim.proc.poll() is not None                                  # reaped, not left stopped
+    assert not list(tmp_path.glob(".hung.h5.tmp.*"))                       # nothing of the killed child's is left beside the target
+    # (the hello of the replacement has its own limit -- ATLASPATCH_H5_PROC_START_TIMEOUT, >= 60 s -- not the 1.5-s job limit)
+    assert hp._start_timeout() >= 60 and abs(hp._job_timeout(20000) - 3.5) < 1e-9
+    (tmp_path / ".x.h5.tmp.deadbeef").write_bytes(b"half a file")
+    (tmp_path / ".x.h5.tmp.cafe").write_bytes(b"another")
+    (tmp_path / ".y.h5.tmp.keep").write_bytes(b"someone else's")
+    hp._remove_leftovers(str(tmp_path / "x.h5"))
+    assert sorted(p.name for p in tmp_path.glob(".*.tmp.*")) == [".y.h5.tmp.keep"]
     assert wait_ready(pool) and not pool.broken                            # the replacement said hello
     assert pool.write(mk().to_kwargs(), str(tmp_path / "after.h5"), coords, mk().passports_array(coords)) == 2
     # a child that dies between jobs
@@ -807,3 +815,21 @@ def test_h5_writer_pool_survives_a_hung_and_a_dead_child(tmp_path, monkeypatch):
     hp._send(proc.stdin, {"quit": True})
     proc.stdin.close()
     assert proc.wait(timeout=30) == 0 and b"libhdf5 says hello" in proc.stderr.read()
+
+
+def test_env_flag_zero_never_switches_a_feature_on(monkeypatch):
+    """ATLASPATCH_GATHER_FEATURES=0 (or false / no / off) must not enable the collective: one parser, both call sites."""
+    from atlaspatch_amd.utils.env import env_flag
+    for raw, want in (("1", True), ("yes", True), ("true", True), ("0", False), ("false", False), ("No", False), ("OFF", False), (" ", False),
+                      ("", False)):
+        monkeypatch.setenv("ATLASPATCH_GATHER_FEATURES", raw)
+        assert env_flag("ATLASPATCH_GATHER_FEATURES") is want, raw
+    monkeypatch.delenv("ATLASPATCH_GATHER_FEATURES")
+    assert env_flag("ATLASPATCH_GATHER_FEATURES") is False and env_flag("ATLASPATCH_GATHER_FEATURES", True) is True
+    import inspect
+    from atlaspatch_amd import cli
+    from atlaspatch_amd.services import feature_embedding
+    for mod in (cli, feature_embedding):
+        src = inspect.getsource(mod)
+        assert 'env_flag("ATLASPATCH_GATHER_FEATURES")' in src and 'os.environ.get("ATLASPATCH_GATHER_FEATURES")' not in src
+

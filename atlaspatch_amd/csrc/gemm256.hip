@@ -72,10 +72,16 @@
 #else
 #define AP_G256_FN(name) name
 #endif
+#ifdef AP_G256_DIAG
+#define AP_G256_DIAG_ON true
+#else
+#define AP_G256_DIAG_ON false
+#endif
 
 namespace ap {
 namespace {
 
+constexpr bool kDiag = AP_G256_DIAG_ON;           // the twin's diagnostics (start skew, time stamps, ablation flags): `if constexpr`, no code in the product
 constexpr int kBM = 256, kBN = 256;
 constexpr int kRowBytes = 128;                    // bytes of K per tile row (64 f16 / bf16)
 constexpr int kUnitBytes = 128 * kRowBytes;       // 16 KiB
@@ -118,18 +124,9 @@ struct Cursor {
 // proj / fc2, which keep the default policy.  sc1 (write through, drop the line) measured the same as nt on qkv and slightly
 // worse elsewhere.  The s_nop: a store of more than 8 bytes followed by a write of its data registers needs wait states
 // that the compiler inserts for its own stores only (without it the 140-case bit-equality check fails).
-#if defined(AP_EXP_STORE_SC1)
-#define AP_STORE_ASM "global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1"
-#else
-#define AP_STORE_ASM "global_store_dwordx4 %0, %1, off nt\n\ts_nop 1"
-#endif
 template <bool NT> __device__ __forceinline__ void out_store16(void* p, u32x4 v) {
-#if defined(AP_EXP_STORE_PLAIN)
-    *(u32x4*)p = v;
-#else
-    if constexpr (NT) asm volatile(AP_STORE_ASM ::"v"(p), "v"(v) : "memory");
+    if constexpr (NT) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
     else *(u32x4*)p = v;
-#endif
 }
 #define AP_OUT_STORE(PTR, V) out_store16<kStoreNT>((PTR), (V))
 
@@ -141,11 +138,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
     constexpr bool kSwiglu = EPI == EPI_NORM_SWIGLU;       // x1 | x2 in the wave's two n blocks -> 32 gated output columns
     constexpr bool kPatch = EPI == EPI_PATCH_STREAM;
     constexpr bool kRes = EPI == EPI_RESID_STATS || kPatch;
-#if defined(AP_EXP_STORE_ALL)
-    constexpr bool kStoreNT = true;
-#else
     constexpr bool kStoreNT = !kRes && EPI != EPI_BIAS_RESID;       // every epilogue whose 16-bit output another kernel reads next
-#endif
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -178,14 +171,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
     // would coincide.  Workgroup j of an XCD starts j / nwx of a tile period late; the early ones are
     // the ones that own one tile more.
     // (diagnostics -- start skew, per-tile time stamps, ablation flags -- exist only under -DAP_G256_DIAG: the twin, impl 257)
-#ifdef AP_G256_DIAG
-    if (g.skew_ticks > 0) {
-        const int nx = gridDim.x < 8 ? gridDim.x : 8;
-        const long long until = (long long)__builtin_amdgcn_s_memrealtime() +
-                                (long long)g.skew_ticks * (int)(blockIdx.x / nx) / tw.stride;
-        while ((long long)__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(16);
+    if constexpr (kDiag) {
+        if (g.skew_ticks > 0) {
+            const int nx = gridDim.x < 8 ? gridDim.x : 8;
+            const long long until = (long long)__builtin_amdgcn_s_memrealtime() +
+                                    (long long)g.skew_ticks * (int)(blockIdx.x / nx) / tw.stride;
+            while ((long long)__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(16);
+        }
     }
-#endif
 
     // ---- staging plan.  Round j of a unit covers unit rows j*64 + wave*8 + (lane >> 3); the lane's
     //      16-byte source chunk is swizzled by the LDS row it lands on.
@@ -216,24 +209,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
         }
     };
     const uint32_t lds_wave = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + wave * 1024;
-#ifdef AP_G256_DIAG
-    bool dma_off = false;
-#endif
+    [[maybe_unused]] bool dma_off = false;
     auto stage = [&](const Cursor& c, bool is_x, int buf, int unit) {
-#ifdef AP_G256_DIAG
-        if ((g.ablate & 4) && dma_off) return;
-#endif
+        if constexpr (kDiag) { if ((g.ablate & 4) && dma_off) return; }
         const char* base = (is_x ? c.abase : c.wbase) + (size_t)c.kt * kRowBytes;
-#ifdef AP_DMA_BUILTIN
-        char* dst = smem + buf * kBufBytes + unit * kUnitBytes + wave * 1024;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (is_x ? c.xo[0] : c.yo[0])),
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (is_x ? c.xo[1] : c.yo[1])),
-                                         (__attribute__((address_space(3))) void*)(dst + 8192), 16, 0, 0);
-#else
         dma_unit(base, is_x ? c.xo[0] : c.yo[0], is_x ? c.xo[1] : c.yo[1],
                  lds_wave + buf * kBufBytes + unit * kUnitBytes);
-#endif
     };
 
     Cursor ca, cb;            // ca: X0 / Y0 stream (two K-tiles ahead), cb: Y1 / X1 stream (one ahead)
@@ -307,45 +288,29 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
     AP_VMCNT(8);              // X0 / Y0 of K-tile 0 have landed (phase 0 reads them)
     __builtin_amdgcn_s_barrier();
     init_acc();
-#ifdef AP_G256_DIAG
-    dma_off = true;
-#endif
+    if constexpr (kDiag) dma_off = true;
 
     // Phase boundary.  The counted wait retires what was staged four phases ago (allowed in flight:
     // the 3 x 2 loads of the last three phases); the barrier publishes it and orders this phase's
     // DMA (issued after it) behind every wave's fragment reads of the unit it overwrites.  The
     // fragment reads written before it may be hoisted by the compiler into the previous phase's
     // MFMA block (everything they read was published by the previous barrier); the wait may not.
-#ifdef AP_G256_DIAG
-    // ablation twin (timing only, results are wrong when a flag is set; ap_gemm impl 257, variant bits 0-2):
+    // ablation twin (-DAP_G256_DIAG; timing only, results are wrong when a flag is set; ap_gemm impl 257, variant bits 0-2):
     // 1 = no counted wait, 2 = no barrier, 4 = no LDS-DMA after the prologue.  Measured (fc2, K = 3072):
     // none 1.005 ms, no wait 1.013, no barrier 0.947, no DMA 0.940, all three 0.812 -> the fragment-read ->
     // MFMA dependence inside a wave, not the synchronisation, bounds this structure at ~1.17 PF/s.
     // A second barrier per phase with the two wave rows half a phase apart (+ s_setprio) was also measured: -1 %.
-    const bool abl_nowait = (g.ablate & 1) != 0, abl_nobar = (g.ablate & 2) != 0;
-#define AP_PHASE_SYNC()                             \
-    __builtin_amdgcn_sched_barrier(0);              \
-    if (wait && !abl_nowait) AP_VMCNT(6);           \
-    __builtin_amdgcn_sched_barrier(0);              \
-    if (!abl_nobar) __builtin_amdgcn_s_barrier();   \
+    [[maybe_unused]] const bool abl_nowait = kDiag && (g.ablate & 1) != 0, abl_nobar = kDiag && (g.ablate & 2) != 0;
+#define AP_PHASE_SYNC()                                       \
+    __builtin_amdgcn_sched_barrier(0);                        \
+    if (wait && !(kDiag && abl_nowait)) AP_VMCNT(6);          \
+    __builtin_amdgcn_sched_barrier(0);                        \
+    if (!(kDiag && abl_nobar)) __builtin_amdgcn_s_barrier();  \
     __builtin_amdgcn_sched_barrier(0)
-#else
-#define AP_PHASE_SYNC()                             \
-    __builtin_amdgcn_sched_barrier(0);              \
-    if (wait) AP_VMCNT(6);                          \
-    __builtin_amdgcn_sched_barrier(0);              \
-    __builtin_amdgcn_s_barrier();                   \
-    __builtin_amdgcn_sched_barrier(0)
-#endif
 #define AP_MMA(ACC, B, A) ACC = Mma<T>::run(B, A, ACC)
-#ifdef AP_NO_READ_HOIST
-#define AP_NOHOIST() __builtin_amdgcn_sched_barrier(0)
-#else
-#define AP_NOHOIST()
-#endif
 
     // (the loop of rounds 2-4: still what EPI_PATCH_STREAM runs -- its epilogue keeps more registers live across the K loop and
-    //  the pipelined form below would spill 5-11 of them -- and, with -DAP_G256_OLD_LOOP, every instantiation, for A/B)
+    //  the pipelined form below would spill 5-11 of them)
     // wait = false only for the first K-tile after an epilogue: everything staged before the epilogue
     // was drained there (vmcnt(0)), so its four phases need no counted wait and the epilogue's own
     // stores keep draining under them.
@@ -353,16 +318,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
         constexpr int BUF = decltype(bufc)::value;
         const char* buf = smem + BUF * kBufBytes;
         // ---------------- phase 0: (X0, Y0), stage Y1 of the next K-tile
-        AP_NOHOIST();
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             fb0[kk] = *(const Frag*)(buf + U_Y0 * kUnitBytes + pb[kk]);
             fa[0][kk] = *(const Frag*)(buf + U_X0 * kUnitBytes + pa[kk]);
-#ifdef AP_ABL_HALF_A
-            fa[1][kk] = fa[0][kk];       // timing probe only (wrong results): the LDS fragment volume of a 128 x 128-per-wave layout
-#else
             fa[1][kk] = *(const Frag*)(buf + U_X0 * kUnitBytes + 32 * kRowBytes + pa[kk]);
-#endif
         }
         AP_PHASE_SYNC();
         AP_MMA(acc[0][0], fb0[0], fa[0][0]); AP_MMA(acc[0][1], fb0[0], fa[1][0]);
@@ -371,7 +331,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
         AP_MMA(acc[0][0], fb0[2], fa[0][2]); AP_MMA(acc[0][1], fb0[2], fa[1][2]);
         AP_MMA(acc[0][0], fb0[3], fa[0][3]); AP_MMA(acc[0][1], fb0[3], fa[1][3]);
         // ---------------- phase 1: (X0, Y1), stage X1 of the next K-tile
-        AP_NOHOIST();
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) fb1[kk] = *(const Frag*)(buf + U_Y1 * kUnitBytes + pb[kk]);
         AP_PHASE_SYNC();
@@ -382,15 +341,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
         AP_MMA(acc[1][0], fb1[2], fa[0][2]); AP_MMA(acc[1][1], fb1[2], fa[1][2]);
         AP_MMA(acc[1][0], fb1[3], fa[0][3]); AP_MMA(acc[1][1], fb1[3], fa[1][3]);
         // ---------------- phase 2: (X1, Y1), stage X0 of the K-tile after next
-        AP_NOHOIST();
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             fa[0][kk] = *(const Frag*)(buf + U_X1 * kUnitBytes + pa[kk]);
-#ifdef AP_ABL_HALF_A
-            fa[1][kk] = fa[0][kk];
-#else
             fa[1][kk] = *(const Frag*)(buf + U_X1 * kUnitBytes + 32 * kRowBytes + pa[kk]);
-#endif
         }
         AP_PHASE_SYNC();
         AP_MMA(acc[1][2], fb1[0], fa[0][0]); AP_MMA(acc[1][3], fb1[0], fa[1][0]);
@@ -408,12 +362,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
         AP_MMA(acc[0][2], fb0[3], fa[0][3]); AP_MMA(acc[0][3], fb0[3], fa[1][3]);
     };
 
-#ifdef AP_G256_OLD_LOOP
-    constexpr bool kOldLoop = true;
-#else
     constexpr bool kOldLoop = kPatch;
-#endif
-    // Software-pipelined fragment reads (round 5; -DAP_G256_OLD_LOOP selects the loop of rounds 2-4 for A/B): the reads of a phase are issued BETWEEN the MFMAs of the phase before it, each as soon
+    // Software-pipelined fragment reads (round 5): the reads of a phase are issued BETWEEN the MFMAs of the phase before it, each as soon
     // as the last MFMA that uses its destination register has been issued (program order pinned with sched_barrier), so every
     // phase opens with MFMAs whose operands arrived long ago instead of with all eight waves' ds_read burst and the
     // latency of its first reply.  Nothing is read earlier than one barrier after the wait that retired its staging (same
@@ -422,15 +372,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
     // tile reads its phase-0 fragments up front (the fragment registers are the epilogue's scratch between tiles);
     // PREFETCH = false: the K-tile that closes a tile reads nothing ahead.
 #define AP_SB() __builtin_amdgcn_sched_barrier(0)
-    // Measured on top of this form and dropped (round 5, profiles/r05b_gemm_twin_ab.txt): barriers only in front of phases 1 and 3
+    // Measured on top of this form and dropped (round 5, profiles/r05_gemm_experiments.txt): barriers only in front of phases 1 and 3
     // (-1 ... +0.5 %: with the operands already in registers the barriers cost nothing -- the twin's no-barrier ablation is
     // SLOWER than the product), and the two waves of a SIMD issuing a phase's LDS-DMA two MFMA pairs apart (+1 ... +3 %).
-#define AP_SYNC_EVEN() AP_PHASE_SYNC()
-#define AP_SYNC_1() AP_PHASE_SYNC()
-#define AP_SYNC_3() AP_PHASE_SYNC()
-#define AP_STAGE_EARLY(...) { __VA_ARGS__; }
-#define AP_STAGE_LATE(...)
-#ifndef AP_G256_NO_ADDR2
     // fragment addresses of both K-tile buffers in registers (the second buffer starts past ds_read's 16-bit offset field:
     // without these every read of it is preceded by a v_add / v_or in the MFMA stream)
     int pa1[4], pb1[4];
@@ -438,12 +382,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
     for (int kk = 0; kk < 4; ++kk) { pa1[kk] = pa[kk] + kBufBytes; pb1[kk] = pb[kk] + kBufBytes; }
 #define AP_PA(B, kk) ((B) ? pa1[kk] : pa[kk])
 #define AP_PB(B, kk) ((B) ? pb1[kk] : pb[kk])
-#define AP_FRAG(B, UNIT_OFF, P) (*(const Frag*)(smem + (UNIT_OFF) + (P)))
-#else
-#define AP_PA(B, kk) ((B) * kBufBytes + pa[kk])
-#define AP_PB(B, kk) ((B) * kBufBytes + pb[kk])
-#define AP_FRAG(B, UNIT_OFF, P) (*(const Frag*)(smem + (UNIT_OFF) + (P)))
-#endif
+#define AP_FRAG(UNIT_OFF, P) (*(const Frag*)(smem + (UNIT_OFF) + (P)))
     [[maybe_unused]] auto ktile_p = [&](auto bufc, auto firstc, auto prefc, const bool wait) {
         constexpr int BUF = decltype(bufc)::value, NBUF = BUF ^ 1;
         constexpr bool FIRST = decltype(firstc)::value, PREFETCH = decltype(prefc)::value;
@@ -451,63 +390,59 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
         if constexpr (FIRST) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                fb0[kk] = AP_FRAG(BUF, U_Y0 * kUnitBytes, AP_PB(BUF, kk));
-                fa[0][kk] = AP_FRAG(BUF, U_X0 * kUnitBytes, AP_PA(BUF, kk));
-                fa[1][kk] = AP_FRAG(BUF, U_X0 * kUnitBytes + 32 * kRowBytes, AP_PA(BUF, kk));
+                fb0[kk] = AP_FRAG(U_Y0 * kUnitBytes, AP_PB(BUF, kk));
+                fa[0][kk] = AP_FRAG(U_X0 * kUnitBytes, AP_PA(BUF, kk));
+                fa[1][kk] = AP_FRAG(U_X0 * kUnitBytes + 32 * kRowBytes, AP_PA(BUF, kk));
             }
         }
-        AP_SYNC_EVEN();
+        AP_PHASE_SYNC();
         AP_MMA(acc[0][0], fb0[0], fa[0][0]); AP_MMA(acc[0][1], fb0[0], fa[1][0]);
-        AP_STAGE_EARLY(stage(cb, false, NBUF, U_Y1));
+        stage(cb, false, NBUF, U_Y1);
         AP_SB();
-        fb1[0] = AP_FRAG(BUF, U_Y1 * kUnitBytes, AP_PB(BUF, 0));
-        fb1[1] = AP_FRAG(BUF, U_Y1 * kUnitBytes, AP_PB(BUF, 1));
+        fb1[0] = AP_FRAG(U_Y1 * kUnitBytes, AP_PB(BUF, 0));
+        fb1[1] = AP_FRAG(U_Y1 * kUnitBytes, AP_PB(BUF, 1));
         AP_SB();
         AP_MMA(acc[0][0], fb0[1], fa[0][1]); AP_MMA(acc[0][1], fb0[1], fa[1][1]);
         AP_SB();
-        fb1[2] = AP_FRAG(BUF, U_Y1 * kUnitBytes, AP_PB(BUF, 2));
-        fb1[3] = AP_FRAG(BUF, U_Y1 * kUnitBytes, AP_PB(BUF, 3));
+        fb1[2] = AP_FRAG(U_Y1 * kUnitBytes, AP_PB(BUF, 2));
+        fb1[3] = AP_FRAG(U_Y1 * kUnitBytes, AP_PB(BUF, 3));
         AP_SB();
         AP_MMA(acc[0][0], fb0[2], fa[0][2]); AP_MMA(acc[0][1], fb0[2], fa[1][2]);
-        AP_STAGE_LATE(stage(cb, false, NBUF, U_Y1));
         AP_MMA(acc[0][0], fb0[3], fa[0][3]); AP_MMA(acc[0][1], fb0[3], fa[1][3]);
         // ---------------- phase 1: (X0, Y1), stage X1 of the next K-tile; read X1 of this one into fa as its registers free up
-        AP_SYNC_1();
+        AP_PHASE_SYNC();
         AP_MMA(acc[1][0], fb1[0], fa[0][0]); AP_MMA(acc[1][1], fb1[0], fa[1][0]);
-        AP_STAGE_EARLY(stage(cb, true, NBUF, U_X1); advance(cb, 1));
+        stage(cb, true, NBUF, U_X1); advance(cb, 1);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             AP_SB();
-            fa[0][kk] = AP_FRAG(BUF, U_X1 * kUnitBytes, AP_PA(BUF, kk));
-            fa[1][kk] = AP_FRAG(BUF, U_X1 * kUnitBytes + 32 * kRowBytes, AP_PA(BUF, kk));
+            fa[0][kk] = AP_FRAG(U_X1 * kUnitBytes, AP_PA(BUF, kk));
+            fa[1][kk] = AP_FRAG(U_X1 * kUnitBytes + 32 * kRowBytes, AP_PA(BUF, kk));
             AP_SB();
             if (kk < 3) { AP_MMA(acc[1][0], fb1[kk + 1], fa[0][kk + 1]); AP_MMA(acc[1][1], fb1[kk + 1], fa[1][kk + 1]); }
-            if (kk == 1) { AP_STAGE_LATE(stage(cb, true, NBUF, U_X1); advance(cb, 1)); }
         }
         // ---------------- phase 2: (X1, Y1), stage X0 of the K-tile after next
-        AP_SYNC_EVEN();
+        AP_PHASE_SYNC();
         AP_MMA(acc[1][2], fb1[0], fa[0][0]); AP_MMA(acc[1][3], fb1[0], fa[1][0]);
-        AP_STAGE_EARLY(stage(ca, true, BUF, U_X0));
+        stage(ca, true, BUF, U_X0);
         AP_SB();
         AP_MMA(acc[1][2], fb1[1], fa[0][1]); AP_MMA(acc[1][3], fb1[1], fa[1][1]);
         AP_MMA(acc[1][2], fb1[2], fa[0][2]); AP_MMA(acc[1][3], fb1[2], fa[1][2]);
-        AP_STAGE_LATE(stage(ca, true, BUF, U_X0));
         AP_MMA(acc[1][2], fb1[3], fa[0][3]); AP_MMA(acc[1][3], fb1[3], fa[1][3]);
         // ---------------- phase 3: (X1, Y0), stage Y0 likewise; read X0 / Y0 of the NEXT K-tile (other buffer)
-        AP_SYNC_3();
+        AP_PHASE_SYNC();
         AP_MMA(acc[0][2], fb0[0], fa[0][0]); AP_MMA(acc[0][3], fb0[0], fa[1][0]);
-        AP_STAGE_EARLY(stage(ca, false, BUF, U_Y0); advance(ca, 0));
+        stage(ca, false, BUF, U_Y0); advance(ca, 0);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             if constexpr (PREFETCH) {
                 AP_SB();
-                fb0[kk] = AP_FRAG(NBUF, U_Y0 * kUnitBytes, AP_PB(NBUF, kk));
-                fa[0][kk] = AP_FRAG(NBUF, U_X0 * kUnitBytes, AP_PA(NBUF, kk));
-                fa[1][kk] = AP_FRAG(NBUF, U_X0 * kUnitBytes + 32 * kRowBytes, AP_PA(NBUF, kk));
+                fb0[kk] = AP_FRAG(U_Y0 * kUnitBytes, AP_PB(NBUF, kk));
+                fa[0][kk] = AP_FRAG(U_X0 * kUnitBytes, AP_PA(NBUF, kk));
+                fa[1][kk] = AP_FRAG(U_X0 * kUnitBytes + 32 * kRowBytes, AP_PA(NBUF, kk));
                 AP_SB();
             }
             if (kk < 3) { AP_MMA(acc[0][2], fb0[kk + 1], fa[0][kk + 1]); AP_MMA(acc[0][3], fb0[kk + 1], fa[1][kk + 1]); }
-            if (kk == 1) { AP_STAGE_LATE(stage(ca, false, BUF, U_Y0); advance(ca, 0)); }
         }
     };
 
@@ -518,20 +453,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
     // the idle epilogue scratch, so that the epilogue's loads hit the L2) made proj 11 % and fc2 1.6 % SLOWER: the window is
     // already served from the XCD's L2 / the Infinity Cache (the previous kernel wrote it), and the extra loads sit in
     // the same queue as the operand stream.
-#ifdef AP_G256_DIAG
     auto stamp = [&](int ti, int k) {
-        if (g.trace && ti < g.trace_tiles && threadIdx.x == 0)
-            g.trace[((size_t)blockIdx.x * g.trace_tiles + ti) * 8 + k] = (long long)__builtin_amdgcn_s_memrealtime();
+        if constexpr (kDiag) {
+            if (g.trace && ti < g.trace_tiles && threadIdx.x == 0)
+                g.trace[((size_t)blockIdx.x * g.trace_tiles + ti) * 8 + k] = (long long)__builtin_amdgcn_s_memrealtime();
+        }
     };
     auto stamp_clk = [&](int ti, int k) {       // shader-clock counter: (slot 6 - slot 5) / (slot 1 - slot 0) = core clock in the main loop
-        if (g.trace && ti < g.trace_tiles && threadIdx.x == 0)
-            g.trace[((size_t)blockIdx.x * g.trace_tiles + ti) * 8 + k] = (long long)__builtin_amdgcn_s_memtime();
+        if constexpr (kDiag) {
+            if (g.trace && ti < g.trace_tiles && threadIdx.x == 0)
+                g.trace[((size_t)blockIdx.x * g.trace_tiles + ti) * 8 + k] = (long long)__builtin_amdgcn_s_memtime();
+        }
     };
-#else
-    auto stamp = [](int, int) {};
-    auto stamp_clk = [](int, int) {};
-#endif
-#ifndef AP_G256_NO_LDSOPS
     // NORM epilogues (round 5; -DAP_G256_NO_LDSOPS restores the loads + drain of rounds 2-4: qkv 4.5 %, fc1 3.2 % slower): this tile's row statistics (128 rows x 8 B), bias and column sums (64 floats each) are brought into the wave's
     // idle epilogue scratch by three LDS-DMA loads at the START of the tile's K loop (older than every staging load that the
     // loop's counted waits leave in flight, so they have landed long before the epilogue), and the epilogue reads them with
@@ -569,15 +502,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
             : "memory");
     };
     if constexpr (kLdsOps) stage_ops(0);
-#else
-    constexpr bool kLdsOps = false;
-#endif
     for (int ti = 0; ti < tw.count; ++ti) {
         stamp(ti, 0);
         stamp_clk(ti, 5);
-#ifndef AP_G256_NO_LDSOPS
         if constexpr (kLdsOps) { if (ti > 0) stage_ops(ti); }
-#endif
         if constexpr (!kOldLoop) {
             using B0 = std::integral_constant<int, 0>; using B1 = std::integral_constant<int, 1>;
             using Y = std::true_type; using N = std::false_type;
@@ -589,12 +517,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
             ktile_p(B1{}, N{}, N{}, true);
         } else {
             for (int kt = 0; kt < nk; kt += 2) {
-#ifdef AP_G256_DIAG
-                // fine timeline (twin only): start of every K-tile pair, in a second [workgroups, tiles, 8] block of the buffer
-                if (g.trace && ti < g.trace_tiles && threadIdx.x == 0 && (kt >> 1) < 8)
-                    g.trace[((size_t)(gridDim.x + blockIdx.x) * g.trace_tiles + ti) * 8 + (kt >> 1)] =
-                        (long long)__builtin_amdgcn_s_memrealtime();
-#endif
+                if constexpr (kDiag) {
+                    // fine timeline (twin only): start of every K-tile pair, in a second [workgroups, tiles, 8] block of the buffer
+                    if (g.trace && ti < g.trace_tiles && threadIdx.x == 0 && (kt >> 1) < 8)
+                        g.trace[((size_t)(gridDim.x + blockIdx.x) * g.trace_tiles + ti) * 8 + (kt >> 1)] =
+                            (long long)__builtin_amdgcn_s_memrealtime();
+                }
                 ktile(std::integral_constant<int, 0>{}, ti == 0 || kt != 0);
                 ktile(std::integral_constant<int, 1>{}, true);
             }
@@ -620,11 +548,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
         // register allocator place such copies in between: seen as a run-to-run race).  vmcnt(0) = 0x0F70 on gfx9
         // (expcnt / lgkmcnt fields left at their maxima).  Only loads are outstanding here.
         bool drain_late = false;
-#ifndef AP_G256_NO_LDSOPS
         if constexpr (kLdsOps) drain_late = tile_uses_lds_ops(tr * kBM);
-#endif
         if (kLdsOps && drain_late) {
-#ifndef AP_G256_NO_LDSOPS
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
@@ -636,7 +561,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) rst[mb] = *(const f32x2*)(scr + (mb * 32 + l31) * 8);
             __builtin_amdgcn_sched_barrier(0);
-#endif
         } else if constexpr (kNorm) {
             // THIS tile's bias, column sums and row statistics
             __builtin_amdgcn_sched_barrier(0);
@@ -740,19 +664,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmArgs g) {
         stamp(ti, 2);
         const bool has_gamma = (EPI == EPI_BIAS_STORE || EPI == EPI_BIAS_RESID) && g.gamma != nullptr;
         const float* gp = g.gamma + n0 + hi * 4;
-#ifdef AP_G256_DIAG
-        if (g.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(ti, 3); }
-#endif
-#ifdef AP_G256_DIAG
-        // ablation bit 8 (timing only): no epilogue body at all (drain and accumulator restart stay) = the bound on what
+        if constexpr (kDiag) { if (g.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(ti, 3); } }
+        // ablation bit 8 (twin, timing only): no epilogue body at all (drain and accumulator restart stay) = the bound on what
         // hiding the epilogue behind another tile's MFMAs could return
-        if (g.ablate & 8) {
+        if (kDiag && (g.ablate & 8)) {
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) asm volatile("" ::"v"(acc[nb][mb]));
         } else
-#endif
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
             if constexpr (EPI == EPI_BIAS_RESID) {
@@ -952,16 +872,15 @@ int AP_G256_FN(launch_gemm256)(int dtype, int epilogue, const GemmArgs& a, int v
     }
     AP_REQUIRE(AP_G256_FN(gemm256_supports)(dtype, epilogue, a), "gemm256: unsupported problem");
     GemmArgs b = a;
-#ifdef AP_G256_DIAG
-    b.trace = g_gemm_trace; b.trace_tiles = g_gemm_trace_tiles;
-    const int skew_pct = (variant >> 4) & 0xfff;
-    const int tiles = ((a.M + kBM - 1) / kBM) * (a.N / kBN);
-    // estimated tile period in 10-ns ticks: ~1.65 us per 64-deep K-tile + epilogue
-    b.skew_ticks = tiles > num_cu ? (int)((long long)((a.K / 64) * 165 + 400) * skew_pct / 100) : 0;
-    b.ablate = variant & 15;
-#else
     b.trace = nullptr; b.trace_tiles = 0; b.skew_ticks = 0; b.ablate = 0;
-#endif
+    if constexpr (kDiag) {
+        b.trace = g_gemm_trace; b.trace_tiles = g_gemm_trace_tiles;
+        const int skew_pct = (variant >> 4) & 0xfff;
+        const int tiles = ((a.M + kBM - 1) / kBM) * (a.N / kBN);
+        // estimated tile period in 10-ns ticks: ~1.65 us per 64-deep K-tile + epilogue
+        b.skew_ticks = tiles > num_cu ? (int)((long long)((a.K / 64) * 165 + 400) * skew_pct / 100) : 0;
+        b.ablate = variant & 15;
+    }
     if ((variant >> 16) & 15) b.walk_cols = (variant >> 16) & 15;
     variant &= 15;
     return dtype == AP_F16 ? launch_typed<f16>(epilogue, b, num_cu, variant, stream)

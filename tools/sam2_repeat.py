@@ -11,10 +11,15 @@ rng = np.random.default_rng(1)
 img = rng.integers(0, 256, (700, 900, 3), dtype=np.uint8)
 img[100:500, 200:700] = (img[100:500, 200:700] // 3 + 120).astype(np.uint8)
 ref = pred.predict_image(img)
-bad = 0
+from PIL import Image
+img1024 = np.asarray(Image.fromarray(img).resize((1024, 1024), Image.Resampling.BILINEAR))
+ref_logits = pred.predict_logits(img1024).clone()            # the float32 logits, bit for bit (a thresholded mask hides small races)
+bad = bad_logits = 0
 for it in range(iters):
     got = pred.predict_image(img)
     if not np.array_equal(np.asarray(got), np.asarray(ref)):
         bad += 1
-print(f"sam2: {bad} of {iters} predictions differ from the first")
-sys.exit(1 if bad else 0)
+    if not torch.equal(pred.predict_logits(img1024), ref_logits):
+        bad_logits += 1
+print(f"sam2: {bad} of {iters} predictions and {bad_logits} of {iters} logit maps differ from the first")
+sys.exit(1 if bad or bad_logits else 0)

@@ -63,15 +63,24 @@ template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf
 // Both GEMM kernels call THIS routine (hipcc contracts the scalar form differently: 1-ulp differences), so the
 // 128x128 and the 256x256 kernel stay bit-identical.
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2_t gelu_sigmoid_poly2(f32x2_t x) {
-    f32x2_t t = x * x;
-    t = f32x2_t{fminf(t[0], 50.0f), fminf(t[1], 50.0f)};
-    f32x2_t p = __builtin_elementwise_fma(t, f32x2_t{1.0148166e-3f, 1.0148166e-3f}, f32x2_t{-1.0677913e-1f, -1.0677913e-1f});
-    p = __builtin_elementwise_fma(t, p, f32x2_t{-2.3011176f, -2.3011176f});
-    const f32x2_t z = x * p;
-    const f32x2_t d = f32x2_t{1.0f, 1.0f} + f32x2_t{__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])};
-    return x * f32x2_t{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+// Round 6: the routine takes xs = x * kGeluS (kGeluS = 1 / sqrt(50)), so that the clamp of t is the packed multiply's CLAMP bit
+//   t' = clamp01(xs * xs) = min(x^2, 50) / 50            (v_pk_mul_f32 ... clamp: no v_min)
+// and everything downstream is re-expressed in xs with the constants rescaled (same instruction count otherwise):
+//   z' = xs * (C0 + C1 t' + C2 t'^2) + log2(s)  =  x p + log2(s),      gelu = xs / (s + 2^z')  =  x / (1 + 2^(x p)).
+// The fused-LayerNorm epilogues produce xs directly (the row's rstd and -mean rstd and the tile's bias registers are
+// multiplied by s once per tile: 24 packed multiplies against 128 v_min per tile and wave); the plain-bias epilogues multiply.
+constexpr float kGeluS = 0.14142135623730950488f;
+__device__ __forceinline__ f32x2_t gelu_sigmoid_poly2_s(f32x2_t xs) {
+    f32x2_t t;
+    asm("v_pk_mul_f32 %0, %1, %1 clamp" : "=v"(t) : "v"(xs));
+    constexpr float c2 = 1.0148166e-3f * 2500.0f / kGeluS, c1 = -1.0677913e-1f * 50.0f / kGeluS, c0 = -2.3011176f / kGeluS;
+    f32x2_t p = __builtin_elementwise_fma(t, f32x2_t{c2, c2}, f32x2_t{c1, c1});
+    p = __builtin_elementwise_fma(t, p, f32x2_t{c0, c0});
+    const f32x2_t z = __builtin_elementwise_fma(xs, p, f32x2_t{-2.8219280948873623f, -2.8219280948873623f});      // + log2(s)
+    const f32x2_t d = f32x2_t{kGeluS, kGeluS} + f32x2_t{__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])};
+    return xs * f32x2_t{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
 }
+__device__ __forceinline__ f32x2_t gelu_sigmoid_poly2(f32x2_t x) { return gelu_sigmoid_poly2_s(x * f32x2_t{kGeluS, kGeluS}); }
 
 // CLIP's QuickGELU (models/patch/clip.py: the OpenAI weights; transformers "quick_gelu"): x * sigmoid(1.702 x), two values, f32
 // (exp2 + rcp; both GEMM kernels call THIS routine)

@@ -351,14 +351,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
         for (int mt = 0; mt < 2; ++mt) {
             const int m = m0 + wave_m * 64 + mt * 32 + l31;
             if (m >= g.M) continue;
-            const float rstd = g.rowstats[2 * (size_t)m], nmr = g.rowstats[2 * (size_t)m + 1];
+            float rstd = g.rowstats[2 * (size_t)m], nmr = g.rowstats[2 * (size_t)m + 1];
+            if constexpr (EPI == EPI_NORM_GELU) { rstd *= kGeluS; nmr *= kGeluS; }      // y * kGeluS for the GELU routine (twin of gemm256)
             const f32x2_t rs2 = {rstd, rstd}, nm2 = {nmr, nmr};
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
                     const int n = n0 + wave_n * 64 + nt * 32 + g4 * 8 + hi * 4;
-                    const f32x4 cs = *(const f32x4*)(g.colsum + n), bb = *(const f32x4*)(g.bias + n);
+                    const f32x4 cs = *(const f32x4*)(g.colsum + n);
+                    f32x4 bb = *(const f32x4*)(g.bias + n);
+                    if constexpr (EPI == EPI_NORM_GELU) bb *= kGeluS;
                     f32x4 v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[nt][mt][g4 * 4 + e];
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
                         __builtin_elementwise_fma(nm2, f32x2_t{cs[2], cs[3]}, f32x2_t{bb[2], bb[3]}));
                     v = f32x4{lo[0], lo[1], hi2[0], hi2[1]};
                     if constexpr (EPI == EPI_NORM_GELU) {
-                        const f32x2_t a = gelu_sigmoid_poly2(f32x2_t{v[0], v[1]}), b = gelu_sigmoid_poly2(f32x2_t{v[2], v[3]});
+                        const f32x2_t a = gelu_sigmoid_poly2_s(f32x2_t{v[0], v[1]}), b = gelu_sigmoid_poly2_s(f32x2_t{v[2], v[3]});
                         v = f32x4{a[0], a[1], b[0], b[1]};
                     }
                     if constexpr (EPI == EPI_NORM_QGELU) {

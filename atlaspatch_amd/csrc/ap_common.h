@@ -57,9 +57,9 @@ template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf
 // (coefficients: minimax fit against 0.5 x (1 + erf(x / sqrt 2)) on [-9, 9], max |error| 2.6e-5,
 // below f16's half-ulp for |gelu| >= 0.06; the clamp keeps the odd polynomial monotone so the
 // sigmoid saturates correctly for any |x|).  -log2(e) is folded into the coefficients:
-// per value 1 min + 3 packed (mul, 2 fma, mul, add, mul over two values) + v_exp_f32 + v_rcp_f32.  The f32 mode uses libm erff.
+// per value 3 packed (mul, 2 fma, fma, add, mul over two values) + v_exp_f32 + v_rcp_f32 (rounds 1-5: + 1 v_min, see below).  The f32 mode uses libm erff.
 // Evaluated two values at a time with the full-rate operations packed two per instruction (v_pk_mul_f32 /
-// v_pk_fma_f32 / v_pk_add_f32); min, exp and rcp have no packed form.  The fc1 epilogue is VALU-bound on this.
+// v_pk_fma_f32 / v_pk_add_f32); exp and rcp have no packed form.  The fc1 epilogue is VALU-bound on this.
 // Both GEMM kernels call THIS routine (hipcc contracts the scalar form differently: 1-ulp differences), so the
 // 128x128 and the 256x256 kernel stay bit-identical.
 typedef float f32x2_t __attribute__((ext_vector_type(2)));

@@ -1,5 +1,5 @@
 import os, sys, json
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from atlaspatch_amd.encoders.vit import build_hip_vit_extractor
 dev = torch.device("cuda:0")

@@ -82,7 +82,7 @@ class HipViTFeatureExtractor(FeatureExtractor):
         self.device = vit.device
         self._resamplers: dict = {}
 
-    def _prepare(self, patches: Sequence) -> np.ndarray:
+    def _validated(self, patches: Sequence) -> list:
         arrs = [_as_uint8_hwc(p) for p in patches]
         shape0 = arrs[0].shape
         if any(a.shape != shape0 for a in arrs):
@@ -92,18 +92,38 @@ class HipViTFeatureExtractor(FeatureExtractor):
             raise ValueError(
                 f"{self.name}: the device preprocess implements the reference transform for "
                 f"{self.expect_size}x{self.expect_size} tiles only (got {shape0[1]}x{shape0[0]})")
-        # gathered straight into a grow-only PINNED buffer (what np.stack would cost, but the H2D copy that follows runs at
-        # the pinned rate instead of through the driver's staging buffer).  Safe to reuse: extract_batch ends with a
-        # synchronous D2H, so every copy out of this buffer has completed when the next call fills it.
-        n = len(arrs)
+        return arrs
+
+    def _prepare(self, patches: Sequence) -> np.ndarray:
+        """The validated patches gathered into the grow-only PINNED buffer (what np.stack would cost, but the H2D copy that
+        follows runs at the pinned rate instead of through the driver's staging buffer).  Safe to reuse: extract_batch ends
+        with a synchronous D2H, so every copy out of this buffer has completed when the next call fills it."""
+        arrs = self._validated(patches)
+        view = self._pinned_view(len(arrs), arrs[0].shape)
+        for i, a in enumerate(arrs):
+            view[i] = a
+        return view
+
+    def _pinned_view(self, n: int, shape0) -> np.ndarray:
         need = n * int(np.prod(shape0))
         pin = getattr(self, "_pin", None)
         if pin is None or pin.numel() < need:
             self._pin = pin = torch.empty(need, dtype=torch.uint8, pin_memory=True)
-        view = pin[:need].view(n, *shape0).numpy()
-        for i, a in enumerate(arrs):
-            view[i] = a
-        return view
+        return pin[:need].view(n, *shape0).numpy()
+
+    UPLOAD_CHUNK = 8        # tiles per gather + H2D piece (1.5 MB at 256 x 256: the copy engine starts while the host still gathers)
+
+    def _upload(self, arrs: list, dev: torch.Tensor) -> None:
+        """arrs -> dev (uint8 [n, H, W, 3] on the device) through the pinned buffer, in pieces: the H2D copy of piece k runs
+        while the host gathers piece k + 1 (a 32-patch call: 0.12 ms of gather + 0.19 ms of copy one after the other before)."""
+        n = len(arrs)
+        view = self._pinned_view(n, arrs[0].shape)
+        pin = torch.from_numpy(view)
+        for s in range(0, n, self.UPLOAD_CHUNK):
+            e = min(n, s + self.UPLOAD_CHUNK)
+            for i in range(s, e):
+                view[i] = arrs[i]
+            dev[s:e].copy_(pin[s:e], non_blocking=True)
 
     def resized(self, tiles_u8: torch.Tensor) -> torch.Tensor:
         """The transform's leading ``Resize`` on a device batch uint8 [n, H, W, 3] (identity when absent)."""
@@ -134,15 +154,20 @@ class HipViTFeatureExtractor(FeatureExtractor):
                       batch_size: Optional[int] = None) -> np.ndarray:
         if not patches:
             return np.empty((0, self.embedding_dim), dtype=np.float32)
-        host = torch.from_numpy(self._prepare(patches))
-        n = host.shape[0]
+        arrs = self._validated(patches)
+        n = len(arrs)
         # the reference runs chunks of min(len, batch_size) (base.py:83); results are identical
         # for any chunking because every image is independent, so use the larger device chunk
         step = max(1, min(n, self.max_batch))
         out = torch.empty((n, self.embedding_dim), dtype=torch.float32, device=self.device)
-        for s in range(0, n, step):
-            dev = host[s:s + step].to(self.device, non_blocking=True)      # pinned source (see _prepare)
-            self.forward_device(dev, out[s:s + step])
+        with torch.cuda.device(self.device):
+            for s in range(0, n, step):
+                part = arrs[s:s + step]
+                dev = torch.empty((len(part), *part[0].shape), dtype=torch.uint8, device=self.device)
+                if s:
+                    torch.cuda.current_stream(self.device).synchronize()    # the pinned buffer is reused: its copies must have left
+                self._upload(part, dev)                                      # pinned source, pieces overlapped with the gather
+                self.forward_device(dev, out[s:s + step])
         return out.cpu().numpy()
 
     @torch.inference_mode()

@@ -1,5 +1,5 @@
 import sys, time, numpy as np, torch
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from atlaspatch_amd.encoders.vit import build_hip_vit_extractor
 ex = build_hip_vit_extractor(name="vit_b_16", arch="vit_b_16", device=torch.device("cuda:0"), dtype=torch.float16, random_init_seed=0, max_batch=2048)
 rng = np.random.default_rng(0)
